@@ -1,0 +1,84 @@
+"""ctypes binding of libenslam_hip.so (include/enslam_hip.h).  No torch types cross this boundary:
+device pointers as integers, sizes, a hipStream_t.  Fails loudly when the library is missing."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int32, c_int64, c_size_t, c_void_p
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libenslam_hip.so")
+
+STAGE = {'coarse': 0, 'middle': 1, 'fine': 2, 'color': 3}
+MLP_COARSE, MLP_MIDDLE, MLP_FINE, MLP_COLOR = 0, 1, 2, 3
+MLP_NAMES = ('coarse_decoder', 'middle_decoder', 'fine_decoder', 'color_decoder')
+GRID_NAMES = ('grid_coarse', 'grid_middle', 'grid_fine', 'grid_color')
+# grids / decoders read by each stage (NICE.forward, decoder.py:312-342); fine reads grid_middle twice
+STAGE_KINDS = {'coarse': (0,), 'middle': (1,), 'fine': (1, 2), 'color': (1, 2, 3)}
+
+
+class MlpParams(ctypes.Structure):
+    _fields_ = [("W", c_void_p * 5), ("b", c_void_p * 5), ("Wc", c_void_p * 5), ("bc", c_void_p * 5),
+                ("Wo", c_void_p), ("bo", c_void_p), ("B", c_void_p)]
+
+
+class Grid(ctypes.Structure):
+    _fields_ = [("data", c_void_p), ("D", c_int32), ("H", c_int32), ("W", c_int32)]
+
+
+class Scene(ctypes.Structure):
+    _fields_ = [("bound", c_double * 6), ("coarse_bound", c_double * 6), ("grids", Grid * 4),
+                ("packed", c_void_p * 4)]
+
+
+class EnslamError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGS = {
+    "enslam_abi_version": (ctypes.c_int, []),
+    "enslam_arch": (c_char_p, []),
+    "enslam_packed_floats": (c_size_t, [ctypes.c_int]),
+    "enslam_packed_grad_floats": (c_size_t, [ctypes.c_int]),
+    "enslam_pack_mlp": (ctypes.c_int, [ctypes.c_int, POINTER(MlpParams), c_void_p, c_void_p]),
+    "enslam_unpack_mlp_grads": (ctypes.c_int, [ctypes.c_int, c_void_p, POINTER(MlpParams), c_void_p]),
+    "enslam_grid_to_voxel_major": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "enslam_grid_from_voxel_major": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "enslam_sample_rays": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                          POINTER(c_double), c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                          c_void_p, c_void_p]),
+    "enslam_render_fwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "enslam_eval_points": (ctypes.c_int, [c_int32, c_int64, c_void_p, POINTER(Scene), c_int32, c_void_p, c_void_p]),
+    "enslam_render_bwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Grid),
+                                         POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "enslam_voxel_index": (ctypes.c_int, [c_int64, c_void_p, POINTER(c_double), c_int32, c_int32, c_int32,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "enslam_ray_points": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(c_double),
+                                         c_void_p, c_void_p, c_void_p]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """The loaded library; raises EnslamError if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EnslamError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                              f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.enslam_abi_version() != 1:
+            raise EnslamError("libenslam_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise EnslamError(f"{what} failed with code {code} "
+                          f"({ {-1: 'EINVAL', -2: 'ELAUNCH', -3: 'EUNSUPPORTED'}.get(code, '?')})")

@@ -1,0 +1,70 @@
+"""Ray generation and pixel sampling (reference: src/common.py:74-107,130-169,300-340).
+
+These are a handful of tiny, differentiable-in-c2w PyTorch-ROCm ops (<1 % of a step) and the
+only RNG draw on the path: they stay in PyTorch so that `torch.randint` consumes the caller's generator
+exactly as the reference does (bit-exact sample indices), and so pose gradients flow through autograd."""
+import numpy as np
+import torch
+
+
+def get_rays_from_uv(i, j, c2w, H, W, fx, fy, cx, cy, device):
+    """Rays through pixels (i = column, j = row): rays_d = R @ [(i-cx)/fx, -(j-cy)/fy, -1], rays_o = t."""
+    if isinstance(c2w, np.ndarray):
+        c2w = torch.from_numpy(c2w).to(device)
+    dirs = torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)], -1).to(device)
+    rays_d = (dirs.reshape(-1, 1, 3) * c2w[:3, :3]).sum(-1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def select_uv(i, j, n, depth, color, device='cuda:0'):
+    """n uniformly drawn pixels (with replacement) of the flattened window."""
+    i, j = i.reshape(-1), j.reshape(-1)
+    idx = torch.randint(i.shape[0], (n,), device=device)
+    return i[idx], j[idx], depth.reshape(-1)[idx], color.reshape(-1, 3)[idx]
+
+
+def get_sample_uv(H0, H1, W0, W1, n, depth, color, device='cuda:0'):
+    cols = torch.linspace(W0, W1 - 1, W1 - W0).to(device)
+    rows = torch.linspace(H0, H1 - 1, H1 - H0).to(device)
+    j, i = torch.meshgrid(rows, cols, indexing='ij')
+    return select_uv(i, j, n, depth[H0:H1, W0:W1], color[H0:H1, W0:W1], device=device)
+
+
+def get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2w, depth, color, device):
+    """n rays from the image window [H0,H1) x [W0,W1) with their depth / colour samples."""
+    i, j, d, c = get_sample_uv(H0, H1, W0, W1, n, depth, color, device=device)
+    rays_o, rays_d = get_rays_from_uv(i, j, c2w, H, W, fx, fy, cx, cy, device)
+    return rays_o, rays_d, d, c
+
+
+def _image_rays(H, W, new_H, new_W, fx, fy, cx, cy, c2w, device):
+    if isinstance(c2w, np.ndarray):
+        c2w = torch.from_numpy(c2w)
+    cols = torch.linspace(0, W - 1, new_W)
+    rows = torch.linspace(0, H - 1, new_H)
+    j, i = torch.meshgrid(rows, cols, indexing='ij')
+    dirs = torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)], -1).to(device)
+    c2w = c2w.to(device)
+    rays_d = (dirs.reshape(new_H, new_W, 1, 3) * c2w[:3, :3]).sum(-1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def get_rays(H, W, fx, fy, cx, cy, c2w, device):
+    """Rays of the whole image, [H,W,3] each."""
+    return _image_rays(H, W, H, W, fx, fy, cx, cy, c2w, device)
+
+
+def get_rays_rescale(H, W, new_H, new_W, fx, fy, cx, cy, c2w, device):
+    """Rays of the image strided down to (new_H,new_W) pixel centres (not averaged)."""
+    return _image_rays(H, W, new_H, new_W, fx, fy, cx, cy, c2w, device)
+
+
+def normalize_3d_coordinate(p, bound):
+    """[-1,1] coordinates of p inside bound (float64 arithmetic when p is float64)."""
+    p = p.reshape(-1, 3)
+    out = torch.empty_like(p)
+    for a in range(3):
+        out[:, a] = ((p[:, a] - bound[a, 0]) / (bound[a, 1] - bound[a, 0])) * 2 - 1.0
+    return out

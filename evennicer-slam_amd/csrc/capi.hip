@@ -1,0 +1,216 @@
+// extern "C" surface of libenslam_hip.so (declared in include/enslam_hip.h).
+// Host-only logic: argument validation, decoder re-layout tables, struct marshalling.
+#include "../../include/enslam_hip.h"
+#include "kernels.hpp"
+
+namespace {
+
+bool is_xyz(int kind) { return kind == ENSLAM_MLP_MIDDLE || kind == ENSLAM_MLP_FINE || kind == ENSLAM_MLP_COLOR; }
+int cdim(int kind) { return kind == ENSLAM_MLP_FINE ? 64 : 32; }
+int nout(int kind) { return kind == ENSLAM_MLP_COLOR ? 4 : 1; }
+
+void add(PackJob& j, float* src, int off, int rows, int cols, int src_ld, int dst_ld, int tr) {
+    if (src == nullptr || j.n >= ENS_MAX_SEGS) return;
+    j.seg[j.n++] = PackSeg{src, off, rows, cols, src_ld, dst_ld, tr};
+}
+
+// Build the segment table of one decoder.  `with_transposed` adds the backward-only copies.
+// Returns false when a required pointer is missing.
+bool build_job(int kind, const enslam_mlp_params& P, bool with_transposed, PackJob& j) {
+    j.n = 0;
+    if (is_xyz(kind)) {
+        const XyzLay L{cdim(kind)};
+        const int CD = cdim(kind), NO = nout(kind);
+        const int kin[5] = {93, 32, 32, 125, 32};
+        add(j, P.B, L.oBT(), 93, 3, 93, 4, 1);                                  // BT[f][k] = B[k][f]
+        for (int i = 0; i < 5; ++i) {
+            if (i == 3) {
+                add(j, P.W[3], L.oW(3), 32, 93, 125, 128, 0);                     // embedding columns
+                add(j, P.W[3] ? P.W[3] + 93 : nullptr, L.oW(3) + 96, 32, 32, 125, 128, 0);   // h2 columns
+            } else {
+                add(j, P.W[i], L.oW(i), 32, kin[i], kin[i], L.K(i), 0);
+            }
+            add(j, P.b[i], L.ob(i), 1, 32, 32, 32, 0);
+            add(j, P.Wc[i], L.oWc(i), 32, CD, CD, CD, 0);
+            add(j, P.bc[i], L.obc(i), 1, 32, 32, 32, 0);
+        }
+        add(j, P.Wo, L.oWo(), NO, 32, 32, 32, 0);
+        add(j, P.bo, L.obo(), 1, NO, NO, 16, 0);
+        if (with_transposed) {
+            for (int i = 0; i < 5; ++i) {
+                if (i == 3) {
+                    add(j, P.W[3], L.oWT(3), 93, 32, 125, 32, 1);
+                    add(j, P.W[3] ? P.W[3] + 93 : nullptr, L.oWT(3) + 96 * 32, 32, 32, 125, 32, 1);
+                } else {
+                    add(j, P.W[i], L.oWT(i), kin[i], 32, kin[i], 32, 1);
+                }
+                add(j, P.Wc[i], L.oWcT(i), 32, 32, CD, 32, 1);                   // grid channels only
+            }
+            add(j, P.Wo, L.oWoT(), 32, NO, 32, 4, 1);
+            add(j, P.B, L.oBp(), 3, 93, 93, 96, 0);
+        }
+        const int need = with_transposed ? 24 + 13 : 24;
+        return j.n == need;
+    }
+    if (kind == ENSLAM_MLP_COARSE) {
+        const FeatLay L{};
+        const int kin[5] = {32, 32, 32, 64, 32};
+        for (int i = 0; i < 5; ++i) {
+            add(j, P.W[i], L.oW(i), 32, kin[i], kin[i], L.K(i), 0);
+            add(j, P.b[i], L.ob(i), 1, 32, 32, 32, 0);
+        }
+        add(j, P.Wo, L.oWo(), 1, 32, 32, 32, 0);
+        add(j, P.bo, L.obo(), 1, 1, 1, 16, 0);
+        if (with_transposed) {
+            for (int i = 0; i < 5; ++i) add(j, P.W[i], L.oWT(i), kin[i], 32, kin[i], 32, 1);
+            add(j, P.Wo, L.oWoT(), 32, 1, 32, 4, 1);
+        }
+        return j.n == (with_transposed ? 12 + 6 : 12);
+    }
+    return false;
+}
+
+bool to_dev_scene(const enslam_scene* s, DevScene& d) {
+    if (s == nullptr) return false;
+    for (int a = 0; a < 3; ++a) {
+        d.lo[a] = s->bound[2 * a]; d.hi[a] = s->bound[2 * a + 1];
+        d.clo[a] = s->coarse_bound[2 * a]; d.chi[a] = s->coarse_bound[2 * a + 1];
+    }
+    for (int k = 0; k < 4; ++k) {
+        d.grid[k] = DevGrid{s->grids[k].data, s->grids[k].D, s->grids[k].H, s->grids[k].W};
+        d.packed[k] = s->packed[k];
+    }
+    return true;
+}
+
+// which grids / decoders a stage reads (NICE.forward, decoder.py:312-342)
+bool stage_ok(int stage, const DevScene& d) {
+    auto has = [&](int k) { return d.grid[k].data != nullptr && d.packed[k] != nullptr && d.grid[k].D > 0 &&
+                                   d.grid[k].H > 0 && d.grid[k].W > 0; };
+    switch (stage) {
+        case ENSLAM_STAGE_COARSE: return has(0);
+        case ENSLAM_STAGE_MIDDLE: return has(1);
+        case ENSLAM_STAGE_FINE: return has(1) && has(2);
+        case ENSLAM_STAGE_COLOR: return has(1) && has(2) && has(3);
+        default: return false;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int enslam_abi_version(void) { return ENSLAM_ABI_VERSION; }
+const char* enslam_arch(void) { return "gfx950"; }
+
+size_t enslam_packed_floats(int kind) {
+    if (is_xyz(kind)) return (size_t)XyzLay{cdim(kind)}.total();
+    if (kind == ENSLAM_MLP_COARSE) return (size_t)FeatLay{}.total();
+    return 0;
+}
+size_t enslam_packed_grad_floats(int kind) {
+    if (is_xyz(kind)) return (size_t)XyzLay{cdim(kind)}.fwd_floats();
+    if (kind == ENSLAM_MLP_COARSE) return (size_t)FeatLay{}.fwd_floats();
+    return 0;
+}
+
+int enslam_pack_mlp(int kind, const enslam_mlp_params* params, float* packed, void* stream) {
+    if (params == nullptr || packed == nullptr) return ENSLAM_EINVAL;
+    PackJob job;
+    if (!build_job(kind, *params, true, job)) return ENSLAM_EINVAL;
+    return ens_launch_pack(job, packed, false, (hipStream_t)stream);
+}
+
+int enslam_unpack_mlp_grads(int kind, const float* packed_grad, const enslam_mlp_params* grads, void* stream) {
+    if (grads == nullptr || packed_grad == nullptr) return ENSLAM_EINVAL;
+    if (!is_xyz(kind) && kind != ENSLAM_MLP_COARSE) return ENSLAM_EINVAL;
+    PackJob job;
+    build_job(kind, *grads, false, job);        // NULL outputs are simply skipped
+    return ens_launch_pack(job, const_cast<float*>(packed_grad), true, (hipStream_t)stream);
+}
+
+int enslam_grid_to_voxel_major(const float* src, float* dst, int64_t n_voxels, void* stream) {
+    if (src == nullptr || dst == nullptr || n_voxels < 0) return ENSLAM_EINVAL;
+    return ens_launch_transpose(src, dst, n_voxels, true, (hipStream_t)stream);
+}
+int enslam_grid_from_voxel_major(const float* src, float* dst, int64_t n_voxels, void* stream) {
+    if (src == nullptr || dst == nullptr || n_voxels < 0) return ENSLAM_EINVAL;
+    return ens_launch_transpose(src, dst, n_voxels, false, (hipStream_t)stream);
+}
+
+int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const float* rays_o, const float* rays_d,
+                       const float* gt_depth, const double* bound_host, const float* t_lin, const double* t_surf,
+                       int32_t lindisp, const float* t_rand, float* scratch, double* z_vals, void* stream) {
+    if (n_rays < 0 || n_lin < 1 || n_surf < 0) return ENSLAM_EINVAL;
+    if (n_rays == 0) return ENSLAM_OK;
+    if (!rays_o || !rays_d || !bound_host || !t_lin || !z_vals) return ENSLAM_EINVAL;
+    if (gt_depth != nullptr && (scratch == nullptr || (n_surf > 0 && t_surf == nullptr))) return ENSLAM_EINVAL;
+    return ens_launch_sample(n_rays, n_lin, n_surf, rays_o, rays_d, gt_depth, bound_host, t_lin, t_surf, lindisp,
+                             t_rand, scratch, z_vals, (hipStream_t)stream);
+}
+
+int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                      const double* z_vals, const enslam_scene* scene, double* depth, double* var, float* rgb,
+                      float* raw_out, void* stream) {
+    if (n_rays < 0) return ENSLAM_EINVAL;
+    if (n_rays == 0) return ENSLAM_OK;
+    if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
+    DevScene d;
+    if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
+    if (!rays_o || !rays_d || !z_vals || !depth || !var || !rgb) return ENSLAM_EINVAL;
+    return ens_launch_render_fwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, nullptr, 0, 1, d, depth, var,
+                                 rgb, raw_out, (hipStream_t)stream);
+}
+
+int enslam_eval_points(int32_t stage, int64_t n_points, const double* points, const enslam_scene* scene,
+                       int32_t apply_mask, float* raw_out, void* stream) {
+    if (n_points < 0) return ENSLAM_EINVAL;
+    if (n_points == 0) return ENSLAM_OK;
+    DevScene d;
+    if (!to_dev_scene(scene, d) || !stage_ok(stage, d) || !points || !raw_out) return ENSLAM_EINVAL;
+    const int64_t units = (n_points + 47) / 48;
+    return ens_launch_render_fwd(stage, 3, units, nullptr, nullptr, nullptr, points, n_points, apply_mask, d, nullptr,
+                                 nullptr, nullptr, raw_out, (hipStream_t)stream);
+}
+
+int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                      const double* z_vals, const enslam_scene* scene, const float* raw, const double* depth,
+                      const double* g_depth, const double* g_var, const float* g_rgb, const enslam_grid* grad_grids,
+                      float* const* grad_packed, float* g_rays_o, float* g_rays_d, float* d_raw, void* stream) {
+    if (n_rays < 0) return ENSLAM_EINVAL;
+    if (n_rays == 0) return ENSLAM_OK;
+    if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
+    DevScene d;
+    if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
+    if (!rays_o || !rays_d || !z_vals || !raw || !depth || !d_raw || !grad_grids || !grad_packed) return ENSLAM_EINVAL;
+    if (!g_depth && !g_var && !g_rgb) return ENSLAM_EINVAL;
+    DevGrid gg[4];
+    for (int k = 0; k < 4; ++k) {
+        gg[k] = DevGrid{grad_grids[k].data, d.grid[k].D, d.grid[k].H, d.grid[k].W};
+        if (grad_grids[k].data != nullptr &&
+            (grad_grids[k].D != d.grid[k].D || grad_grids[k].H != d.grid[k].H || grad_grids[k].W != d.grid[k].W))
+            return ENSLAM_EINVAL;
+    }
+    return ens_launch_render_bwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, raw, depth, g_depth, g_var,
+                                 g_rgb, gg, grad_packed, g_rays_o, g_rays_d, d_raw, (hipStream_t)stream);
+}
+
+int enslam_voxel_index(int64_t n_points, const double* points, const double* bound_host, int32_t D, int32_t H,
+                       int32_t W, int32_t* ix, int32_t* iy, int32_t* iz, float* fx, float* fy, float* fz,
+                       void* stream) {
+    if (n_points < 0 || D < 1 || H < 1 || W < 1) return ENSLAM_EINVAL;
+    if (n_points == 0) return ENSLAM_OK;
+    if (!points || !bound_host || !ix || !iy || !iz || !fx || !fy || !fz) return ENSLAM_EINVAL;
+    return ens_launch_voxel_index(n_points, points, bound_host, D, H, W, ix, iy, iz, fx, fy, fz, (hipStream_t)stream);
+}
+
+int enslam_ray_points(int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                      const double* z_vals, const double* bound_host, double* points, uint8_t* mask, void* stream) {
+    if (n_rays < 0 || n_samples < 1) return ENSLAM_EINVAL;
+    if (n_rays == 0) return ENSLAM_OK;
+    if (!rays_o || !rays_d || !z_vals || !bound_host || !points || !mask) return ENSLAM_EINVAL;
+    return ens_launch_ray_points(n_rays, n_samples, rays_o, rays_d, z_vals, bound_host, points, mask,
+                                 (hipStream_t)stream);
+}
+
+}  // extern "C"

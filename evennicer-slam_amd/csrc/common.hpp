@@ -1,0 +1,218 @@
+// Shared device helpers for the gfx950 rendering kernels.
+//
+// Register-tile convention used everywhere ("D layout" of v_mfma_f32_16x16x4_f32):
+//   lane = 16*q + p  (p = lane & 15, q = lane >> 4)
+//   an activation tile  f32x4 x[t]  holds, for sample point p of the tile,
+//   features 16*t + 4*q + r  in component r.
+// This is what the MFMA writes as C/D (col = lane&15, row = 4*(lane>>4)+reg), and it is also a valid
+// B operand of the next layer when the K order is permuted to (t, r): at step (t,r) k-slot q carries
+// feature 16t+4q+r.  The matching A operand (weights, row i = lane&15 of the output tile) is then the
+// 4 consecutive floats  W[16*rt + i][16*t + 4*q .. +3]  of a row-major weight matrix, i.e. one 16-byte
+// load per lane per 4 MFMAs, with no packing beyond zero-padding K to a multiple of 16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ENS_DEV __device__ __forceinline__
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+ENS_DEV f32x4 ld4(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
+ENS_DEV f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+ENS_DEV f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+
+// ----------------------------------------------------------------------------------------------
+// Packed decoder layouts (float offsets).  Forward section first (the gradient accumulator has the
+// same layout and size), then the transposed copies the backward chain reads.
+// ----------------------------------------------------------------------------------------------
+struct XyzLay {                 // MLP (middle / fine / color): decoder.py:91-203
+    int CD;                     // fc_c input width: 32, fine 64
+    constexpr int K(int i) const { return i == 0 ? 96 : (i == 3 ? 128 : 32); }   // padded pts_linears input width
+    constexpr int oBT() const { return 0; }                                        // [96][4]  B^T (rows >=93, col 3 zero)
+    constexpr int oW(int i) const {
+        int o = 384;
+        for (int j = 0; j < i; ++j) o += 32 * K(j) + 32 + 32 * CD + 32;
+        return o;
+    }
+    constexpr int ob(int i) const { return oW(i) + 32 * K(i); }
+    constexpr int oWc(int i) const { return ob(i) + 32; }
+    constexpr int obc(int i) const { return oWc(i) + 32 * CD; }
+    constexpr int oWo() const { return oW(5); }                                    // [16][32], rows >= n_out zero
+    constexpr int obo() const { return oWo() + 512; }                              // [16]
+    constexpr int fwd_floats() const { return obo() + 16; }
+    constexpr int oWT(int i) const {                                               // [K(i)][32]
+        int o = fwd_floats();
+        for (int j = 0; j < i; ++j) o += 32 * K(j);
+        return o;
+    }
+    constexpr int oWcT(int i) const { return oWT(5) + i * 1024; }                  // [32][32] grid channels only
+    constexpr int oWoT() const { return oWcT(5); }                                 // [32][4]
+    constexpr int oBp() const { return oWoT() + 128; }                             // [16][96] rows 0..2 = B
+    constexpr int total() const { return oBp() + 16 * 96; }
+};
+
+struct FeatLay {                // MLP_no_xyz (coarse): decoder.py:206-274
+    constexpr int K(int i) const { return i == 3 ? 64 : 32; }
+    constexpr int oW(int i) const {
+        int o = 0;
+        for (int j = 0; j < i; ++j) o += 32 * K(j) + 32;
+        return o;
+    }
+    constexpr int ob(int i) const { return oW(i) + 32 * K(i); }
+    constexpr int oWo() const { return oW(5); }
+    constexpr int obo() const { return oWo() + 512; }
+    constexpr int fwd_floats() const { return obo() + 16; }
+    constexpr int oWT(int i) const {
+        int o = fwd_floats();
+        for (int j = 0; j < i; ++j) o += 32 * K(j);
+        return o;
+    }
+    constexpr int oWoT() const { return oWT(5); }
+    constexpr int total() const { return oWoT() + 128; }
+};
+
+// ----------------------------------------------------------------------------------------------
+// Scene description passed by value to kernels
+// ----------------------------------------------------------------------------------------------
+struct DevGrid {
+    float* data;          // [D*H*W][32]
+    int D, H, W;
+};
+struct DevScene {
+    double lo[3], hi[3];      // Renderer.bound
+    double clo[3], chi[3];    // coarse decoder bound
+    DevGrid grid[4];
+    const float* packed[4];
+};
+
+// Position of one sample inside one grid: base corner, fractions, clip-gradient flags.
+struct Vox {
+    int ix, iy, iz;
+    float fx, fy, fz;
+    float gx, gy, gz;     // d(unnormalised, clipped coord)/d(world coord); 0 where clipped
+};
+
+// normalize_3d_coordinate (common.py:354-356) in float64, cast to float32, then ATen
+// grid_sampler_unnormalize (align_corners) / clip_coordinates / floor in float32.
+ENS_DEV void axis_coord(double pw, double lo, double hi, int size, int& i0, float& fr, float& gmul) {
+    const double pn64 = ((pw - lo) / (hi - lo)) * 2.0 - 1.0;
+    const float pn = (float)pn64;
+    float c = ((pn + 1.f) / 2.f) * (float)(size - 1);
+    const float mx = (float)(size - 1);
+    float g = (float)(size - 1) / 2.f;            // unnormalize grad
+    if (c <= 0.f) { c = 0.f; g = 0.f; }
+    else if (c >= mx) { c = mx; g = 0.f; }
+    const float fl = floorf(c);
+    i0 = (int)fl;
+    fr = c - fl;
+    gmul = g * (float)(2.0 / (hi - lo));          // chain through the float64 normalisation
+}
+
+ENS_DEV Vox make_vox(const double pw[3], const double* lo, const double* hi, const DevGrid& g) {
+    Vox v;
+    axis_coord(pw[0], lo[0], hi[0], g.W, v.ix, v.fx, v.gx);
+    axis_coord(pw[1], lo[1], hi[1], g.H, v.iy, v.fy, v.gy);
+    axis_coord(pw[2], lo[2], hi[2], g.D, v.iz, v.fz, v.gz);
+    return v;
+}
+
+// corner k = 4*dz + 2*dy + dx (ATen order tnw,tne,tsw,tse,bnw,bne,bsw,bse); weight = (wx*wy)*wz.
+// A corner beyond the last voxel has weight exactly 0 (fraction is 0 there); its index is clamped so
+// the load stays in bounds, and the weight is forced to 0 as ATen skips it.
+ENS_DEV void corner(const Vox& v, const DevGrid& g, int k, int64_t& idx, float& w) {
+    const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+    int x = v.ix + dx, y = v.iy + dy, z = v.iz + dz;
+    const bool ok = (x < g.W) && (y < g.H) && (z < g.D);
+    x = min(x, g.W - 1); y = min(y, g.H - 1); z = min(z, g.D - 1);
+    const float wx = dx ? v.fx : (1.f - v.fx);
+    const float wy = dy ? v.fy : (1.f - v.fy);
+    const float wz = dz ? v.fz : (1.f - v.fz);
+    w = ok ? (wx * wy) * wz : 0.f;
+    idx = ((int64_t)z * g.H + y) * g.W + x;
+}
+
+// Trilinear gather of the lane's 8 channels (16t+4q+r, t=0,1) of one sample.
+ENS_DEV void gather8(const Vox& v, const DevGrid& g, int q, f32x4& c0, f32x4& c1) {
+    c0 = splat4(0.f);
+    c1 = splat4(0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int64_t idx; float w;
+        corner(v, g, k, idx, w);
+        const float* src = g.data + idx * 32 + 4 * q;
+        const f32x4 a = ld4(src), b = ld4(src + 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { c0[r] = fmaf(a[r], w, c0[r]); c1[r] = fmaf(b[r], w, c1[r]); }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// MFMA building blocks
+// ----------------------------------------------------------------------------------------------
+// acc[tl][rt] += W[32 x 16*KT] (row-major, leading dim ld) * x[tl][0..KT)   for NTL point tiles
+template <int KT, int NTL, int XS>
+ENS_DEV void linear32(f32x4 (&acc)[NTL][2], const float* __restrict__ W, int ld, const f32x4 (&x)[NTL][XS], int xoff,
+                      int p, int q) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const f32x4 a = ld4(W + (16 * rt + p) * ld + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int tl = 0; tl < NTL; ++tl) acc[tl][rt] = MFMA16(a[r], x[tl][xoff + t][r], acc[tl][rt]);
+            }
+        }
+    }
+}
+
+// out[tl] (one 16-row tile, rows >= n_out are zero padding) = Wo[16 x 32] * h + bo
+template <int NTL>
+ENS_DEV void out_layer(f32x4 (&o)[NTL], const float* __restrict__ Wo, const float* __restrict__ bo,
+                       const f32x4 (&h)[NTL][2], int p, int q) {
+    const f32x4 b = ld4(bo + 4 * q);
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) o[tl] = b;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x4 a = ld4(Wo + p * 32 + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int tl = 0; tl < NTL; ++tl) o[tl] = MFMA16(a[r], h[tl][t][r], o[tl]);
+        }
+    }
+}
+
+// sin / cos of the Fourier argument p@B (|x| up to a few thousand: B ~ 25*randn, decoder.py:21-22).
+// Range reduction in float64 (one fma against pi/2: exact to ~1e-9 for |x| < 1e7), then the
+// classic float32 minimax polynomials on [-pi/4, pi/4].  ~1 ulp; no calls, no tables.
+ENS_DEV void ens_sincosf(float x, float& s, float& c) {
+    const double xd = (double)x;
+    const double k = rint(xd * 0.63661977236758134308);             // 2/pi
+    const float r = (float)fma(-k, 1.57079632679489661923, xd);
+    const int n = (int)k;
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                          fmaf(-0.5f, z, 1.f));
+    const float ss = (n & 1) ? pc : ps;
+    const float cc = (n & 1) ? ps : pc;
+    s = (n & 2) ? -ss : ss;
+    c = ((n + 1) & 2) ? -cc : cc;
+}
+ENS_DEV float ens_sinf(float x) { float s, c; ens_sincosf(x, s, c); return s; }
+
+// wave-wide helpers (64 lanes)
+ENS_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+ENS_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}

@@ -1,0 +1,36 @@
+// Internal launcher declarations shared by the C ABI translation unit and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.hpp"
+
+// one segment of a decoder re-layout: dst[r*dst_ld + c] = T ? src[c*src_ld + r] : src[r*src_ld + c]
+struct PackSeg {
+    float* src;          // caller tensor (input of pack, output of unpack)
+    int off;             // float offset in the packed buffer
+    int rows, cols;      // extent in packed orientation
+    int src_ld, dst_ld;
+    int transpose;
+};
+#define ENS_MAX_SEGS 48
+struct PackJob {
+    PackSeg seg[ENS_MAX_SEGS];
+    int n;
+};
+
+int ens_launch_pack(const PackJob& job, float* packed, bool unpack, hipStream_t st);
+int ens_launch_transpose(const float* src, float* dst, int64_t n_vox, bool to_voxel_major, hipStream_t st);
+int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
+                      const double* bound, const float* t_lin, const double* t_surf, int lindisp,
+                      const float* t_rand, float* scratch, double* z, hipStream_t st);
+int ens_launch_ray_points(int n_rays, int S, const float* ro, const float* rd, const double* z, const double* bound,
+                          double* pts, uint8_t* mask, hipStream_t st);
+int ens_launch_voxel_index(int64_t n, const double* pts, const double* bound, int D, int H, int W, int* ix, int* iy,
+                           int* iz, float* fx, float* fy, float* fz, hipStream_t st);
+int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
+                          const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
+                          double* var, float* rgb, float* raw, hipStream_t st);
+int ens_launch_render_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
+                          const DevScene& sc, const float* raw, const double* depth, const double* g_depth,
+                          const double* g_var, const float* g_rgb, const DevGrid* grad_grids,
+                          float* const* grad_packed, float* g_ro, float* g_rd, float* d_raw, hipStream_t st);

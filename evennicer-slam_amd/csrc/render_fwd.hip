@@ -1,0 +1,280 @@
+// Fused forward of the rendering hot path for gfx950: one 64-lane wave renders one ray
+// (S = 16*NTL samples): sample points (float64) -> bound mask -> trilinear gather from voxel-major
+// grids -> decoders as chained v_mfma_f32_16x16x4_f32 with activations kept in registers
+// -> alpha compositing with wave shuffles.
+//
+// Replaces (reference paths): src/utils/Renderer.py:173-181 (points, eval_points call),
+// Renderer.py:24-62 (bound mask), src/conv_onet/models/decoder.py:168-203,254-274,312-342
+// (grid_sample + MLPs + stage combine), src/common.py:256-297 (raw2outputs, occupancy branch).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+ENS_DEV f32x4 sin4(f32x4 v) { return f32x4{ens_sinf(v[0]), ens_sinf(v[1]), ens_sinf(v[2]), ens_sinf(v[3])}; }
+
+// One block of MLP.forward (decoder.py:193-199): h = relu(W_i x + b_i) + (Wc_i c + bc_i).
+template <int I, int CT, int NTL>
+ENS_DEV void xyz_layer(const float* __restrict__ pk, const f32x4 (&emb)[NTL][6], const f32x4 (&c)[NTL][CT],
+                       f32x4 (&h)[NTL][2], int p, int q) {
+    constexpr XyzLay L{CT * 16};
+    f32x4 acc[NTL][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const f32x4 b = ld4(pk + L.ob(I) + 16 * rt + 4 * q);
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) acc[tl][rt] = b;
+    }
+    if constexpr (I == 0) {
+        linear32<6, NTL, 6>(acc, pk + L.oW(0), 96, emb, 0, p, q);
+    } else if constexpr (I == 3) {
+        linear32<6, NTL, 6>(acc, pk + L.oW(3), 128, emb, 0, p, q);
+        linear32<2, NTL, 2>(acc, pk + L.oW(3) + 96, 128, h, 0, p, q);
+    } else {
+        linear32<2, NTL, 2>(acc, pk + L.oW(I), 32, h, 0, p, q);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const f32x4 bc = ld4(pk + L.obc(I) + 16 * rt + 4 * q);
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) acc[tl][rt] = relu4(acc[tl][rt]) + bc;
+    }
+    linear32<CT, NTL, CT>(acc, pk + L.oWc(I), CT * 16, c, 0, p, q);
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) { h[tl][0] = acc[tl][0]; h[tl][1] = acc[tl][1]; }
+}
+
+// MLP (middle/fine/color), decoder.py:177-203.  c: CT feature tiles; o: output tile (rows 0..n_out-1
+// valid on lanes q == 0).
+template <int CT, int NTL>
+ENS_DEV void mlp_xyz_fwd(const float* __restrict__ pk, const float (&pc)[NTL], const f32x4 (&c)[NTL][CT],
+                         f32x4 (&o)[NTL], int p, int q) {
+    constexpr XyzLay L{CT * 16};
+    f32x4 emb[NTL][6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const float a = pk[L.oBT() + (16 * t + p) * 4 + q];
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) emb[tl][t] = sin4(MFMA16(a, pc[tl], splat4(0.f)));
+    }
+    f32x4 h[NTL][2];
+    xyz_layer<0, CT, NTL>(pk, emb, c, h, p, q);
+    xyz_layer<1, CT, NTL>(pk, emb, c, h, p, q);
+    xyz_layer<2, CT, NTL>(pk, emb, c, h, p, q);
+    xyz_layer<3, CT, NTL>(pk, emb, c, h, p, q);
+    xyz_layer<4, CT, NTL>(pk, emb, c, h, p, q);
+    out_layer<NTL>(o, pk + L.oWo(), pk + L.obo(), h, p, q);
+}
+
+template <int I, int NTL>
+ENS_DEV void feat_layer(const float* __restrict__ pk, const f32x4 (&c)[NTL][2], f32x4 (&h)[NTL][2], int p, int q) {
+    constexpr FeatLay L{};
+    f32x4 acc[NTL][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const f32x4 b = ld4(pk + L.ob(I) + 16 * rt + 4 * q);
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) acc[tl][rt] = b;
+    }
+    if constexpr (I == 0) {
+        linear32<2, NTL, 2>(acc, pk + L.oW(0), 32, c, 0, p, q);
+    } else if constexpr (I == 3) {
+        linear32<2, NTL, 2>(acc, pk + L.oW(3), 64, c, 0, p, q);
+        linear32<2, NTL, 2>(acc, pk + L.oW(3) + 32, 64, h, 0, p, q);
+    } else {
+        linear32<2, NTL, 2>(acc, pk + L.oW(I), 32, h, 0, p, q);
+    }
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) { h[tl][0] = relu4(acc[tl][0]); h[tl][1] = relu4(acc[tl][1]); }
+}
+
+// MLP_no_xyz (coarse), decoder.py:262-274.
+template <int NTL>
+ENS_DEV void mlp_feat_fwd(const float* __restrict__ pk, const f32x4 (&c)[NTL][2], f32x4 (&o)[NTL], int p, int q) {
+    constexpr FeatLay L{};
+    f32x4 h[NTL][2];
+    feat_layer<0, NTL>(pk, c, h, p, q);
+    feat_layer<1, NTL>(pk, c, h, p, q);
+    feat_layer<2, NTL>(pk, c, h, p, q);
+    feat_layer<3, NTL>(pk, c, h, p, q);
+    feat_layer<4, NTL>(pk, c, h, p, q);
+    out_layer<NTL>(o, pk + L.oWo(), pk + L.obo(), h, p, q);
+}
+
+// value held by lane (p, q=0) for tile tl  ->  lane 16*tl + p
+template <int NTL>
+ENS_DEV float to_sample_lane(const f32x4 (&o)[NTL], int comp, int lane) {
+    float r = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) {
+        const float v = __shfl(o[tl][comp], lane & 15);
+        r = ((lane >> 4) == tl) ? v : r;
+    }
+    return r;
+}
+
+template <int STAGE, int NTL>
+__global__ __launch_bounds__(64) void render_fwd_kernel(int64_t n_units, const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d,
+                                                        const double* __restrict__ z_vals,
+                                                        const double* __restrict__ points, int64_t n_points,
+                                                        int apply_mask, DevScene sc, double* __restrict__ depth,
+                                                        double* __restrict__ var, float* __restrict__ rgb,
+                                                        float* __restrict__ raw_out) {
+    constexpr int S = 16 * NTL;
+    const int lane = threadIdx.x, p = lane & 15, q = lane >> 4;
+    const int64_t unit = blockIdx.x;
+    const bool ray_mode = (points == nullptr);
+
+    double pw[NTL][3];
+    float pc[NTL];
+    if (ray_mode) {
+        double o[3], d[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { o[a] = (double)rays_o[unit * 3 + a]; d[a] = (double)rays_d[unit * 3 + a]; }
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) {
+            const double z = z_vals[unit * S + 16 * tl + p];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pw[tl][a] = o[a] + d[a] * z;     // Renderer.py:173-174 (float64)
+        }
+    } else {
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) {
+            int64_t i = unit * S + 16 * tl + p;
+            i = i < n_points ? i : n_points - 1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pw[tl][a] = points[i * 3 + a];
+        }
+    }
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) {
+        pc[tl] = q == 0 ? (float)pw[tl][0] : (q == 1 ? (float)pw[tl][1] : (q == 2 ? (float)pw[tl][2] : 0.f));
+    }
+
+    f32x4 occ[NTL], col[NTL];
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) { occ[tl] = splat4(0.f); col[tl] = splat4(0.f); }
+
+    if constexpr (STAGE == 0) {
+        f32x4 c[NTL][2];
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) {
+            const Vox v = make_vox(pw[tl], sc.clo, sc.chi, sc.grid[0]);
+            gather8(v, sc.grid[0], q, c[tl][0], c[tl][1]);
+        }
+        mlp_feat_fwd<NTL>(sc.packed[0], c, occ, p, q);
+    } else {
+        f32x4 cm[NTL][2];
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) {
+            const Vox v = make_vox(pw[tl], sc.lo, sc.hi, sc.grid[1]);
+            gather8(v, sc.grid[1], q, cm[tl][0], cm[tl][1]);
+        }
+        mlp_xyz_fwd<2, NTL>(sc.packed[1], pc, cm, occ, p, q);
+        if constexpr (STAGE >= 2) {
+            f32x4 cf[NTL][4];
+#pragma unroll
+            for (int tl = 0; tl < NTL; ++tl) {
+                const Vox v = make_vox(pw[tl], sc.lo, sc.hi, sc.grid[2]);
+                gather8(v, sc.grid[2], q, cf[tl][0], cf[tl][1]);
+                cf[tl][2] = cm[tl][0];                                    // decoder.py:184-187 concat
+                cf[tl][3] = cm[tl][1];
+            }
+            f32x4 of[NTL];
+            mlp_xyz_fwd<4, NTL>(sc.packed[2], pc, cf, of, p, q);
+#pragma unroll
+            for (int tl = 0; tl < NTL; ++tl) occ[tl][0] = of[tl][0] + occ[tl][0];   // fine_occ + middle_occ
+        }
+        if constexpr (STAGE == 3) {
+            f32x4 cc[NTL][2];
+#pragma unroll
+            for (int tl = 0; tl < NTL; ++tl) {
+                const Vox v = make_vox(pw[tl], sc.lo, sc.hi, sc.grid[3]);
+                gather8(v, sc.grid[3], q, cc[tl][0], cc[tl][1]);
+            }
+            mlp_xyz_fwd<2, NTL>(sc.packed[3], pc, cc, col, p, q);
+        }
+    }
+
+    // ---- per-sample values on lane k = 16*tile + point
+    const bool valid = lane < S;
+    float occ_k = to_sample_lane<NTL>(occ, 0, lane);
+    const float r_k = to_sample_lane<NTL>(col, 0, lane);
+    const float g_k = to_sample_lane<NTL>(col, 1, lane);
+    const float b_k = to_sample_lane<NTL>(col, 2, lane);
+    const int64_t sidx = unit * S + lane;
+    double zk = 0.0;
+    {   // strict in-bound test of this lane's own sample (Renderer.py:44-47); outside -> occ = 100 (:58)
+        double pk3[3] = {0.0, 0.0, 0.0};
+        if (ray_mode) {
+            zk = valid ? z_vals[sidx] : 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pk3[a] = (double)rays_o[unit * 3 + a] + (double)rays_d[unit * 3 + a] * zk;
+        } else {
+            const int64_t i = sidx < n_points ? sidx : n_points - 1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pk3[a] = points[i * 3 + a];
+        }
+        bool in = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) in = in && (pk3[a] < sc.hi[a]) && (pk3[a] > sc.lo[a]);
+        if (!in && apply_mask) occ_k = 100.f;
+    }
+    if (raw_out != nullptr && valid && (ray_mode || sidx < n_points))
+        *reinterpret_cast<f32x4*>(raw_out + sidx * 4) = f32x4{r_k, g_k, b_k, occ_k};
+    if (!ray_mode) return;
+
+    // ---- raw2outputs_nerf_color, occupancy branch (common.py:284-296)
+    const float alpha = valid ? 1.f / (1.f + expf(-(10.f * occ_k))) : 0.f;
+    const float m = valid ? (1.f - alpha) + 1e-10f : 1.f;
+    float incl = m;                                                        // inclusive prefix product
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(incl, off);
+        incl = lane >= off ? incl * t : incl;
+    }
+    float T = __shfl_up(incl, 1);
+    T = lane == 0 ? 1.f : T;
+    const float w = alpha * T;
+    const float cr = wave_sum(w * r_k), cg = wave_sum(w * g_k), cb = wave_sum(w * b_k);
+    const double dep = wave_sum((double)w * zk);
+    const double tmp = zk - dep;
+    const double vr = wave_sum(((double)w * tmp) * tmp);
+    if (lane == 0) {
+        depth[unit] = dep;
+        var[unit] = vr;
+        rgb[unit * 3 + 0] = cr;
+        rgb[unit * 3 + 1] = cg;
+        rgb[unit * 3 + 2] = cb;
+    }
+}
+
+template <int STAGE>
+int launch_stage(int ntl, int64_t n_units, const float* ro, const float* rd, const double* z, const double* pts,
+                 int64_t n_points, int apply_mask, const DevScene& sc, double* depth, double* var, float* rgb, float* raw,
+                 hipStream_t st) {
+    if (n_units <= 0) return 0;
+    const dim3 grid((unsigned)n_units), block(64);
+    switch (ntl) {
+        case 1: render_fwd_kernel<STAGE, 1><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw); break;
+        case 2: render_fwd_kernel<STAGE, 2><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw); break;
+        case 3: render_fwd_kernel<STAGE, 3><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw); break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
+                          const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
+                          double* var, float* rgb, float* raw, hipStream_t st) {
+    switch (stage) {
+        case 0: return launch_stage<0>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw, st);
+        case 1: return launch_stage<1>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw, st);
+        case 2: return launch_stage<2>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw, st);
+        case 3: return launch_stage<3>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw, st);
+        default: return -1;
+    }
+}

@@ -1,0 +1,229 @@
+// Small kernels around the fused render kernels: depth-guided sampling (bit-exact float64 order),
+// grid layout conversion, decoder re-layout, parity helpers.
+#include "kernels.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------ batch max of gt_depth
+// Renderer.py:110,145 need max(gt_depth) over the whole batch (max(gd*1.2) == fl32(max(gd)*1.2f):
+// rounding is monotone).  One block; N <= ray_batch_size (100000).
+__global__ __launch_bounds__(1024) void depth_max_kernel(int n, const float* __restrict__ gd, float* __restrict__ out) {
+    __shared__ float red[16];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, gd[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        m = red[threadIdx.x];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (threadIdx.x == 0) { out[0] = m; out[1] = m * 1.2f; }
+    }
+}
+
+// ------------------------------------------------------------------ z sampling, one thread per ray
+// Follows the dtype promotion of Renderer.py:95-171 term by term:
+//   far_bb  float64: min_axis(max_side((bound - o)/d)) + 0.01
+//   near    float32: gt_depth*0.01f  (0.01f when no depth)
+//   z_lin   float64: (double)(near * (1.f - t)) + far * (double)t
+//   surface float64: (double)(0.95f*d) * (1 - ts) + (double)(1.05f*d) * ts   | 0.001*(1-ts) + (double)dmax*ts
+//   sort ascending (values only).
+constexpr int MAX_S = 64;
+__global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n_surf, const float* __restrict__ ro,
+                                                     const float* __restrict__ rd, const float* __restrict__ gd,
+                                                     double lo0, double hi0, double lo1, double hi1, double lo2,
+                                                     double hi2, const float* __restrict__ t_lin,
+                                                     const double* __restrict__ t_surf, int lindisp,
+                                                     const float* __restrict__ t_rand,
+                                                     const float* __restrict__ dmax, double* __restrict__ zout) {
+    const int ray = blockIdx.x * 64 + threadIdx.x;
+    if (ray >= n_rays) return;
+    const double lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+    double far_bb = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double o = (double)ro[ray * 3 + a], d = (double)rd[ray * 3 + a];
+        const double t0 = (lo[a] - o) / d, t1 = (hi[a] - o) / d;
+        const double tm = t0 > t1 ? t0 : t1;            // torch.max over the two faces
+        far_bb = tm < far_bb ? tm : far_bb;            // torch.min over axes
+    }
+    far_bb += 0.01;
+    const bool guided = gd != nullptr;
+    const float g = guided ? gd[ray] : 0.f;
+    float near32 = 0.01f;
+    double far = far_bb;
+    if (guided) {
+        near32 = g * 0.01f;
+        const double cap = (double)dmax[1];             // fl32(max(gd)*1.2f)
+        far = far_bb < 0.0 ? 0.0 : far_bb;              // clamp(min=0, max=cap)
+        far = far > cap ? cap : far;
+    }
+    double z[MAX_S];
+    for (int k = 0; k < n_lin; ++k) {
+        const float t = t_lin[k];
+        const float omt = 1.f - t;
+        if (!lindisp) {
+            z[k] = (double)(near32 * omt) + far * (double)t;
+        } else {
+            const float inv_near = guided ? 1.f / near32 : 100.0f;
+            z[k] = 1.0 / ((double)(inv_near * omt) + (1.0 / far) * (double)t);
+        }
+    }
+    if (t_rand != nullptr) {                             // Renderer.py:160-167
+        double lower[MAX_S], upper[MAX_S];
+        for (int k = 0; k < n_lin; ++k) {
+            const double mid_hi = k + 1 < n_lin ? 0.5 * (z[k + 1] + z[k]) : z[n_lin - 1];
+            const double mid_lo = k > 0 ? 0.5 * (z[k] + z[k - 1]) : z[0];
+            upper[k] = mid_hi;
+            lower[k] = mid_lo;
+        }
+        for (int k = 0; k < n_lin; ++k) z[k] = lower[k] + (upper[k] - lower[k]) * (double)t_rand[(int64_t)ray * n_lin + k];
+    }
+    int S = n_lin;
+    if (guided && n_surf > 0) {
+        const float a32 = 0.95f * g, b32 = 1.05f * g;
+        const double dm = (double)dmax[0];
+        for (int k = 0; k < n_surf; ++k) {
+            const double ts = t_surf[k];
+            z[n_lin + k] = g > 0.f ? (double)a32 * (1.0 - ts) + (double)b32 * ts : 0.001 * (1.0 - ts) + dm * ts;
+        }
+        S = n_lin + n_surf;
+        for (int i = 1; i < S; ++i) {                    // insertion sort (inputs are two sorted runs)
+            const double v = z[i];
+            int j = i - 1;
+            while (j >= 0 && z[j] > v) { z[j + 1] = z[j]; --j; }
+            z[j + 1] = v;
+        }
+    }
+    for (int k = 0; k < S; ++k) zout[(int64_t)ray * S + k] = z[k];
+}
+
+// ------------------------------------------------------------------ parity helpers
+__global__ void ray_points_kernel(int n_rays, int S, const float* __restrict__ ro, const float* __restrict__ rd,
+                                  const double* __restrict__ z, double lo0, double hi0, double lo1, double hi1,
+                                  double lo2, double hi2, double* __restrict__ pts, uint8_t* __restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_rays * S) return;
+    const int ray = (int)(i / S);
+    const double lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+    bool in = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double pw = (double)ro[ray * 3 + a] + (double)rd[ray * 3 + a] * z[i];
+        pts[i * 3 + a] = pw;
+        in = in && (pw < hi[a]) && (pw > lo[a]);
+    }
+    mask[i] = in ? 1 : 0;
+}
+
+__global__ void voxel_index_kernel(int64_t n, const double* __restrict__ pts, double lo0, double hi0, double lo1,
+                                   double hi1, double lo2, double hi2, DevGrid g, int* ix, int* iy, int* iz,
+                                   float* fx, float* fy, float* fz) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+    const double pw[3] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
+    const Vox v = make_vox(pw, lo, hi, g);
+    ix[i] = v.ix; iy[i] = v.iy; iz[i] = v.iz;
+    fx[i] = v.fx; fy[i] = v.fy; fz[i] = v.fz;
+}
+
+// ------------------------------------------------------------------ [32][V] <-> [V][32]
+// 64 voxels per block through a padded LDS tile; both sides move 256-byte rows.
+__global__ __launch_bounds__(256) void to_voxel_major_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              int64_t V) {
+    __shared__ float tile[32][65];
+    const int64_t v0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = ty; c < 32; c += 4) {
+        const int64_t v = v0 + tx;
+        tile[c][tx] = v < V ? src[(int64_t)c * V + v] : 0.f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 31, vv = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = vv; j < 64; j += 8) {
+        const int64_t v = v0 + j;
+        if (v < V) dst[v * 32 + c] = tile[c][j];
+    }
+}
+
+__global__ __launch_bounds__(256) void from_voxel_major_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                int64_t V) {
+    __shared__ float tile[32][65];
+    const int64_t v0 = (int64_t)blockIdx.x * 64;
+    const int c = threadIdx.x & 31, vv = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = vv; j < 64; j += 8) {
+        const int64_t v = v0 + j;
+        tile[c][j] = v < V ? src[v * 32 + c] : 0.f;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int cc = ty; cc < 32; cc += 4) {
+        const int64_t v = v0 + tx;
+        if (v < V) dst[(int64_t)cc * V + v] = tile[cc][tx];
+    }
+}
+
+// ------------------------------------------------------------------ decoder re-layout
+__global__ __launch_bounds__(256) void pack_kernel(PackJob job, float* __restrict__ packed, int unpack) {
+    const PackSeg s = job.seg[blockIdx.x];
+    const int n = s.rows * s.cols;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int r = e / s.cols, c = e - r * s.cols;
+        float* src = s.src + (s.transpose ? (int64_t)c * s.src_ld + r : (int64_t)r * s.src_ld + c);
+        float* dst = packed + s.off + r * s.dst_ld + c;
+        if (unpack) *src = *dst; else *dst = *src;
+    }
+}
+
+}  // namespace
+
+int ens_launch_pack(const PackJob& job, float* packed, bool unpack, hipStream_t st) {
+    if (job.n <= 0) return 0;
+    pack_kernel<<<dim3(job.n), dim3(256), 0, st>>>(job, packed, unpack ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_transpose(const float* src, float* dst, int64_t V, bool to_vm, hipStream_t st) {
+    if (V <= 0) return 0;
+    const dim3 grid((unsigned)((V + 63) / 64)), block(256);
+    if (to_vm) to_voxel_major_kernel<<<grid, block, 0, st>>>(src, dst, V);
+    else from_voxel_major_kernel<<<grid, block, 0, st>>>(src, dst, V);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
+                      const double* b, const float* t_lin, const double* t_surf, int lindisp, const float* t_rand,
+                      float* scratch, double* z, hipStream_t st) {
+    if (n_rays <= 0) return 0;
+    if (n_lin + n_surf > MAX_S || n_lin < 1) return -1;
+    if (gd != nullptr) depth_max_kernel<<<1, 1024, 0, st>>>(n_rays, gd, scratch);
+    sample_kernel<<<dim3((n_rays + 63) / 64), dim3(64), 0, st>>>(n_rays, n_lin, gd ? n_surf : 0, ro, rd, gd, b[0], b[1],
+                                                                 b[2], b[3], b[4], b[5], t_lin, t_surf, lindisp,
+                                                                 t_rand, scratch, z);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_ray_points(int n_rays, int S, const float* ro, const float* rd, const double* z, const double* b,
+                          double* pts, uint8_t* mask, hipStream_t st) {
+    const int64_t n = (int64_t)n_rays * S;
+    if (n <= 0) return 0;
+    ray_points_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n_rays, S, ro, rd, z, b[0], b[1], b[2],
+                                                                                b[3], b[4], b[5], pts, mask);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_voxel_index(int64_t n, const double* pts, const double* b, int D, int H, int W, int* ix, int* iy,
+                           int* iz, float* fx, float* fy, float* fz, hipStream_t st) {
+    if (n <= 0) return 0;
+    DevGrid g{nullptr, D, H, W};
+    voxel_index_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, pts, b[0], b[1], b[2], b[3], b[4],
+                                                                                 b[5], g, ix, iy, iz, fx, fy, fz);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,387 @@
+"""Host side of the HIP rendering path: tensor plumbing around the C ABI (include/enslam_hip.h).
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; every arithmetic step of the
+path (sampling, gather, decoders, compositing and their backward) runs in libenslam_hip.so.
+There is no CPU implementation here: non-HIP tensors raise.
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import _lib as L
+
+_KIND_OF_GRID = {'grid_coarse': 0, 'grid_middle': 1, 'grid_fine': 2, 'grid_color': 3}
+
+
+def _require_hip(t, what):
+    if not t.is_cuda:
+        raise L.EnslamError(f"{what} must live on a HIP device (got {t.device}); the rendering path has no CPU "
+                            f"fallback")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def bound6(bound):
+    """[3,2] tensor -> (c_double*6) x_lo,x_hi,y_lo,y_hi,z_lo,z_hi."""
+    b = bound.detach().to('cpu', torch.float64).reshape(-1).tolist()
+    return (ctypes.c_double * 6)(*b)
+
+
+# ------------------------------------------------------------------------------------------------
+# decoder parameters: ordering, packing cache
+# ------------------------------------------------------------------------------------------------
+def decoder_params(dec, kind):
+    """Parameter tensors of one decoder in ABI order.  Works on this package's modules and on any
+    module with the reference's attribute names (pts_linears, fc_c, output_linear, embedder._B)."""
+    ps = []
+    for i in range(5):
+        ps += [dec.pts_linears[i].weight, dec.pts_linears[i].bias]
+    if kind != L.MLP_COARSE:
+        for i in range(5):
+            ps += [dec.fc_c[i].weight, dec.fc_c[i].bias]
+    ps += [dec.output_linear.weight, dec.output_linear.bias]
+    if kind != L.MLP_COARSE:
+        ps.append(dec.embedder._B)
+    return ps
+
+
+def _fill_params_struct(kind, tensors):
+    """enslam_mlp_params from tensors in decoder_params() order (entries may be None)."""
+    s = L.MlpParams()
+    it = iter(tensors)
+    for i in range(5):
+        s.W[i] = _ptr(next(it)).value
+        s.b[i] = _ptr(next(it)).value
+    if kind != L.MLP_COARSE:
+        for i in range(5):
+            s.Wc[i] = _ptr(next(it)).value
+            s.bc[i] = _ptr(next(it)).value
+    s.Wo = _ptr(next(it)).value
+    s.bo = _ptr(next(it)).value
+    if kind != L.MLP_COARSE:
+        s.B = _ptr(next(it)).value
+    return s
+
+
+_EXPECT_SHAPES = {
+    L.MLP_COARSE: [(32, 32), (32,), (32, 32), (32,), (32, 32), (32,), (32, 64), (32,), (32, 32), (32,), (1, 32), (1,)],
+}
+
+
+def _xyz_shapes(cd, nout):
+    s = []
+    for k in (93, 32, 32, 125, 32):
+        s += [(32, k), (32,)]
+    for _ in range(5):
+        s += [(32, cd), (32,)]
+    return s + [(nout, 32), (nout,), (3, 93)]
+
+
+_EXPECT_SHAPES[L.MLP_MIDDLE] = _xyz_shapes(32, 1)
+_EXPECT_SHAPES[L.MLP_FINE] = _xyz_shapes(64, 1)
+_EXPECT_SHAPES[L.MLP_COLOR] = _xyz_shapes(32, 4)
+
+
+def _check_params(kind, ps):
+    for t, shp in zip(ps, _EXPECT_SHAPES[kind]):
+        if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_contiguous():
+            raise L.EnslamError(f"decoder {L.MLP_NAMES[kind]}: parameter of shape {tuple(t.shape)} / {t.dtype}, "
+                                f"expected contiguous float32 {shp}")
+        _require_hip(t, "decoder parameters")
+
+
+class _PackCache:
+    """Packed form of a decoder, refreshed when any parameter's (data_ptr, _version) changes."""
+
+    def __init__(self):
+        self.key = None
+        self.packed = None
+
+    def get(self, kind, ps):
+        key = tuple((id(p), p.data_ptr(), p._version) for p in ps)
+        if key != self.key:
+            _check_params(kind, ps)
+            n = L.lib().enslam_packed_floats(kind)
+            # fresh buffer: an earlier forward's saved packing stays valid for its backward
+            packed = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+            s = _fill_params_struct(kind, ps)
+            L.check(L.lib().enslam_pack_mlp(kind, ctypes.byref(s), _ptr(packed), _stream()), "enslam_pack_mlp")
+            self.key, self.packed = key, packed
+        return self.packed
+
+
+_pack_caches = weakref.WeakKeyDictionary()      # decoder module -> _PackCache
+
+
+def packed_decoder(dec, kind):
+    cache = _pack_caches.get(dec)
+    if cache is None:
+        cache = _pack_caches[dec] = _PackCache()
+    return cache.get(kind, decoder_params(dec, kind))
+
+
+# ------------------------------------------------------------------------------------------------
+# grids: voxel-major copies, cached per (storage, version)
+# ------------------------------------------------------------------------------------------------
+class _GridCache:
+    """Voxel-major copies keyed on tensor IDENTITY + version counter.  (A data_ptr key would go stale when the
+    caching allocator hands a freed grid's address to a new tensor, e.g. Tracker.update_para_from_mapping's
+    per-frame clones.)  Entries die with their source tensor."""
+
+    def __init__(self):
+        self.items = {}          # id(tensor) -> (weakref, version, voxel-major tensor)
+
+    def get(self, g):
+        if g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32 or g.dtype != torch.float32:
+            raise L.EnslamError(f"feature grid must be float32 [1,32,D,H,W], got {tuple(g.shape)} {g.dtype}")
+        _require_hip(g, "feature grids")
+        e = self.items.get(id(g))
+        if e is not None and e[0]() is g and e[1] == g._version:
+            return e[2]
+        src = g.detach()
+        if not src.is_contiguous():
+            src = src.contiguous()
+        V = g.shape[2] * g.shape[3] * g.shape[4]
+        # fresh buffer each refresh: an earlier forward's saved copy stays valid for its backward
+        vm = torch.empty((V, 32), dtype=torch.float32, device=g.device)
+        L.check(L.lib().enslam_grid_to_voxel_major(_ptr(src), _ptr(vm), V, _stream()), "grid_to_voxel_major")
+        key, items = id(g), self.items
+        self.items[key] = (weakref.ref(g, lambda _r, key=key, items=items: items.pop(key, None)), g._version, vm)
+        return vm
+
+
+_grid_cache = _GridCache()
+
+
+def clear_caches():
+    _grid_cache.items.clear()
+    _pack_caches.clear()
+
+
+def _scene_struct(stage, bound, coarse_bound, grids_vm, grid_dims, packed):
+    """enslam_scene for a stage. grids_vm / packed: dict kind -> tensor."""
+    sc = L.Scene()
+    sc.bound = bound
+    sc.coarse_bound = coarse_bound
+    for k in range(4):
+        if k in grids_vm:
+            sc.grids[k].data = grids_vm[k].data_ptr()
+            sc.grids[k].D, sc.grids[k].H, sc.grids[k].W = grid_dims[k]
+        if k in packed:
+            sc.packed[k] = packed[k].data_ptr()
+    return sc
+
+
+def stage_kinds(stage):
+    return L.STAGE_KINDS[stage]
+
+
+# ------------------------------------------------------------------------------------------------
+# the differentiable render call
+# ------------------------------------------------------------------------------------------------
+class RenderPlan:
+    """Static description of one render_batch_ray call (everything that is not a differentiable tensor)."""
+
+    def __init__(self, stage, bound, coarse_bound, n_lin, n_surf, lindisp, t_lin, t_surf, kinds, decoders):
+        self.stage = stage
+        self.bound6 = bound6(bound)
+        self.coarse_bound6 = bound6(coarse_bound)
+        self.n_lin, self.n_surf, self.lindisp = n_lin, n_surf, int(bool(lindisp))
+        self.t_lin, self.t_surf = t_lin, t_surf
+        self.kinds = kinds                      # decoder / grid kinds used, ascending
+        self.decoders = decoders                # dict kind -> module
+        self.n_params = {k: (12 if k == L.MLP_COARSE else 23) for k in kinds}
+
+
+class _RenderFn(torch.autograd.Function):
+    """inputs: plan, rays_o, rays_d, gt_depth|None, t_rand|None, then for each kind in plan.kinds: grid,
+    then for each kind: its parameters.  Outputs depth f64 [N], var f64 [N], rgb f32 [N,3]."""
+
+    @staticmethod
+    def forward(ctx, plan, rays_o, rays_d, gt_depth, t_rand, *tensors):
+        lib = L.lib()
+        nk = len(plan.kinds)
+        grids = tensors[:nk]
+        N = rays_o.shape[0]
+        dev = rays_o.device
+        S = plan.n_lin + (plan.n_surf if gt_depth is not None else 0)
+        st = _stream()
+        ro = rays_o.detach().contiguous().float()
+        rd = rays_d.detach().contiguous().float()
+        gd = gt_depth.detach().contiguous().float().reshape(-1) if gt_depth is not None else None
+        z = torch.empty((N, S), dtype=torch.float64, device=dev)
+        scratch = torch.empty(2, dtype=torch.float32, device=dev)
+        L.check(lib.enslam_sample_rays(N, plan.n_lin, plan.n_surf, _ptr(ro), _ptr(rd), _ptr(gd), plan.bound6,
+                                       _ptr(plan.t_lin), _ptr(plan.t_surf), plan.lindisp, _ptr(t_rand),
+                                       _ptr(scratch), _ptr(z), st), "enslam_sample_rays")
+        grids_vm, dims, packed = {}, {}, {}
+        for k, g in zip(plan.kinds, grids):
+            grids_vm[k] = _grid_cache.get(g)
+            dims[k] = tuple(g.shape[2:])
+            packed[k] = packed_decoder(plan.decoders[k], k)
+        sc = _scene_struct(plan.stage, plan.bound6, plan.coarse_bound6, grids_vm, dims, packed)
+        depth = torch.empty(N, dtype=torch.float64, device=dev)
+        var = torch.empty(N, dtype=torch.float64, device=dev)
+        rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
+        L.check(lib.enslam_render_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
+                                      _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), st), "enslam_render_fwd")
+        ctx.plan, ctx.S, ctx.dims = plan, S, dims
+        ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed)
+        ctx.grid_shapes = [tuple(g.shape) for g in grids]
+        ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
+        return depth, var, rgb
+
+    @staticmethod
+    def backward(ctx, g_depth, g_var, g_rgb):
+        lib = L.lib()
+        plan, S = ctx.plan, ctx.S
+        ro, rd, z, raw, depth, grids_vm, packed = ctx.keep
+        N, dev, st = ro.shape[0], ro.device, _stream()
+        nk = len(plan.kinds)
+        needs = ctx.needs_input_grad            # (plan, ro, rd, gd, t_rand, grids..., params...)
+        need_rays = needs[1] or needs[2]
+        need_grid = {k: needs[5 + i] for i, k in enumerate(plan.kinds)}
+        off = 5 + nk
+        need_par = {}
+        for k in plan.kinds:
+            n = plan.n_params[k]
+            need_par[k] = any(needs[off:off + n])
+            off += n
+
+        def prep(g, dtype, shape):
+            if g is None:
+                return None
+            return g.detach().to(dtype).expand(shape).contiguous()
+
+        gD, gV, gC = prep(g_depth, torch.float64, (N,)), prep(g_var, torch.float64, (N,)), prep(g_rgb, torch.float32, (N, 3))
+        if gD is None and gV is None and gC is None:
+            return (None,) * len(needs)
+        sc = _scene_struct(plan.stage, plan.bound6, plan.coarse_bound6, grids_vm, ctx.dims, packed)
+        gg = (L.Grid * 4)()
+        gpk = (ctypes.c_void_p * 4)()
+        g_grids_vm, g_packed = {}, {}
+        for k in plan.kinds:
+            D, H, W = ctx.dims[k]
+            gg[k].D, gg[k].H, gg[k].W = D, H, W
+            # fine decoder's middle-feature concat gets no gradient: grid 1 only via the middle decoder
+            if need_grid[k]:
+                g_grids_vm[k] = torch.zeros((D * H * W, 32), dtype=torch.float32, device=dev)
+                gg[k].data = g_grids_vm[k].data_ptr()
+            if need_par[k]:
+                g_packed[k] = torch.zeros(lib.enslam_packed_grad_floats(k), dtype=torch.float32, device=dev)
+                gpk[k] = g_packed[k].data_ptr()
+        g_ro = torch.zeros((N, 3), dtype=torch.float32, device=dev) if need_rays else None
+        g_rd = torch.zeros((N, 3), dtype=torch.float32, device=dev) if need_rays else None
+        d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
+        L.check(lib.enslam_render_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
+                                      _ptr(raw), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC), gg, gpk, _ptr(g_ro),
+                                      _ptr(g_rd), _ptr(d_raw), st), "enslam_render_bwd")
+        out = [None, g_ro if needs[1] else None, g_rd if needs[2] else None, None, None]
+        for i, k in enumerate(plan.kinds):
+            if need_grid[k]:
+                g = torch.empty(ctx.grid_shapes[i], dtype=torch.float32, device=dev)
+                V = g_grids_vm[k].shape[0]
+                L.check(lib.enslam_grid_from_voxel_major(_ptr(g_grids_vm[k]), _ptr(g), V, st), "grid_from_voxel_major")
+                out.append(g)
+            else:
+                out.append(None)
+        pm = iter(ctx.param_meta)
+        for k in plan.kinds:
+            shapes = [next(pm) for _ in range(plan.n_params[k])]
+            if not need_par[k]:
+                out += [None] * len(shapes)
+                continue
+            sizes = [int(torch.Size(s).numel()) for s in shapes]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+            views, o = [], 0
+            for s, n in zip(shapes, sizes):
+                views.append(flat[o:o + n].view(s))
+                o += n
+            ps = _fill_params_struct(k, views)
+            L.check(lib.enslam_unpack_mlp_grads(k, _ptr(g_packed[k]), ctypes.byref(ps), st), "unpack_mlp_grads")
+            out += views
+        return tuple(out)
+
+
+def render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params_flat):
+    return _RenderFn.apply(plan, rays_o, rays_d, gt_depth, t_rand, *grids, *params_flat)
+
+
+# ------------------------------------------------------------------------------------------------
+# forward-only helpers
+# ------------------------------------------------------------------------------------------------
+def eval_points(p, decoders, c, stage, bound, apply_mask=True, coarse_bound=None):
+    """raw [P,4] float32 for points p [P,3] (any float dtype; evaluated as float64 like the reference)."""
+    lib = L.lib()
+    _require_hip(p, "points")
+    if torch.is_grad_enabled() and (p.requires_grad or any(
+            c[L.GRID_NAMES[k]].requires_grad for k in stage_kinds(stage))):
+        raise NotImplementedError("eval_points is forward-only on the HIP path (its differentiable use, "
+                                  "Renderer.regulation, belongs to the iMAP mode); wrap the call in torch.no_grad()")
+    pts = p.detach().to(torch.float64).contiguous()
+    P = pts.shape[0]
+    kinds = stage_kinds(stage)
+    grids_vm, dims, packed = {}, {}, {}
+    for k in kinds:
+        g = c[L.GRID_NAMES[k]]
+        grids_vm[k] = _grid_cache.get(g)
+        dims[k] = tuple(g.shape[2:])
+        packed[k] = packed_decoder(getattr(decoders, L.MLP_NAMES[k]), k)
+    if coarse_bound is None:
+        coarse_bound = decoders.coarse_decoder.bound if 0 in kinds else bound
+    sc = _scene_struct(stage, bound6(bound), bound6(coarse_bound), grids_vm, dims, packed)
+    raw = torch.empty((P, 4), dtype=torch.float32, device=p.device)
+    L.check(lib.enslam_eval_points(L.STAGE[stage], P, _ptr(pts), ctypes.byref(sc), int(apply_mask), _ptr(raw),
+                                   _stream()), "enslam_eval_points")
+    return raw
+
+
+def voxel_index(points, bound, shape):
+    """Parity helper: (ix,iy,iz int32, fx,fy,fz float32) the gather uses for float64 points [P,3]."""
+    lib = L.lib()
+    pts = points.detach().to(torch.float64).contiguous()
+    P, dev = pts.shape[0], pts.device
+    outs = [torch.empty(P, dtype=torch.int32, device=dev) for _ in range(3)] + \
+           [torch.empty(P, dtype=torch.float32, device=dev) for _ in range(3)]
+    D, H, W = shape
+    L.check(lib.enslam_voxel_index(P, _ptr(pts), bound6(bound), D, H, W, *[_ptr(t) for t in outs], _stream()),
+            "enslam_voxel_index")
+    return outs
+
+
+def ray_points(rays_o, rays_d, z_vals, bound):
+    """Parity helper: float64 sample points [N*S,3] and the strict in-bound mask."""
+    lib = L.lib()
+    N, S = z_vals.shape
+    pts = torch.empty((N * S, 3), dtype=torch.float64, device=z_vals.device)
+    mask = torch.empty(N * S, dtype=torch.uint8, device=z_vals.device)
+    L.check(lib.enslam_ray_points(N, S, _ptr(rays_o.contiguous().float()), _ptr(rays_d.contiguous().float()),
+                                  _ptr(z_vals.contiguous()), bound6(bound), _ptr(pts), _ptr(mask), _stream()),
+            "enslam_ray_points")
+    return pts, mask.bool()
+
+
+def sample_rays(rays_o, rays_d, gt_depth, bound, n_lin, n_surf, lindisp=False, t_rand=None):
+    """z_vals float64 [N,S] (Renderer.py:83-171)."""
+    lib = L.lib()
+    _require_hip(rays_o, "rays")
+    N, dev = rays_o.shape[0], rays_o.device
+    S = n_lin + (n_surf if gt_depth is not None else 0)
+    t_lin = torch.linspace(0., 1., steps=n_lin, device=dev)
+    t_surf = torch.linspace(0., 1., steps=max(n_surf, 1), device=dev).double() if n_surf > 0 else None
+    z = torch.empty((N, S), dtype=torch.float64, device=dev)
+    scratch = torch.empty(2, dtype=torch.float32, device=dev)
+    gd = gt_depth.contiguous().float().reshape(-1) if gt_depth is not None else None
+    L.check(lib.enslam_sample_rays(N, n_lin, n_surf, _ptr(rays_o.contiguous().float()),
+                                   _ptr(rays_d.contiguous().float()), _ptr(gd), bound6(bound), _ptr(t_lin),
+                                   _ptr(t_surf), int(bool(lindisp)), _ptr(t_rand), _ptr(scratch), _ptr(z), _stream()),
+            "enslam_sample_rays")
+    return z

@@ -1,0 +1,127 @@
+"""`Renderer` with the reference's constructor and method signatures (src/utils/Renderer.py:6-360),
+backed by the HIP library.  Callers (Tracker.py:150,175; Mapper.py:548,567,591; Mesher.py:548;
+Visualizer.py:79,244) use it unchanged."""
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import functional as EF
+from .common import get_rays, get_rays_rescale
+
+
+class Renderer(object):
+    def __init__(self, cfg, args, slam, points_batch_size=500000, ray_batch_size=100000):
+        self.ray_batch_size = ray_batch_size
+        self.points_batch_size = points_batch_size
+        r = cfg['rendering']
+        self.lindisp, self.perturb = r['lindisp'], r['perturb']
+        self.N_samples, self.N_surface, self.N_importance = r['N_samples'], r['N_surface'], r['N_importance']
+        self.scale = cfg['scale']
+        self.occupancy = cfg['occupancy']
+        self.nice = slam.nice
+        self.bound = slam.bound
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = slam.H, slam.W, slam.fx, slam.fy, slam.cx, slam.cy
+        if not self.nice or not self.occupancy:
+            raise NotImplementedError("the HIP path implements the NICE / occupancy configuration "
+                                      "(configs/nice_slam.yaml: occupancy True); iMAP mode is out of scope")
+        self._tvals = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _t_vals(self, device, n_lin, n_surf):
+        key = (str(device), n_lin, n_surf)
+        if key not in self._tvals:
+            t_lin = torch.linspace(0., 1., steps=n_lin, device=device)
+            t_surf = torch.linspace(0., 1., steps=n_surf, device=device).double() if n_surf > 0 else None
+            self._tvals[key] = (t_lin, t_surf)
+        return self._tvals[key]
+
+    def _coarse_bound(self, decoders):
+        cd = getattr(decoders, 'coarse_decoder', None)
+        b = getattr(cd, 'bound', None) if cd is not None else None
+        return b if b is not None else self.bound
+
+    # ------------------------------------------------------------------ API
+    def eval_points(self, p, decoders, c=None, stage='color', device='cuda:0'):
+        """occupancy (and colour) of points p [N,3]; out-of-bound points get occ = 100."""
+        rets = []
+        for pi in torch.split(p, self.points_batch_size):
+            rets.append(EF.eval_points(pi, decoders, c, stage, self.bound, apply_mask=True,
+                                       coarse_bound=self._coarse_bound(decoders)))
+        return torch.cat(rets, dim=0)
+
+    def render_batch_ray(self, c, decoders, rays_d, rays_o, device, stage, gt_depth=None):
+        """(depth f64 [N], uncertainty f64 [N], color f32 [N,3]) -- note rays_d comes before rays_o."""
+        if self.N_importance > 0:
+            raise NotImplementedError("hierarchical sampling (N_importance > 0) is not exercised by the NICE "
+                                      "configuration and is not built on the HIP path")
+        if stage not in L.STAGE:
+            raise ValueError(f"unknown stage {stage!r}")
+        EF._require_hip(rays_o, "rays")
+        if stage == 'coarse':
+            gt_depth = None
+        N = rays_o.shape[0]
+        if gt_depth is not None:
+            gt_depth = gt_depth.reshape(-1)
+            if N == 0:
+                raise RuntimeError("render_batch_ray: empty ray batch with gt_depth (the reference's "
+                                   "torch.max over an empty tensor raises here too)")
+        n_lin, n_surf = self.N_samples, (self.N_surface if gt_depth is not None else 0)
+        S = n_lin + n_surf
+        if S not in (16, 32, 48):
+            raise NotImplementedError(f"N_samples + N_surface = {S}: kernels are built for 16, 32 or 48 samples")
+        dev = rays_o.device
+        t_lin, t_surf = self._t_vals(dev, n_lin, self.N_surface)
+        t_rand = torch.rand((N, n_lin), device=dev) if self.perturb > 0. else None
+        kinds = EF.stage_kinds(stage)
+        decs = {k: getattr(decoders, L.MLP_NAMES[k]) for k in kinds}
+        plan = EF.RenderPlan(stage, self.bound, self._coarse_bound(decoders), n_lin, n_surf, self.lindisp, t_lin,
+                             t_surf, kinds, decs)
+        grids = [c[L.GRID_NAMES[k]] for k in kinds]
+        params = []
+        for k in kinds:
+            params += EF.decoder_params(decs[k], k)
+        if N == 0:
+            z = rays_o.new_zeros((0,))
+            return z.double(), z.double(), rays_o.new_zeros((0, 3))
+        depth, var, color = EF.render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params)
+        return depth, var, color
+
+    def _render_chunks(self, c, decoders, rays_o, rays_d, device, stage, gt_depth):
+        depth_l, var_l, col_l = [], [], []
+        for i in range(0, rays_d.shape[0], self.ray_batch_size):
+            gd = None if gt_depth is None else gt_depth[i:i + self.ray_batch_size]
+            d, u, col = self.render_batch_ray(c, decoders, rays_d[i:i + self.ray_batch_size],
+                                              rays_o[i:i + self.ray_batch_size], device, stage, gt_depth=gd)
+            depth_l.append(d.double())
+            var_l.append(u.double())
+            col_l.append(col)
+        return torch.cat(depth_l, 0), torch.cat(var_l, 0), torch.cat(col_l, 0)
+
+    def render_img(self, c, decoders, c2w, device, stage, gt_depth=None):
+        """Full-resolution depth / uncertainty / colour images, no gradient (Renderer.py:201-256)."""
+        with torch.no_grad():
+            H, W = self.H, self.W
+            rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+            gd = gt_depth.reshape(-1) if gt_depth is not None else None
+            depth, var, color = self._render_chunks(c, decoders, rays_o.reshape(-1, 3), rays_d.reshape(-1, 3),
+                                                    device, stage, gd)
+            return depth.reshape(H, W), var.reshape(H, W), color.reshape(H, W, 3)
+
+    def render_img_rescale(self, c, decoders, c2w, device, stage, gt_depth=None, scale_factor=0.1):
+        """Image rendered at (int(H*s), int(W*s)) pixel centres WITH gradient (Renderer.py:258-319)."""
+        H, W = self.H, self.W
+        new_H, new_W = int(H * scale_factor), int(W * scale_factor)
+        rays_o, rays_d = get_rays_rescale(H, W, new_H, new_W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+        gd = None
+        if gt_depth is not None:
+            # torchvision Resize(BILINEAR) on a tensor == F.interpolate(bilinear, align_corners=False)
+            # (antialias only applies when asked for on tensors in the pinned torchvision).
+            gd = F.interpolate(gt_depth[None, None].float(), size=(new_H, new_W), mode='bilinear',
+                               align_corners=False).reshape(-1)
+        depth, var, color = self._render_chunks(c, decoders, rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), device,
+                                                stage, gd)
+        return depth.reshape(new_H, new_W), var.reshape(new_H, new_W), color.reshape(new_H, new_W, 3)
+
+    def regulation(self, c, decoders, rays_d, rays_o, gt_depth, device, stage='color'):
+        raise NotImplementedError("Renderer.regulation is the iMAP (occupancy=False) free-space regulariser "
+                                  "(Renderer.py:322-360); not part of the NICE hot path")

@@ -1,0 +1,158 @@
+/*
+ * enslam_hip.h -- C ABI of the MI355X (gfx950) volume-rendering hot path.
+ *
+ * The reference (cs-vision/EvenNICER-SLAM) has no FFI on this path: its boundary
+ * is a Python object protocol.  This library is what a
+ * Python (ctypes) host binds instead of the PyTorch op sequence; each entry
+ * point names the reference code it replaces (paths relative to the reference
+ * checkout).  All pointers are DEVICE pointers unless marked "host".  Nothing
+ * here allocates, frees, synchronises or takes ownership: the caller owns every
+ * buffer, every call is stream-ordered on `stream` (a hipStream_t passed as
+ * void*), re-entrant, and returns 0 on success or a negative ENSLAM_E* code.
+ *
+ * Memory layouts
+ *   rays_o, rays_d      float32 [N,3]
+ *   gt_depth            float32 [N]            (may be NULL: no depth guidance)
+ *   z_vals              float64 [N,S]          sorted sample distances
+ *   grid (reference)    float32 [1,32,D,H,W]   "channel-major", as the callers hold it
+ *   grid (kernel)       float32 [D*H*W,32]     "voxel-major": one voxel corner = 128 contiguous bytes
+ *   raw                 float32 [N*S,4]        (r,g,b,occ) after the out-of-bound mask
+ *   depth, var          float64 [N];   rgb float32 [N,3]
+ *   packed MLP          float32 [enslam_packed_floats(kind)]   (see enslam_pack_mlp)
+ */
+#ifndef ENSLAM_HIP_H
+#define ENSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ENSLAM_ABI_VERSION 1
+
+/* error codes */
+#define ENSLAM_OK 0
+#define ENSLAM_EINVAL (-1)      /* bad argument (NULL where required, unsupported size) */
+#define ENSLAM_ELAUNCH (-2)     /* hipLaunch / hipMemsetAsync reported an error */
+#define ENSLAM_EUNSUPPORTED (-3)
+
+/* stages of NICE.forward, src/conv_onet/models/decoder.py:312-342 */
+#define ENSLAM_STAGE_COARSE 0
+#define ENSLAM_STAGE_MIDDLE 1
+#define ENSLAM_STAGE_FINE 2
+#define ENSLAM_STAGE_COLOR 3
+
+/* decoder kinds (index into the arrays below) */
+#define ENSLAM_MLP_COARSE 0     /* MLP_no_xyz, decoder.py:206-274 */
+#define ENSLAM_MLP_MIDDLE 1     /* MLP,        decoder.py:91-203  */
+#define ENSLAM_MLP_FINE 2       /* MLP with concat_feature (c_dim 64) */
+#define ENSLAM_MLP_COLOR 3      /* MLP with 4 outputs */
+
+/* Parameter tensors of one decoder, in the reference's state_dict layout
+ * (row-major nn.Linear weights [out,in]).  Used as input by enslam_pack_mlp and
+ * as OUTPUT (gradient tensors of the same shapes) by enslam_unpack_mlp_grads. */
+typedef struct enslam_mlp_params {
+    float *W[5];    /* pts_linears.{i}.weight  [32,K_i]; K = 93,32,32,125,32 (coarse: 32,32,32,64,32) */
+    float *b[5];    /* pts_linears.{i}.bias    [32] */
+    float *Wc[5];   /* fc_c.{i}.weight         [32,c_dim] (c_dim 32; fine 64); NULL for coarse */
+    float *bc[5];   /* fc_c.{i}.bias           [32]; NULL for coarse */
+    float *Wo;      /* output_linear.weight    [n_out,32]  (n_out 1; color 4) */
+    float *bo;      /* output_linear.bias      [n_out] */
+    float *B;       /* embedder._B             [3,93]; NULL for coarse */
+} enslam_mlp_params;
+
+/* One feature grid in voxel-major layout. */
+typedef struct enslam_grid {
+    float *data;    /* [D*H*W,32] (const for the forward; accumulation target for gradients) */
+    int32_t D, H, W;
+} enslam_grid;
+
+/* Everything a render call reads.  grids/packed are indexed by ENSLAM_MLP_*.
+ * Entries the stage does not use may be NULL. */
+typedef struct enslam_scene {
+    double bound[6];         /* host: x_lo,x_hi,y_lo,y_hi,z_lo,z_hi  (Renderer.bound, Renderer.py:20)   */
+    double coarse_bound[6];  /* host: bound * coarse_bound_enlarge (EvenNICER_SLAM.py:182)             */
+    enslam_grid grids[4];    /* coarse, middle, fine, color                                            */
+    const float *packed[4];  /* packed decoders (enslam_pack_mlp)                                       */
+} enslam_scene;
+
+int enslam_abi_version(void);
+const char *enslam_arch(void);          /* "gfx950" */
+
+/* number of float32 in the packed form of decoder `kind` (forward + transposed sections) and
+ * in its gradient accumulator (forward section only). */
+size_t enslam_packed_floats(int kind);
+size_t enslam_packed_grad_floats(int kind);
+
+/* Re-layout one decoder's parameters for the MFMA kernels (zero-padded K, transposed copies for
+ * the backward).  `packed` must have been zero-filled once by the caller; padding is never written.
+ * Replaces nothing in the reference (layout glue for decoder.py:149-159 parameters). */
+int enslam_pack_mlp(int kind, const enslam_mlp_params *params, float *packed, void *stream);
+
+/* Inverse for gradients: packed_grad (accumulated by enslam_render_bwd) -> tensors shaped like the
+ * reference parameters.  Pointers in `grads` that are NULL are skipped. */
+int enslam_unpack_mlp_grads(int kind, const float *packed_grad, const enslam_mlp_params *grads, void *stream);
+
+/* [C,V] -> [V,C] and back (C = 32).  Replaces the implicit layout of F.grid_sample's input
+ * (decoder.py:173-174).  `to` reads the caller's grid; `from` writes a gradient the caller's
+ * autograd expects ([1,32,D,H,W]). */
+int enslam_grid_to_voxel_major(const float *src, float *dst, int64_t n_voxels, void *stream);
+int enslam_grid_from_voxel_major(const float *src, float *dst, int64_t n_voxels, void *stream);
+
+/* Sample distances along rays.  Replaces Renderer.render_batch_ray lines 83-171
+ * (src/utils/Renderer.py): near/far from gt_depth and the AABB exit, n_lin linear samples,
+ * n_surf near-surface samples (gt_depth>0: [0.95d,1.05d]; else [0.001,max d]), ascending merge.
+ *   t_lin   float32 [n_lin]  = torch.linspace(0,1,n_lin)
+ *   t_surf  float64 [n_surf] = torch.linspace(0,1,n_surf).double()   (ignored if n_surf == 0)
+ *   t_rand  float32 [N,n_lin] or NULL (perturb == 0)
+ *   scratch float32 [2]: receives max(gt_depth) (batch-global, Renderer.py:110,145)
+ *   z_vals  float64 [N, n_lin + n_surf] (n_surf forced to 0 when gt_depth is NULL)
+ * Bit-exact with the reference's float64/float32 evaluation order. */
+int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const float *rays_o, const float *rays_d,
+                       const float *gt_depth, const double *bound_host, const float *t_lin, const double *t_surf,
+                       int32_t lindisp, const float *t_rand, float *scratch, double *z_vals, void *stream);
+
+/* Forward of Renderer.render_batch_ray lines 173-181 + eval_points (Renderer.py:24-62) +
+ * NICE.forward (decoder.py:312-342) + raw2outputs_nerf_color (common.py:256-297, occupancy):
+ * points, bound mask, trilinear gather, decoders, alpha compositing.  S must be 16, 32 or 48.
+ * raw_out (may be NULL) receives the per-sample (r,g,b,occ) needed by enslam_render_bwd. */
+int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                      const double *z_vals, const enslam_scene *scene, double *depth, double *var, float *rgb,
+                      float *raw_out, void *stream);
+
+/* Forward of Renderer.eval_points (Renderer.py:24-62) on explicit points p float64 [P,3].
+ * apply_mask = 0 gives the bare decoder call NICE.forward (decoder.py:312-342, as Mesher.py:308 uses it). */
+int enslam_eval_points(int32_t stage, int64_t n_points, const double *points, const enslam_scene *scene,
+                       int32_t apply_mask, float *raw_out, void *stream);
+
+/* Hand-derived backward of enslam_render_fwd (replaces autograd of the reference ops).
+ *   g_depth float64 [N], g_var float64 [N] or NULL, g_rgb float32 [N,3] or NULL
+ *   grad_grids[k].data : voxel-major accumulators (caller-zeroed) or NULL to skip that grid
+ *   grad_packed[k]     : packed-layout accumulators (caller-zeroed, enslam_packed_grad_floats) or NULL
+ *   g_rays_o/g_rays_d  : float32 [N,3] accumulators (caller-zeroed) or NULL
+ *   d_raw              : float32 [N*S,4] workspace
+ * Gradients follow the reference's autograd exactly: none through the out-of-bound occupancy
+ * overwrite (Renderer.py:58), none to grid_middle / positions through the fine decoder's
+ * concatenated middle feature (decoder.py:184-186), none to z_vals. */
+int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                      const double *z_vals, const enslam_scene *scene, const float *raw, const double *depth,
+                      const double *g_depth, const double *g_var, const float *g_rgb,
+                      const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o, float *g_rays_d,
+                      float *d_raw, void *stream);
+
+/* Parity helper: base voxel index and fractions the gather uses for points p float64 [P,3]
+ * (normalize_3d_coordinate, common.py:342-357, then ATen grid_sampler unnormalize/clip/floor). */
+int enslam_voxel_index(int64_t n_points, const double *points, const double *bound_host, int32_t D, int32_t H,
+                       int32_t W, int32_t *ix, int32_t *iy, int32_t *iz, float *fx, float *fy, float *fz,
+                       void *stream);
+
+/* Parity helper: points p = o + d*z (float64 [N*S,3]) and the strict in-bound mask (uint8 [N*S]). */
+int enslam_ray_points(int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                      const double *z_vals, const double *bound_host, double *points, uint8_t *mask, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENSLAM_HIP_H */
