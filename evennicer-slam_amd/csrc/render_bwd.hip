@@ -1,4 +1,726 @@
+// Hand-derived backward of the rendering hot path for gfx950.
+//
+//   composite_bwd_kernel : one wave per ray; d(depth,var,rgb) -> d_raw[sample] = (dr,dg,db,docc)
+//                          (backward of common.py:284-296, occupancy branch; suffix sums by shuffles)
+//   decoder_bwd_kernel   : persistent workgroups (one per CU, 4 waves), each workgroup specialised on ONE
+//                          decoder of the stage.  A wave takes a 16-sample tile at a time:
+//                            recompute gather + embedding + forward chain in registers (nothing is saved by
+//                            the forward but raw/z) -> backward chain on MFMA (dX = W^T dY) ->
+//                            weight gradients as MFMA outer products over the tile's 16 samples, operands
+//                            transposed through wave-private LDS, accumulated with LDS atomics into ONE
+//                            workgroup-wide accumulator that is flushed once at the end ->
+//                            feature gradient scattered to the voxel-major grid gradient with 256-byte
+//                            contiguous float atomics; coordinate gradient reduced per ray.
+//
+// Gradient semantics follow the reference's autograd: no gradient through the out-of-bound overwrite
+// (Renderer.py:58: sigmoid'(10*100) is exactly 0), none to grid_middle / the position through the fine
+// decoder's concatenated middle feature (decoder.py:184-186), none to z_vals, and the colour decoder's
+// 4th output is unused (decoder.py:338-341).
+#include <type_traits>
+#include "common.hpp"
 #include "kernels.hpp"
-int ens_launch_render_bwd(int, int, int, const float*, const float*, const double*, const DevScene&, const float*,
-                          const double*, const double*, const double*, const float*, const DevGrid*, float* const*,
-                          float*, float*, float*, hipStream_t) { return -3; }
+
+#define IC(n) std::integral_constant<int, n>{}
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// composite backward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void composite_bwd_kernel(int S, const float* __restrict__ raw,
+                                                           const double* __restrict__ z_vals,
+                                                           const double* __restrict__ depth,
+                                                           const double* __restrict__ g_depth,
+                                                           const double* __restrict__ g_var,
+                                                           const float* __restrict__ g_rgb,
+                                                           float* __restrict__ d_raw) {
+    const int lane = threadIdx.x;
+    const int64_t ray = blockIdx.x, sidx = ray * S + lane;
+    const bool valid = lane < S;
+    f32x4 rw = valid ? *reinterpret_cast<const f32x4*>(raw + sidx * 4) : splat4(0.f);
+    const double zk = valid ? z_vals[sidx] : 0.0;
+    const float alpha = valid ? 1.f / (1.f + expf(-(10.f * rw[3]))) : 0.f;
+    const float m = valid ? (1.f - alpha) + 1e-10f : 1.f;
+    float incl = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(incl, off);
+        incl = lane >= off ? incl * t : incl;
+    }
+    float T = __shfl_up(incl, 1);
+    T = lane == 0 ? 1.f : T;
+    const float w = alpha * T;
+    const double dep = depth[ray];
+    const double gD = g_depth ? g_depth[ray] : 0.0, gV = g_var ? g_var[ray] : 0.0;
+    float gc[3] = {0.f, 0.f, 0.f};
+    if (g_rgb) { gc[0] = g_rgb[ray * 3]; gc[1] = g_rgb[ray * 3 + 1]; gc[2] = g_rgb[ray * 3 + 2]; }
+    const double tmp = zk - dep;
+    // var depends on depth through tmp:  d var / d depth = -2 sum_k w_k tmp_k
+    const double gDt = gD - 2.0 * gV * wave_sum((double)w * tmp);
+    float gw = (float)(gDt * zk + gV * tmp * tmp);
+    gw += gc[0] * rw[0] + gc[1] * rw[1] + gc[2] * rw[2];
+    gw = valid ? gw : 0.f;
+    // exclusive suffix sum of gw*w  (cumprod backward: d m_j = sum_{k>j} gw_k w_k / m_j)
+    const float gww = gw * w;
+    float suf = gww;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_down(suf, off);
+        suf = lane + off < 64 ? suf + t : suf;
+    }
+    suf -= gww;
+    const float ga = gw * T - suf / m;
+    const float gocc = ga * (1.f - alpha) * alpha * 10.f;
+    if (valid) *reinterpret_cast<f32x4*>(d_raw + sidx * 4) = f32x4{gc[0] * w, gc[1] * w, gc[2] * w, gocc};
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS helpers (wave-private transposition scratch + workgroup-wide gradient accumulator)
+// ------------------------------------------------------------------------------------------------
+// A "deposit" stores register tiles so that they can be read back with the SAMPLE index in the MFMA K slot:
+//   float address(tile T, feature i in 0..15, sample pt in 0..15) = T*256 + (pt>>2)*64 + i*4 + (pt&3)
+// so the fragment of tile T is the lane-linear 16-byte read at T*256 + lane*4, whose component s belongs to
+// (feature lane&15, sample 4*(lane>>4)+s): A and B operands of a 16x16x4 MFMA that sums over samples.
+ENS_DEV void deposit(float* dep, int T, const f32x4& x, int p, int q) {
+    float* d = dep + T * 256 + (p >> 2) * 64 + (p & 3) + 16 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[4 * r] = x[r];
+}
+ENS_DEV f32x4 frag(const float* dep, int T, int lane) { return *reinterpret_cast<const f32x4*>(dep + T * 256 + lane * 4); }
+
+ENS_DEV void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+ENS_DEV void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// sacc[(16rt+4q+r)*ld + col0 + 16ct + p] += sum_samples Y[sample][16rt+i] * X[sample][16ct+j]
+// rows >= rows_valid / cols >= cols_valid are padding and skipped.
+template <int NR, int NC>
+ENS_DEV void outer_acc(float* sacc, int ld, int col0, const float* depY, int y0, const float* depX, int x0,
+                       int rows_valid, int cols_valid, int lane, int p, int q) {
+    f32x4 a[NR], b[NC];
+#pragma unroll
+    for (int rt = 0; rt < NR; ++rt) a[rt] = frag(depY, y0 + rt, lane);
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) b[ct] = frag(depX, x0 + ct, lane);
+#pragma unroll
+    for (int rt = 0; rt < NR; ++rt) {
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) {
+            f32x4 acc = splat4(0.f);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = MFMA16(a[rt][s], b[ct][s], acc);
+            const int col = 16 * ct + p;
+            if (col < cols_valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * rt + 4 * q + r;
+                    if (row < rows_valid) lds_add(sacc + row * ld + col0 + col, acc[r]);
+                }
+            }
+        }
+    }
+}
+
+// acc[rt] += M[(16rt+p)*ld + 16t + 4q ..] * x[t]   (NR output row tiles, KT input tiles), single sample tile
+template <int NR, int KT>
+ENS_DEV void linear_n(f32x4 (&acc)[NR], const float* __restrict__ M, int ld, const f32x4 (&x)[KT], int p, int q) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt) {
+            const f32x4 a = ld4(M + (16 * rt + p) * ld + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rt] = MFMA16(a[r], x[t][r], acc[rt]);
+        }
+    }
+}
+
+ENS_DEV f32x4 mask4(const f32x4& v, unsigned bits, int sh) {
+    return f32x4{(bits >> sh) & 1u ? v[0] : 0.f, (bits >> (sh + 1)) & 1u ? v[1] : 0.f,
+                 (bits >> (sh + 2)) & 1u ? v[2] : 0.f, (bits >> (sh + 3)) & 1u ? v[3] : 0.f};
+}
+ENS_DEV unsigned pos_bits(const f32x4& v) {
+    return (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-tile geometry shared by the decoder roles
+// ------------------------------------------------------------------------------------------------
+struct TileGeo {
+    double pw[3];
+    float zf;
+    int64_t sidx;
+    int ray;
+};
+
+ENS_DEV TileGeo tile_geo(int64_t tile, int ntl, int S, const float* ro, const float* rd, const double* z, int p) {
+    TileGeo g;
+    g.ray = (int)(tile / ntl);
+    const int tl = (int)(tile - (int64_t)g.ray * ntl);
+    g.sidx = (int64_t)g.ray * S + 16 * tl + p;
+    const double zz = z[g.sidx];
+    g.zf = (float)zz;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) g.pw[a] = (double)ro[g.ray * 3 + a] + (double)rd[g.ray * 3 + a] * zz;
+    return g;
+}
+
+// Coordinate gradient through the trilinear weights (ATen grid_sampler_3d_backward, gix/giy/giz) for the lane's
+// 8 channels; partial over channels -> caller reduces over the 4 q lanes.
+ENS_DEV void coord_grad_partial(const Vox& v, const DevGrid& g, int q, const f32x4& d0, const f32x4& d1, float& gx,
+                                float& gy, float& gz) {
+    gx = gy = gz = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+        int x = v.ix + dx, y = v.iy + dy, z = v.iz + dz;
+        const bool ok = (x < g.W) && (y < g.H) && (z < g.D);
+        x = min(x, g.W - 1); y = min(y, g.H - 1); z = min(z, g.D - 1);
+        const float* src = g.data + (((int64_t)z * g.H + y) * g.W + x) * 32 + 4 * q;
+        const f32x4 a = ld4(src), b = ld4(src + 16);
+        float dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dot = fmaf(a[r], d0[r], fmaf(b[r], d1[r], dot));
+        dot = ok ? dot : 0.f;
+        const float wx = dx ? v.fx : (1.f - v.fx), wy = dy ? v.fy : (1.f - v.fy), wz = dz ? v.fz : (1.f - v.fz);
+        gx += (dx ? dot : -dot) * wy * wz;
+        gy += (dy ? dot : -dot) * wx * wz;
+        gz += (dz ? dot : -dot) * wx * wy;
+    }
+}
+
+// Scatter the tile's feature gradient (deposited as [sample][32] floats in `dep`) into the voxel-major grid
+// gradient: per sample 4 wave instructions, each 2 x-adjacent corners x 32 channels = 256 contiguous bytes.
+ENS_DEV void scatter_tile(const float* dep, const Vox& v, const DevGrid& gg, int lane) {
+    const int ch = lane & 31, dxb = lane >> 5;
+#pragma unroll
+    for (int pt = 0; pt < 16; ++pt) {
+        const float val = dep[pt * 32 + ch];
+        if (!__any(val != 0.f)) continue;                 // e.g. masked samples of an occupancy decoder
+        const int ix = __builtin_amdgcn_readlane(v.ix, pt), iy = __builtin_amdgcn_readlane(v.iy, pt),
+                  iz = __builtin_amdgcn_readlane(v.iz, pt);
+        const float fx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.fx), pt));
+        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.fy), pt));
+        const float fz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.fz), pt));
+        const int x = ix + dxb;
+        const float wx = dxb ? fx : (1.f - fx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dy = k & 1, dz = k >> 1;
+            const int y = iy + dy, z = iz + dz;
+            const bool ok = (x < gg.W) && (y < gg.H) && (z < gg.D);
+            const float w = (wx * (dy ? fy : (1.f - fy))) * (dz ? fz : (1.f - fz));
+            if (ok) atomicAdd(gg.data + (((int64_t)z * gg.H + y) * gg.W + x) * 32 + ch, w * val);
+        }
+    }
+}
+
+// reduce the per-sample position gradient over the tile and add it to the ray gradients
+ENS_DEV void add_ray_grad(float dpx, float dpy, float dpz, float zf, int ray, float* g_ro, float* g_rd, int lane) {
+    float v[6] = {dpx, dpy, dpz, dpx * zf, dpy * zf, dpz * zf};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicAdd(g_ro + ray * 3 + a, v[a]); atomicAdd(g_rd + ray * 3 + a, v[3 + a]); }
+    }
+}
+
+struct BwdArgs {
+    int n_rays, ntl;
+    const float* ro;
+    const float* rd;
+    const double* z;
+    const float* d_raw;
+    DevScene sc;
+    DevGrid ggrid[4];        // gradient accumulators (data may be null)
+    float* gpacked[4];       // packed-layout gradient accumulators (may be null)
+    float* g_ro;
+    float* g_rd;
+    int role_begin[5];       // workgroup ranges of the roles (decoder kinds) of this launch
+    int role_kind[4];
+    int n_roles;
+};
+
+// ------------------------------------------------------------------------------------------------
+// MLP (middle / fine / color) backward for one workgroup role
+// ------------------------------------------------------------------------------------------------
+template <int CT, int NOUT>
+ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem) {
+    constexpr XyzLay L{CT * 16};
+    constexpr int GF = L.fwd_floats();
+    constexpr int WSCR = (6 + CT + 2 + 2 + 2 + 1) * 256;           // emb, c, x, dh, dpre, coords tiles (floats)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+    const float* __restrict__ pk = A.sc.packed[kind];
+    const DevGrid grid = A.sc.grid[kind];
+    const DevGrid ggrid = A.ggrid[kind];
+    float* gpk = A.gpacked[kind];
+    const bool want_w = gpk != nullptr, want_g = ggrid.data != nullptr, want_r = A.g_ro != nullptr;
+    const bool want_c = want_g || want_r;
+
+    float* sacc = smem;                                              // [GF] workgroup-wide dW accumulator
+    float* scr = smem + GF + wave * WSCR;
+    float* dEmb = scr;                       // 6 tiles: embedding (later d_arg)
+    float* dC = dEmb + 6 * 256;              // CT tiles: grid features
+    float* dX = dC + CT * 256;               // 2 tiles: layer input h_{i-1}
+    float* dH = dX + 2 * 256;                // 2 tiles: dh_i (also the [sample][32] scatter staging)
+    float* dP = dH + 2 * 256;                // 2 tiles: dpre_i
+    float* dQ = dP + 2 * 256;                // 1 tile : coordinates / d_out
+    for (int e = threadIdx.x; e < GF; e += 256) sacc[e] = 0.f;
+    __syncthreads();
+
+    f32x4 gb[5][2], gbc[5][2];               // bias gradients, per-lane partial sums over this wave's tiles
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { gb[i][0] = gb[i][1] = gbc[i][0] = gbc[i][1] = splat4(0.f); }
+    f32x4 gbo = splat4(0.f);
+
+    const int64_t n_tiles = (int64_t)A.n_rays * A.ntl;
+    const int S = 16 * A.ntl;
+    for (int64_t tile = (int64_t)wg * 4 + wave; tile < n_tiles; tile += (int64_t)n_wg * 4) {
+        const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
+        const f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4);
+        // output gradient of this decoder as a D-layout tile (rows 0..NOUT-1 live on q == 0 lanes)
+        f32x4 dout = splat4(0.f);
+        if (q == 0) dout = NOUT == 4 ? f32x4{draw[0], draw[1], draw[2], 0.f} : f32x4{draw[3], 0.f, 0.f, 0.f};
+        if (!__any(dout[0] != 0.f || dout[1] != 0.f || dout[2] != 0.f)) continue;   // nothing flows into this tile
+
+        // ---- recompute the forward chain
+        const float pc = q == 0 ? (float)G.pw[0] : (q == 1 ? (float)G.pw[1] : (q == 2 ? (float)G.pw[2] : 0.f));
+        const Vox v = make_vox(G.pw, A.sc.lo, A.sc.hi, grid);
+        f32x4 c[1][CT];
+        gather8(v, grid, q, c[0][0], c[0][1]);
+        if constexpr (CT == 4) {
+            const Vox vm = make_vox(G.pw, A.sc.lo, A.sc.hi, A.sc.grid[1]);
+            gather8(vm, A.sc.grid[1], q, c[0][2], c[0][3]);
+        }
+        f32x4 emb[1][6], cosv[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const float a = pk[L.oBT() + (16 * t + p) * 4 + q];
+            const f32x4 arg = MFMA16(a, pc, splat4(0.f));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sv, cv;
+                ens_sincosf(arg[r], sv, cv);
+                emb[0][t][r] = sv;
+                cosv[t][r] = cv;
+            }
+        }
+        f32x4 h[5][1][2];
+        unsigned mbits[5];
+        auto fwd_layer = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            f32x4 acc[1][2];
+            acc[0][0] = ld4(pk + L.ob(i) + 4 * q);
+            acc[0][1] = ld4(pk + L.ob(i) + 16 + 4 * q);
+            if constexpr (i == 0) {
+                linear32<6, 1, 6>(acc, pk + L.oW(0), 96, emb, 0, p, q);
+            } else if constexpr (i == 3) {
+                linear32<6, 1, 6>(acc, pk + L.oW(3), 128, emb, 0, p, q);
+                linear32<2, 1, 2>(acc, pk + L.oW(3) + 96, 128, h[2], 0, p, q);
+            } else {
+                linear32<2, 1, 2>(acc, pk + L.oW(i), 32, h[i - 1], 0, p, q);
+            }
+            mbits[i] = pos_bits(acc[0][0]) | (pos_bits(acc[0][1]) << 4);
+            acc[0][0] = relu4(acc[0][0]) + ld4(pk + L.obc(i) + 4 * q);
+            acc[0][1] = relu4(acc[0][1]) + ld4(pk + L.obc(i) + 16 + 4 * q);
+            linear32<CT, 1, CT>(acc, pk + L.oWc(i), CT * 16, c, 0, p, q);
+            h[i][0][0] = acc[0][0];
+            h[i][0][1] = acc[0][1];
+        };
+        fwd_layer(IC(0)); fwd_layer(IC(1)); fwd_layer(IC(2)); fwd_layer(IC(3)); fwd_layer(IC(4));
+
+        // ---- backward chain
+        if (want_w) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) deposit(dEmb, t, emb[0][t], p, q);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) deposit(dC, t, c[0][t], p, q);
+            deposit(dQ, 0, dout, p, q);
+            deposit(dX, 0, h[4][0][0], p, q);
+            deposit(dX, 1, h[4][0][1], p, q);
+            wave_lds_fence();
+            outer_acc<1, 2>(sacc + L.oWo(), 32, 0, dQ, 0, dX, 0, NOUT, 32, lane, p, q);       // dWo
+            gbo += dout;
+            wave_lds_fence();
+        }
+        f32x4 dh[2] = {splat4(0.f), splat4(0.f)};
+        {   // dh4 = Wo^T d_out (K = 4: one step per row tile; k-slot q carries output q)
+            const float dq = NOUT == 4 ? (q == 0 ? draw[0] : (q == 1 ? draw[1] : (q == 2 ? draw[2] : 0.f)))
+                                       : (q == 0 ? draw[3] : 0.f);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) dh[rt] = MFMA16(pk[L.oWoT() + (16 * rt + p) * 4 + q], dq, dh[rt]);
+        }
+        f32x4 dc[2] = {splat4(0.f), splat4(0.f)};
+        f32x4 demb[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) demb[t] = splat4(0.f);
+        auto bwd_layer = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            f32x4 dpre[2] = {mask4(dh[0], mbits[i], 0), mask4(dh[1], mbits[i], 4)};
+            if (want_w) {
+                gbc[i][0] += dh[0]; gbc[i][1] += dh[1];
+                gb[i][0] += dpre[0]; gb[i][1] += dpre[1];
+                deposit(dH, 0, dh[0], p, q); deposit(dH, 1, dh[1], p, q);
+                deposit(dP, 0, dpre[0], p, q); deposit(dP, 1, dpre[1], p, q);
+                if constexpr (i == 1 || i == 2 || i == 4) { deposit(dX, 0, h[i - 1][0][0], p, q); deposit(dX, 1, h[i - 1][0][1], p, q); }
+                if constexpr (i == 3) { deposit(dX, 0, h[2][0][0], p, q); deposit(dX, 1, h[2][0][1], p, q); }
+                wave_lds_fence();
+                outer_acc<2, CT>(sacc + L.oWc(i), CT * 16, 0, dH, 0, dC, 0, 32, CT * 16, lane, p, q);     // dWc_i
+                if constexpr (i == 0) {
+                    outer_acc<2, 6>(sacc + L.oW(0), 96, 0, dP, 0, dEmb, 0, 32, 96, lane, p, q);
+                } else if constexpr (i == 3) {
+                    outer_acc<2, 6>(sacc + L.oW(3), 128, 0, dP, 0, dEmb, 0, 32, 96, lane, p, q);
+                    outer_acc<2, 2>(sacc + L.oW(3), 128, 96, dP, 0, dX, 0, 32, 32, lane, p, q);
+                } else {
+                    outer_acc<2, 2>(sacc + L.oW(i), 32, 0, dP, 0, dX, 0, 32, 32, lane, p, q);
+                }
+                wave_lds_fence();
+            }
+            if (want_c) linear_n<2, 2>(dc, pk + L.oWcT(i), 32, dh, p, q);                 // dC += Wc_i^T dh_i
+            if constexpr (i == 0) {
+                if (want_r || want_w) linear_n<6, 2>(demb, pk + L.oWT(0), 32, dpre, p, q);
+            } else if constexpr (i == 3) {
+                if (want_r || want_w) linear_n<6, 2>(demb, pk + L.oWT(3), 32, dpre, p, q);
+                dh[0] = dh[1] = splat4(0.f);
+                linear_n<2, 2>(dh, pk + L.oWT(3) + 96 * 32, 32, dpre, p, q);
+            } else {
+                dh[0] = dh[1] = splat4(0.f);
+                linear_n<2, 2>(dh, pk + L.oWT(i), 32, dpre, p, q);
+            }
+        };
+        bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
+        // ---- embedding: d_arg = d_emb * cos(arg);  dB^T += d_arg (x) p ;  dp += B d_arg
+        float dpx = 0.f, dpy = 0.f, dpz = 0.f;
+        if (want_r || want_w) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) demb[t] *= cosv[t];
+            if (want_w) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) deposit(dEmb, t, demb[t], p, q);
+                f32x4 pt4 = splat4(0.f);
+                if (q == 0) pt4 = f32x4{(float)G.pw[0], (float)G.pw[1], (float)G.pw[2], 0.f};
+                deposit(dQ, 0, pt4, p, q);
+                wave_lds_fence();
+                outer_acc<6, 1>(sacc + L.oBT(), 4, 0, dEmb, 0, dQ, 0, 93, 3, lane, p, q);
+                wave_lds_fence();
+            }
+            if (want_r) {
+                f32x4 dpe[1] = {splat4(0.f)};
+                linear_n<1, 6>(dpe, pk + L.oBp(), 96, demb, p, q);
+                dpx = dpe[0][0]; dpy = dpe[0][1]; dpz = dpe[0][2];      // valid on q == 0 lanes
+            }
+        }
+        // ---- grid: coordinate gradient and feature-gradient scatter
+        if (want_c) {
+            if (want_r) {
+                float gx, gy, gz;
+                coord_grad_partial(v, grid, q, dc[0], dc[1], gx, gy, gz);
+                gx += __shfl_xor(gx, 16); gx += __shfl_xor(gx, 32);
+                gy += __shfl_xor(gy, 16); gy += __shfl_xor(gy, 32);
+                gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
+                dpx += gx * v.gx; dpy += gy * v.gy; dpz += gz * v.gz;
+            }
+            if (want_g) {
+                // stage dC as [sample][32 channels]
+                *reinterpret_cast<f32x4*>(dH + p * 32 + 4 * q) = dc[0];
+                *reinterpret_cast<f32x4*>(dH + p * 32 + 16 + 4 * q) = dc[1];
+                wave_lds_fence();
+                scatter_tile(dH, v, ggrid, lane);
+                wave_lds_fence();
+            }
+        }
+        if (want_r) {
+            if (q != 0) { dpx = dpy = dpz = 0.f; }
+            add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
+        }
+    }
+
+    // ---- bias gradients: reduce over the 16 sample lanes, add to the workgroup accumulator
+    if (want_w) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = gb[i][rt][r], b = gbc[i][rt][r];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+                    if (p == 0) {
+                        lds_add(sacc + L.ob(i) + 16 * rt + 4 * q + r, a);
+                        lds_add(sacc + L.obc(i) + 16 * rt + 4 * q + r, b);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = gbo[r];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0 && r < NOUT) lds_add(sacc + L.obo() + r, a);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < GF; e += 256) {
+            const float vsum = sacc[e];
+            if (vsum != 0.f) atomicAdd(gpk + e, vsum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MLP_no_xyz (coarse) backward role
+// ------------------------------------------------------------------------------------------------
+ENS_DEV void feat_role(const BwdArgs& A, int wg, int n_wg, float* smem) {
+    constexpr FeatLay L{};
+    constexpr int GF = L.fwd_floats();
+    constexpr int WSCR = (2 + 2 + 2 + 1) * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+    const float* __restrict__ pk = A.sc.packed[0];
+    const DevGrid grid = A.sc.grid[0];
+    const DevGrid ggrid = A.ggrid[0];
+    float* gpk = A.gpacked[0];
+    const bool want_w = gpk != nullptr, want_g = ggrid.data != nullptr, want_r = A.g_ro != nullptr;
+    float* sacc = smem;
+    float* scr = smem + GF + wave * WSCR;
+    float* dC = scr;                 // 2 tiles: grid features
+    float* dX = dC + 2 * 256;        // 2 tiles: layer input
+    float* dP = dX + 2 * 256;        // 2 tiles: dpre (also scatter staging)
+    float* dQ = dP + 2 * 256;        // 1 tile : d_out
+    for (int e = threadIdx.x; e < GF; e += 256) sacc[e] = 0.f;
+    __syncthreads();
+    f32x4 gb[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) gb[i][0] = gb[i][1] = splat4(0.f);
+    f32x4 gbo = splat4(0.f);
+
+    const int64_t n_tiles = (int64_t)A.n_rays * A.ntl;
+    const int S = 16 * A.ntl;
+    for (int64_t tile = (int64_t)wg * 4 + wave; tile < n_tiles; tile += (int64_t)n_wg * 4) {
+        const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
+        const f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4);
+        f32x4 dout = splat4(0.f);
+        if (q == 0) dout[0] = draw[3];
+        if (!__any(dout[0] != 0.f)) continue;
+        const Vox v = make_vox(G.pw, A.sc.clo, A.sc.chi, grid);
+        f32x4 c[1][2];
+        gather8(v, grid, q, c[0][0], c[0][1]);
+        f32x4 h[5][1][2];
+        unsigned mbits[5];
+        auto fwd_layer = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            f32x4 acc[1][2];
+            acc[0][0] = ld4(pk + L.ob(i) + 4 * q);
+            acc[0][1] = ld4(pk + L.ob(i) + 16 + 4 * q);
+            if constexpr (i == 0) {
+                linear32<2, 1, 2>(acc, pk + L.oW(0), 32, c, 0, p, q);
+            } else if constexpr (i == 3) {
+                linear32<2, 1, 2>(acc, pk + L.oW(3), 64, c, 0, p, q);
+                linear32<2, 1, 2>(acc, pk + L.oW(3) + 32, 64, h[2], 0, p, q);
+            } else {
+                linear32<2, 1, 2>(acc, pk + L.oW(i), 32, h[i - 1], 0, p, q);
+            }
+            mbits[i] = pos_bits(acc[0][0]) | (pos_bits(acc[0][1]) << 4);
+            h[i][0][0] = relu4(acc[0][0]);
+            h[i][0][1] = relu4(acc[0][1]);
+        };
+        fwd_layer(IC(0)); fwd_layer(IC(1)); fwd_layer(IC(2)); fwd_layer(IC(3)); fwd_layer(IC(4));
+        if (want_w) {
+            deposit(dC, 0, c[0][0], p, q); deposit(dC, 1, c[0][1], p, q);
+            deposit(dQ, 0, dout, p, q);
+            deposit(dX, 0, h[4][0][0], p, q); deposit(dX, 1, h[4][0][1], p, q);
+            wave_lds_fence();
+            outer_acc<1, 2>(sacc + L.oWo(), 32, 0, dQ, 0, dX, 0, 1, 32, lane, p, q);
+            gbo += dout;
+            wave_lds_fence();
+        }
+        f32x4 dh[2] = {splat4(0.f), splat4(0.f)};
+        {
+            const float dq = q == 0 ? draw[3] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) dh[rt] = MFMA16(pk[L.oWoT() + (16 * rt + p) * 4 + q], dq, dh[rt]);
+        }
+        f32x4 dc[2] = {splat4(0.f), splat4(0.f)};
+        auto bwd_layer = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            f32x4 dpre[2] = {mask4(dh[0], mbits[i], 0), mask4(dh[1], mbits[i], 4)};
+            if (want_w) {
+                gb[i][0] += dpre[0]; gb[i][1] += dpre[1];
+                deposit(dP, 0, dpre[0], p, q); deposit(dP, 1, dpre[1], p, q);
+                if constexpr (i >= 1) {
+                    constexpr int j = i == 3 ? 2 : i - 1;
+                    deposit(dX, 0, h[j][0][0], p, q); deposit(dX, 1, h[j][0][1], p, q);
+                }
+                wave_lds_fence();
+                if constexpr (i == 0) {
+                    outer_acc<2, 2>(sacc + L.oW(0), 32, 0, dP, 0, dC, 0, 32, 32, lane, p, q);
+                } else if constexpr (i == 3) {
+                    outer_acc<2, 2>(sacc + L.oW(3), 64, 0, dP, 0, dC, 0, 32, 32, lane, p, q);
+                    outer_acc<2, 2>(sacc + L.oW(3), 64, 32, dP, 0, dX, 0, 32, 32, lane, p, q);
+                } else {
+                    outer_acc<2, 2>(sacc + L.oW(i), 32, 0, dP, 0, dX, 0, 32, 32, lane, p, q);
+                }
+                wave_lds_fence();
+            }
+            if constexpr (i == 0) {
+                linear_n<2, 2>(dc, pk + L.oWT(0), 32, dpre, p, q);
+            } else if constexpr (i == 3) {
+                linear_n<2, 2>(dc, pk + L.oWT(3), 32, dpre, p, q);
+                dh[0] = dh[1] = splat4(0.f);
+                linear_n<2, 2>(dh, pk + L.oWT(3) + 32 * 32, 32, dpre, p, q);
+            } else {
+                dh[0] = dh[1] = splat4(0.f);
+                linear_n<2, 2>(dh, pk + L.oWT(i), 32, dpre, p, q);
+            }
+        };
+        bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
+        if (want_r) {
+            float gx, gy, gz;
+            coord_grad_partial(v, grid, q, dc[0], dc[1], gx, gy, gz);
+            gx += __shfl_xor(gx, 16); gx += __shfl_xor(gx, 32);
+            gy += __shfl_xor(gy, 16); gy += __shfl_xor(gy, 32);
+            gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
+            float dpx = gx * v.gx, dpy = gy * v.gy, dpz = gz * v.gz;
+            if (q != 0) { dpx = dpy = dpz = 0.f; }
+            add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
+        }
+        if (want_g) {
+            *reinterpret_cast<f32x4*>(dP + p * 32 + 4 * q) = dc[0];
+            *reinterpret_cast<f32x4*>(dP + p * 32 + 16 + 4 * q) = dc[1];
+            wave_lds_fence();
+            scatter_tile(dP, v, ggrid, lane);
+            wave_lds_fence();
+        }
+    }
+    if (want_w) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = gb[i][rt][r];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                    if (p == 0) lds_add(sacc + L.ob(i) + 16 * rt + 4 * q + r, a);
+                }
+            }
+        }
+        float a = gbo[0];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) lds_add(sacc + L.obo(), a);
+        __syncthreads();
+        for (int e = threadIdx.x; e < GF; e += 256) {
+            const float vsum = sacc[e];
+            if (vsum != 0.f) atomicAdd(gpk + e, vsum);
+        }
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) float ens_smem[];
+
+__global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(BwdArgs A) {
+    int role = 0;
+#pragma unroll
+    for (int r = 1; r < 4; ++r) role = (r < A.n_roles && (int)blockIdx.x >= A.role_begin[r]) ? r : role;
+    const int wg = blockIdx.x - A.role_begin[role], n_wg = A.role_begin[role + 1] - A.role_begin[role];
+    const int kind = A.role_kind[role];
+    switch (kind) {
+        case 0: feat_role(A, wg, n_wg, ens_smem); break;
+        case 1: xyz_role<2, 1>(A, 1, wg, n_wg, ens_smem); break;
+        case 2: xyz_role<4, 1>(A, 2, wg, n_wg, ens_smem); break;
+        case 3: xyz_role<2, 4>(A, 3, wg, n_wg, ens_smem); break;
+        default: break;
+    }
+}
+
+constexpr int lds_bytes_xyz(int ct) { return (XyzLay{ct * 16}.fwd_floats() + 4 * (6 + ct + 2 + 2 + 2 + 1) * 256) * 4; }
+constexpr int lds_bytes_feat() { return (FeatLay{}.fwd_floats() + 4 * 7 * 256) * 4; }
+
+int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+}  // namespace
+
+int ens_launch_render_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
+                          const DevScene& sc, const float* raw, const double* depth, const double* g_depth,
+                          const double* g_var, const float* g_rgb, const DevGrid* grad_grids,
+                          float* const* grad_packed, float* g_ro, float* g_rd, float* d_raw, hipStream_t st) {
+    if (n_rays <= 0) return 0;
+    const int S = 16 * ntl;
+    composite_bwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(S, raw, z, depth, g_depth, g_var, g_rgb, d_raw);
+    if (hipGetLastError() != hipSuccess) return -2;
+
+    BwdArgs A;
+    A.n_rays = n_rays; A.ntl = ntl; A.ro = ro; A.rd = rd; A.z = z; A.d_raw = d_raw; A.sc = sc;
+    A.g_ro = (g_ro && g_rd) ? g_ro : nullptr;
+    A.g_rd = (g_ro && g_rd) ? g_rd : nullptr;
+    // roles and their relative cost (MFMA count per tile: middle/color 270, fine 350)
+    int kinds[3], nk = 0;
+    float cost[3];
+    switch (stage) {
+        case 0: kinds[nk] = 0; cost[nk++] = 1.f; break;
+        case 1: kinds[nk] = 1; cost[nk++] = 1.f; break;
+        case 2: kinds[nk] = 1; cost[nk++] = 0.44f; kinds[nk] = 2; cost[nk++] = 0.56f; break;
+        case 3: kinds[nk] = 1; cost[nk++] = 0.30f; kinds[nk] = 2; cost[nk++] = 0.40f; kinds[nk] = 3; cost[nk++] = 0.30f; break;
+        default: return -1;
+    }
+    for (int k = 0; k < 4; ++k) { A.ggrid[k] = DevGrid{nullptr, 0, 0, 0}; A.gpacked[k] = nullptr; }
+    int lds = 0;
+    // drop roles with nothing to produce
+    int kk[3], n2 = 0;
+    float cc[3], csum = 0.f;
+    for (int i = 0; i < nk; ++i) {
+        const int k = kinds[i];
+        const bool any = grad_grids[k].data != nullptr || grad_packed[k] != nullptr || A.g_ro != nullptr;
+        if (!any) continue;
+        A.ggrid[k] = grad_grids[k];
+        A.gpacked[k] = grad_packed[k];
+        kk[n2] = k; cc[n2] = cost[i]; csum += cost[i]; ++n2;
+        const int need = k == 0 ? lds_bytes_feat() : lds_bytes_xyz(k == 2 ? 4 : 2);
+        lds = need > lds ? need : lds;
+    }
+    if (n2 == 0) return 0;
+    const int64_t n_tiles = (int64_t)n_rays * ntl;
+    int total = device_cus();
+    const int64_t max_useful = (n_tiles + 3) / 4 * n2;
+    if (total > max_useful) total = (int)max_useful;
+    if (total < n2) total = n2;
+    A.n_roles = n2;
+    int begin = 0;
+    for (int i = 0; i < n2; ++i) {
+        A.role_kind[i] = kk[i];
+        A.role_begin[i] = begin;
+        int n = (i == n2 - 1) ? total - begin : (int)(total * cc[i] / csum + 0.5f);
+        if (n < 1) n = 1;
+        if (begin + n > total - (n2 - 1 - i)) n = total - (n2 - 1 - i) - begin;
+        begin += n;
+    }
+    A.role_begin[n2] = total;
+    for (int i = n2; i < 4; ++i) A.role_kind[i] = -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_xyz(4)) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
+    decoder_bwd_kernel<<<dim3(total), dim3(256), lds, st>>>(A);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,124 @@
+"""GPU parity, backward: hand-derived HIP backward (through the C ABI + torch.autograd.Function) vs the
+gradients the reference's autograd produced (tests/golden), for all four stages.
+
+Bar: gradients within 1e-3 of the tensor's max magnitude (float atomics reorder sums),
+in practice ~1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import GRID_KEYS, STAGES, load, rel_err
+
+pytestmark = pytest.mark.gpu
+GTOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from tests.hip_util import tiny_on_gpu
+    return tiny_on_gpu()
+
+
+def _run(tiny, stage, cot=None, mapper=False):
+    s, bound, model, grids, rays, renderer = tiny
+    for p in model.parameters():
+        p.grad = None
+    cg = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+    ro = rays['rays_o'].clone().requires_grad_(True)
+    rd = rays['rays_d'].clone().requires_grad_(True)
+    depth, var, color = renderer.render_batch_ray(cg, model, rd, ro, 'cuda:0', stage, gt_depth=rays['gt_depth'])
+    if mapper:
+        m = rays['gt_depth'] > 0
+        loss = torch.abs(rays['gt_depth'][m] - depth[m]).sum()
+        if stage == 'color':
+            loss = loss + 0.2 * torch.abs(rays['gt_color'] - color).sum()
+    else:
+        gd, gv, gc = cot
+        loss = (depth * gd).sum() + (var * gv).sum() + (color * gc).sum()
+    loss.backward()
+    return cg, ro, rd, model, loss
+
+
+def _check(g, cg, ro, rd, model, tol=GTOL):
+    worst = {}
+    worst['rays_o'] = rel_err(ro.grad.cpu().numpy(), g["g_rays_o"])
+    worst['rays_d'] = rel_err(rd.grad.cpu().numpy(), g["g_rays_d"])
+    for k in GRID_KEYS:
+        if "g_" + k in g:
+            assert cg[k].grad is not None, k
+            assert cg[k].grad.shape == cg[k].shape
+            worst[k] = rel_err(cg[k].grad.cpu().numpy(), g["g_" + k])
+        else:
+            assert cg[k].grad is None or float(cg[k].grad.abs().max()) == 0.0, k
+    for name, p in model.named_parameters():
+        if "gp_" + name in g:
+            assert p.grad is not None, name
+            ref = g["gp_" + name]
+            if np.abs(ref).max() == 0:
+                assert float(p.grad.abs().max()) == 0.0, name
+            else:
+                worst[name] = rel_err(p.grad.cpu().numpy(), ref)
+        else:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+    bad = {k: v for k, v in worst.items() if not v < tol}
+    assert not bad, f"gradient mismatch: {bad}"
+    return worst
+
+
+@pytest.mark.parametrize("stage", STAGES)
+def test_backward_random_cotangents(tiny, stage):
+    g = load("tiny_" + stage)
+    cot = [torch.from_numpy(g[k]).cuda() for k in ("cot_depth", "cot_var", "cot_color")]
+    cg, ro, rd, model, loss = _run(tiny, stage, cot=cot)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * max(1.0, abs(float(g["loss"])))
+    worst = _check(g, cg, ro, rd, model)
+    assert len(worst) >= 4
+
+
+def test_backward_mapper_loss_color(tiny):
+    g = load("tiny_color_mapperloss")
+    cg, ro, rd, model, loss = _run(tiny, "color", mapper=True)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    _check(g, cg, ro, rd, model)
+
+
+def test_backward_only_rays_need_grad(tiny):
+    """Tracker case (Tracker.py:248-260): grids carry no grad; gradients flow to the rays only."""
+    s, bound, model, grids, rays, renderer = tiny
+    g = load("tiny_color")
+    cot = [torch.from_numpy(g[k]).cuda() for k in ("cot_depth", "cot_var", "cot_color")]
+    for p in model.parameters():
+        p.requires_grad_(False)
+    try:
+        ro = rays['rays_o'].clone().requires_grad_(True)
+        rd = rays['rays_d'].clone().requires_grad_(True)
+        depth, var, color = renderer.render_batch_ray(grids, model, rd, ro, 'cuda:0', 'color', gt_depth=rays['gt_depth'])
+        ((depth * cot[0]).sum() + (var * cot[1]).sum() + (color * cot[2]).sum()).backward()
+        assert rel_err(ro.grad.cpu().numpy(), g["g_rays_o"]) < GTOL
+        assert rel_err(rd.grad.cpu().numpy(), g["g_rays_d"]) < GTOL
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(True)
+
+
+def test_room0_coarse200_backward():
+    from tests.hip_util import model_from_state, renderer_for
+    g = load("room0_coarse200")
+    bound = torch.from_numpy(g["bound"].copy())
+    model = model_from_state(g, bound)
+    grid = torch.from_numpy(g["grid_coarse"].copy()).cuda().requires_grad_(True)
+    renderer = renderer_for(bound, cam=(680, 1200, 600.0, 600.0, 599.5, 339.5))
+    ro = torch.from_numpy(g["rays_o"]).cuda().requires_grad_(True)
+    rd = torch.from_numpy(g["rays_d"]).cuda().requires_grad_(True)
+    gd = torch.from_numpy(g["gt_depth"]).cuda()
+    depth, var, color = renderer.render_batch_ray({"grid_coarse": grid}, model, rd, ro, 'cuda:0', 'coarse')
+    m = gd > 0
+    loss = torch.abs(gd[m] - depth[m]).sum()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert rel_err(grid.grad.cpu().numpy(), g["g_grid_coarse"]) < GTOL
+    assert rel_err(rd.grad.cpu().numpy(), g["g_rays_d"]) < GTOL
+    assert rel_err(ro.grad.cpu().numpy(), g["g_rays_o"]) < GTOL
+    for name, p in model.named_parameters():
+        if "gp_" + name in g and np.abs(g["gp_" + name]).max() > 0:
+            assert rel_err(p.grad.cpu().numpy(), g["gp_" + name]) < GTOL, name
