@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the volume-rendering hot path (BASELINE.json metric: rendered rays/sec, fwd+bwd).
+
+One "step" = Renderer.render_batch_ray (sampling, gather, decoders, compositing) + the mapper's loss
+(Mapper.py:553-562) + backward producing gradients for the three feature grids, EVERY decoder parameter
+(the reference never freezes any, so its autograd computes them all) and the rays -- on synthetic data of
+BASELINE configs[1]: Replica room0, full 4-level grid, stage `color`, 1000 rays x 48 samples per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; rays are sharded, i.e. every rank renders its
+   own 1000-ray block (weak scaling), and leaf gradients are summed with one bucketed RCCL all-reduce.)
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the `roofline` and `cpu_baseline` objects).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# yardstick of SURVEY.md 8(d): linear-layer FLOPs per sample point, 2*MAC
+FLOP_FWD_PER_POINT = {'coarse': 12352, 'middle': 30958, 'fine': 72156, 'color': 103306}
+PEAK_F32_MFMA = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM = 8.0e12
+
+SCENES = {      # mapping.bound of the reference configs (configs/Replica/room0.yaml:3, office0.yaml:3, rpg/recording4.yaml:4)
+    'room0': [[-2.9, 8.9], [-3.2, 5.5], [-3.5, 3.3]],
+    'office0': [[-5.5, 5.9], [-6.7, 5.4], [-4.7, 5.3]],
+}
+CAM = dict(H=680, W=1200, fx=600.0, fy=600.0, cx=599.5, cy=339.5)       # configs/Replica/replica.yaml:37-43
+GRID_LEN = {'coarse': 2, 'middle': 0.32, 'fine': 0.16, 'color': 0.16, 'bound_divisible': 0.32}
+
+
+def cfg_dict():
+    return {'rendering': {'lindisp': False, 'perturb': 0.0, 'N_samples': 32, 'N_surface': 16, 'N_importance': 0},
+            'scale': 1, 'occupancy': True, 'coarse': True, 'data': {'dim': 3},
+            'model': {'c_dim': 32, 'coarse_bound_enlarge': 2, 'pos_embedding_method': 'fourier'},
+            'grid_len': dict(GRID_LEN)}
+
+
+def build_scene_cpu(scene='room0', seed=0):
+    """Seeded synthetic scene on the CPU, in the RNG order of BASELINE.md section 3 (decoders, then grids
+    coarse/middle/fine/color, then the depth and colour images)."""
+    import evennicer_slam_amd as E
+    torch.manual_seed(seed)
+    cfg = cfg_dict()
+    model = E.get_model(cfg)
+    bound = E.scene.scene_bound(SCENES[scene], 1.0, GRID_LEN['bound_divisible'])
+    grids = E.scene.grid_init(bound, GRID_LEN)
+    depth_img = torch.rand(CAM['H'], CAM['W']) * 3.0 + 0.5
+    depth_img[300:340, :] = 0.0                                   # 5.9 % pixels without depth
+    color_img = torch.rand(CAM['H'], CAM['W'], 3)
+    c2w = torch.eye(4)[:3].clone()
+    c2w[:, 3] = torch.tensor([3.0, 1.0, 0.0]) if scene == 'room0' else torch.tensor([0.0, 0.0, 0.0])
+    return dict(cfg=cfg, model=model, bound=bound, grids=grids, depth_img=depth_img, color_img=color_img, c2w=c2w)
+
+
+def attach_bounds(model, bound):
+    model.bound = bound
+    for name in ('middle_decoder', 'fine_decoder', 'color_decoder'):
+        getattr(model, name).bound = bound
+    model.coarse_decoder.bound = bound * 2
+
+
+def make_rays(sc, n_rays, seed):
+    from evennicer_slam_amd.common import get_samples
+    torch.manual_seed(seed)
+    ro, rd, gd, gc = get_samples(0, CAM['H'], 0, CAM['W'], n_rays, CAM['H'], CAM['W'], CAM['fx'], CAM['fy'],
+                                 CAM['cx'], CAM['cy'], sc['c2w'], sc['depth_img'], sc['color_img'], 'cpu')
+    return ro.float().contiguous(), rd.float().contiguous(), gd.float().contiguous(), gc.float().contiguous()
+
+
+def mapper_loss(depth, color, gt_depth, gt_color, stage, w_color=0.2):
+    m = gt_depth > 0
+    loss = torch.abs(gt_depth[m] - depth[m]).sum()
+    if stage == 'color':
+        loss = loss + w_color * torch.abs(gt_color - color).sum()
+    return loss
+
+
+def cpu_baseline(sc, rays, stage, budget_s=20.0):
+    """The CPU oracle (a port of the reference's PyTorch-CPU op sequence, pinned to reference goldens) timed on
+    this host on the same 1000-ray workload: fwd + loss + backward, bounded to ~budget_s of CPU work."""
+    from oracle import render_oracle as R
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sc['model'].state_dict().items()}
+    grids = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sc['grids'].items()}
+    ro, rd, gd, gc = [t.clone() for t in rays]
+    ro.requires_grad_(True)
+    rd.requires_grad_(True)
+
+    def step():
+        for t in list(params.values()) + list(grids.values()) + [ro, rd]:
+            t.grad = None
+        d, v, c = R.render_batch_ray(params, grids, rd, ro, stage, sc['bound'], gt_depth=gd)
+        mapper_loss(d, c, gd, gc, stage).backward()
+
+    t0 = time.perf_counter()
+    step()
+    first = time.perf_counter() - t0
+    iters = max(2, min(8, int(budget_s / max(first, 1e-3)) - 1))
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    n = ro.shape[0]
+    return {"value": n / med, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} rays x 48 samples, stage {stage}, fwd+loss+bwd, median of {iters} iterations after 1 warm-up "
+                      f"({med * 1e3:.0f} ms/iter), torch CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--rays', type=int, default=1000, help='rays per GPU per step')
+    ap.add_argument('--stage', default='color')
+    ap.add_argument('--scene', default='room0')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import evennicer_slam_amd as E
+    import evennicer_slam_amd.functional as EF
+    from evennicer_slam_amd import parallel as PAR
+
+    sc = build_scene_cpu(args.scene, seed=0)                      # identical replicas on every rank
+    rays_cpu = make_rays(sc, args.rays, seed=1000 + rank)         # each rank renders its own block of the batch
+    model = sc['model'].to(dev)
+    attach_bounds(model, sc['bound'])
+    grids = {k: v.to(dev).requires_grad_(True) for k, v in sc['grids'].items()}
+    ro, rd, gd, gc = [t.to(dev) for t in rays_cpu]
+    ro.requires_grad_(True)
+    rd.requires_grad_(True)
+    slam = types.SimpleNamespace(nice=True, bound=sc['bound'], **CAM)
+    renderer = E.Renderer(sc['cfg'], None, slam)
+    stage = args.stage
+    kinds = EF.stage_kinds(stage)
+    leaves = [grids[E._lib.GRID_NAMES[k]] for k in kinds]
+    for k in kinds:
+        leaves += list(getattr(model, E._lib.MLP_NAMES[k]).parameters())
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        ro.grad = None
+        rd.grad = None
+        if world > 1 and stage != 'coarse':
+            renderer.depth_max_override = PAR.global_depth_max(gd)
+        depth, var, color = renderer.render_batch_ray(grids, model, rd, ro, dev, stage, gt_depth=gd)
+        loss = mapper_loss(depth, color, gd, gc, stage)
+        loss.backward()
+        if world > 1:
+            PAR.allreduce_gradients(leaves)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_kernel_events:
+        EF.PROFILE['decoder_bwd'] = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    events = EF.PROFILE.pop('decoder_bwd', None)
+
+    S = 48 if stage != 'coarse' else 32
+    n_points = args.rays * S
+    out = {
+        "metric": "rendered rays/sec (fwd+bwd)", "value": world * args.rays * args.steps / elapsed, "unit": "rays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"Replica {args.scene} full 4-level grid, stage {stage}, {args.rays} rays x {S} samples "
+                               f"per GPU, render_batch_ray + mapper loss + backward (grads: grids, all decoder params, rays)",
+                   "rays_per_gpu": args.rays, "samples_per_ray": S,
+                   "parallelism": "1 GPU" if world == 1 else f"ray-sharded dp{world}, one bucketed RCCL all-reduce of leaf grads"},
+        "loss": float(loss.item()),
+    }
+    if events:
+        dur = np.array([a.elapsed_time(b) for a, b in events]) * 1e-3          # seconds
+        avg = float(dur.mean())
+        flops = n_points * 2 * FLOP_FWD_PER_POINT[stage]                        # dX + dW of every linear layer
+        step_flops = args.rays * S * 3 * FLOP_FWD_PER_POINT[stage]
+        out["roofline"] = {
+            "kernel": "decoder_bwd_kernel", "bound": "mfma", "achieved": flops / avg / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": flops / avg / PEAK_F32_MFMA, "traffic": None,
+            "avg_launch_us": avg * 1e6, "launches": int(len(dur)),
+            "step_frac": step_flops / PEAK_F32_MFMA / (elapsed / args.steps),
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sc, rays_cpu, stage)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

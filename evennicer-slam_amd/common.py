@@ -68,3 +68,13 @@ def normalize_3d_coordinate(p, bound):
     for a in range(3):
         out[:, a] = ((p[:, a] - bound[a, 0]) / (bound[a, 1] - bound[a, 0])) * 2 - 1.0
     return out
+
+
+def raw2outputs_nerf_color(raw, z_vals, rays_d, occupancy=False, device='cuda:0'):
+    """Alpha compositing of per-sample (r,g,b,occ) -> depth, depth variance, colour, weights
+    (reference: src/common.py:256-297).  Only the occupancy branch -- the one every shipped NICE config
+    selects (configs/nice_slam.yaml:5) -- is built; it runs as one HIP kernel (and one for its backward)."""
+    if not occupancy:
+        raise NotImplementedError("volume-density compositing (occupancy=False) is the iMAP mode, out of scope")
+    from . import functional as EF
+    return EF.composite(raw, z_vals)

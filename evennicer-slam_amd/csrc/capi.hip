@@ -140,13 +140,14 @@ int enslam_grid_from_voxel_major(const float* src, float* dst, int64_t n_voxels,
 
 int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const float* rays_o, const float* rays_d,
                        const float* gt_depth, const double* bound_host, const float* t_lin, const double* t_surf,
-                       int32_t lindisp, const float* t_rand, float* scratch, double* z_vals, void* stream) {
+                       int32_t lindisp, const float* t_rand, float* scratch, int32_t depth_max_given, double* z_vals,
+                       void* stream) {
     if (n_rays < 0 || n_lin < 1 || n_surf < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (!rays_o || !rays_d || !bound_host || !t_lin || !z_vals) return ENSLAM_EINVAL;
     if (gt_depth != nullptr && (scratch == nullptr || (n_surf > 0 && t_surf == nullptr))) return ENSLAM_EINVAL;
     return ens_launch_sample(n_rays, n_lin, n_surf, rays_o, rays_d, gt_depth, bound_host, t_lin, t_surf, lindisp,
-                             t_rand, scratch, z_vals, (hipStream_t)stream);
+                             t_rand, scratch, depth_max_given, z_vals, (hipStream_t)stream);
 }
 
 int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
@@ -173,17 +174,34 @@ int enslam_eval_points(int32_t stage, int64_t n_points, const double* points, co
                                  nullptr, nullptr, raw_out, (hipStream_t)stream);
 }
 
-int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
-                      const double* z_vals, const enslam_scene* scene, const float* raw, const double* depth,
-                      const double* g_depth, const double* g_var, const float* g_rgb, const enslam_grid* grad_grids,
-                      float* const* grad_packed, float* g_rays_o, float* g_rays_d, float* d_raw, void* stream) {
+int enslam_composite_fwd(int32_t n_rays, int32_t n_samples, const float* raw, const double* z_vals, double* depth,
+                         double* var, float* rgb, float* weights, void* stream) {
+    if (n_rays < 0 || n_samples < 1 || n_samples > 64) return ENSLAM_EINVAL;
+    if (n_rays == 0) return ENSLAM_OK;
+    if (!raw || !z_vals || !depth || !var || !rgb) return ENSLAM_EINVAL;
+    return ens_launch_composite_fwd(n_rays, n_samples, raw, z_vals, depth, var, rgb, weights, (hipStream_t)stream);
+}
+
+int enslam_composite_bwd(int32_t n_rays, int32_t n_samples, const float* raw, const double* z_vals,
+                         const double* depth, const double* g_depth, const double* g_var, const float* g_rgb,
+                         float* d_raw, void* stream) {
+    if (n_rays < 0 || n_samples < 1 || n_samples > 64) return ENSLAM_EINVAL;
+    if (n_rays == 0) return ENSLAM_OK;
+    if (!raw || !z_vals || !depth || !d_raw) return ENSLAM_EINVAL;
+    return ens_launch_composite_bwd(n_rays, n_samples, raw, z_vals, depth, g_depth, g_var, g_rgb, d_raw,
+                                    (hipStream_t)stream);
+}
+
+int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                       const double* z_vals, const enslam_scene* scene, const float* d_raw,
+                       const enslam_grid* grad_grids, float* const* grad_packed, float* g_rays_o, float* g_rays_d,
+                       void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
     DevScene d;
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
-    if (!rays_o || !rays_d || !z_vals || !raw || !depth || !d_raw || !grad_grids || !grad_packed) return ENSLAM_EINVAL;
-    if (!g_depth && !g_var && !g_rgb) return ENSLAM_EINVAL;
+    if (!rays_o || !rays_d || !z_vals || !d_raw || !grad_grids || !grad_packed) return ENSLAM_EINVAL;
     DevGrid gg[4];
     for (int k = 0; k < 4; ++k) {
         gg[k] = DevGrid{grad_grids[k].data, d.grid[k].D, d.grid[k].H, d.grid[k].W};
@@ -191,8 +209,19 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
             (grad_grids[k].D != d.grid[k].D || grad_grids[k].H != d.grid[k].H || grad_grids[k].W != d.grid[k].W))
             return ENSLAM_EINVAL;
     }
-    return ens_launch_render_bwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, raw, depth, g_depth, g_var,
-                                 g_rgb, gg, grad_packed, g_rays_o, g_rays_d, d_raw, (hipStream_t)stream);
+    return ens_launch_decoder_bwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, d_raw, gg, grad_packed,
+                                  g_rays_o, g_rays_d, (hipStream_t)stream);
+}
+
+int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                      const double* z_vals, const enslam_scene* scene, const float* raw, const double* depth,
+                      const double* g_depth, const double* g_var, const float* g_rgb, const enslam_grid* grad_grids,
+                      float* const* grad_packed, float* g_rays_o, float* g_rays_d, float* d_raw, void* stream) {
+    if (!g_depth && !g_var && !g_rgb) return ENSLAM_EINVAL;
+    const int rc = enslam_composite_bwd(n_rays, n_samples, raw, z_vals, depth, g_depth, g_var, g_rgb, d_raw, stream);
+    if (rc != ENSLAM_OK) return rc;
+    return enslam_decoder_bwd(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, d_raw, grad_grids, grad_packed,
+                              g_rays_o, g_rays_d, stream);
 }
 
 int enslam_voxel_index(int64_t n_points, const double* points, const double* bound_host, int32_t D, int32_t H,

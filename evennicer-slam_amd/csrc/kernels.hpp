@@ -22,7 +22,7 @@ int ens_launch_pack(const PackJob& job, float* packed, bool unpack, hipStream_t 
 int ens_launch_transpose(const float* src, float* dst, int64_t n_vox, bool to_voxel_major, hipStream_t st);
 int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
                       const double* bound, const float* t_lin, const double* t_surf, int lindisp,
-                      const float* t_rand, float* scratch, double* z, hipStream_t st);
+                      const float* t_rand, float* scratch, int dmax_given, double* z, hipStream_t st);
 int ens_launch_ray_points(int n_rays, int S, const float* ro, const float* rd, const double* z, const double* bound,
                           double* pts, uint8_t* mask, hipStream_t st);
 int ens_launch_voxel_index(int64_t n, const double* pts, const double* bound, int D, int H, int W, int* ix, int* iy,
@@ -30,7 +30,11 @@ int ens_launch_voxel_index(int64_t n, const double* pts, const double* bound, in
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
                           double* var, float* rgb, float* raw, hipStream_t st);
-int ens_launch_render_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
-                          const DevScene& sc, const float* raw, const double* depth, const double* g_depth,
-                          const double* g_var, const float* g_rgb, const DevGrid* grad_grids,
-                          float* const* grad_packed, float* g_ro, float* g_rd, float* d_raw, hipStream_t st);
+int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* z, double* depth, double* var,
+                             float* rgb, float* weights, hipStream_t st);
+int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* z, const double* depth,
+                             const double* g_depth, const double* g_var, const float* g_rgb, float* d_raw,
+                             hipStream_t st);
+int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
+                           const DevScene& sc, const float* d_raw, const DevGrid* grad_grids,
+                           float* const* grad_packed, float* g_ro, float* g_rd, hipStream_t st);

@@ -658,15 +658,18 @@ int device_cus() {
 
 }  // namespace
 
-int ens_launch_render_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
-                          const DevScene& sc, const float* raw, const double* depth, const double* g_depth,
-                          const double* g_var, const float* g_rgb, const DevGrid* grad_grids,
-                          float* const* grad_packed, float* g_ro, float* g_rd, float* d_raw, hipStream_t st) {
+int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* z, const double* depth,
+                             const double* g_depth, const double* g_var, const float* g_rgb, float* d_raw,
+                             hipStream_t st) {
     if (n_rays <= 0) return 0;
-    const int S = 16 * ntl;
     composite_bwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(S, raw, z, depth, g_depth, g_var, g_rgb, d_raw);
-    if (hipGetLastError() != hipSuccess) return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
+int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
+                           const DevScene& sc, const float* d_raw, const DevGrid* grad_grids,
+                           float* const* grad_packed, float* g_ro, float* g_rd, hipStream_t st) {
+    if (n_rays <= 0) return 0;
     BwdArgs A;
     A.n_rays = n_rays; A.ntl = ntl; A.ro = ro; A.rd = rd; A.z = z; A.d_raw = d_raw; A.sc = sc;
     A.g_ro = (g_ro && g_rd) ? g_ro : nullptr;

@@ -250,6 +250,41 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(int64_t n_units, const f
     }
 }
 
+// raw2outputs_nerf_color on its own (common.py:256-297, occupancy branch): one wave per ray.
+__global__ __launch_bounds__(64) void composite_fwd_kernel(int S, const float* __restrict__ raw,
+                                                           const double* __restrict__ z_vals,
+                                                           double* __restrict__ depth, double* __restrict__ var,
+                                                           float* __restrict__ rgb, float* __restrict__ weights) {
+    const int lane = threadIdx.x;
+    const int64_t ray = blockIdx.x, sidx = ray * S + lane;
+    const bool valid = lane < S;
+    const f32x4 rw = valid ? *reinterpret_cast<const f32x4*>(raw + sidx * 4) : splat4(0.f);
+    const double zk = valid ? z_vals[sidx] : 0.0;
+    const float alpha = valid ? 1.f / (1.f + expf(-(10.f * rw[3]))) : 0.f;
+    const float m = valid ? (1.f - alpha) + 1e-10f : 1.f;
+    float incl = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(incl, off);
+        incl = lane >= off ? incl * t : incl;
+    }
+    float T = __shfl_up(incl, 1);
+    T = lane == 0 ? 1.f : T;
+    const float w = alpha * T;
+    const float cr = wave_sum(w * rw[0]), cg = wave_sum(w * rw[1]), cb = wave_sum(w * rw[2]);
+    const double dep = wave_sum((double)w * zk);
+    const double tmp = zk - dep;
+    const double vr = wave_sum(((double)w * tmp) * tmp);
+    if (weights != nullptr && valid) weights[sidx] = w;
+    if (lane == 0) {
+        depth[ray] = dep;
+        var[ray] = vr;
+        rgb[ray * 3 + 0] = cr;
+        rgb[ray * 3 + 1] = cg;
+        rgb[ray * 3 + 2] = cb;
+    }
+}
+
 template <int STAGE>
 int launch_stage(int ntl, int64_t n_units, const float* ro, const float* rd, const double* z, const double* pts,
                  int64_t n_points, int apply_mask, const DevScene& sc, double* depth, double* var, float* rgb, float* raw,
@@ -266,6 +301,13 @@ int launch_stage(int ntl, int64_t n_units, const float* ro, const float* rd, con
 }
 
 }  // namespace
+
+int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* z, double* depth, double* var,
+                             float* rgb, float* weights, hipStream_t st) {
+    if (n_rays <= 0) return 0;
+    composite_fwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(S, raw, z, depth, var, rgb, weights);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,

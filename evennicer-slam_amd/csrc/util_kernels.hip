@@ -200,10 +200,10 @@ int ens_launch_transpose(const float* src, float* dst, int64_t V, bool to_vm, hi
 
 int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
                       const double* b, const float* t_lin, const double* t_surf, int lindisp, const float* t_rand,
-                      float* scratch, double* z, hipStream_t st) {
+                      float* scratch, int dmax_given, double* z, hipStream_t st) {
     if (n_rays <= 0) return 0;
     if (n_lin + n_surf > MAX_S || n_lin < 1) return -1;
-    if (gd != nullptr) depth_max_kernel<<<1, 1024, 0, st>>>(n_rays, gd, scratch);
+    if (gd != nullptr && !dmax_given) depth_max_kernel<<<1, 1024, 0, st>>>(n_rays, gd, scratch);
     sample_kernel<<<dim3((n_rays + 63) / 64), dim3(64), 0, st>>>(n_rays, n_lin, gd ? n_surf : 0, ro, rd, gd, b[0], b[1],
                                                                  b[2], b[3], b[4], b[5], t_lin, t_surf, lindisp,
                                                                  t_rand, scratch, z);

@@ -189,8 +189,10 @@ def stage_kinds(stage):
 class RenderPlan:
     """Static description of one render_batch_ray call (everything that is not a differentiable tensor)."""
 
-    def __init__(self, stage, bound, coarse_bound, n_lin, n_surf, lindisp, t_lin, t_surf, kinds, decoders):
+    def __init__(self, stage, bound, coarse_bound, n_lin, n_surf, lindisp, t_lin, t_surf, kinds, decoders,
+                 depth_max=None):
         self.stage = stage
+        self.depth_max = depth_max              # float32 [2] {max, fl32(max*1.2)} of the WHOLE batch, or None
         self.bound6 = bound6(bound)
         self.coarse_bound6 = bound6(coarse_bound)
         self.n_lin, self.n_surf, self.lindisp = n_lin, n_surf, int(bool(lindisp))
@@ -217,10 +219,11 @@ class _RenderFn(torch.autograd.Function):
         rd = rays_d.detach().contiguous().float()
         gd = gt_depth.detach().contiguous().float().reshape(-1) if gt_depth is not None else None
         z = torch.empty((N, S), dtype=torch.float64, device=dev)
-        scratch = torch.empty(2, dtype=torch.float32, device=dev)
+        scratch = plan.depth_max if plan.depth_max is not None else torch.empty(2, dtype=torch.float32, device=dev)
         L.check(lib.enslam_sample_rays(N, plan.n_lin, plan.n_surf, _ptr(ro), _ptr(rd), _ptr(gd), plan.bound6,
                                        _ptr(plan.t_lin), _ptr(plan.t_surf), plan.lindisp, _ptr(t_rand),
-                                       _ptr(scratch), _ptr(z), st), "enslam_sample_rays")
+                                       _ptr(scratch), int(plan.depth_max is not None), _ptr(z), st),
+                "enslam_sample_rays")
         grids_vm, dims, packed = {}, {}, {}
         for k, g in zip(plan.kinds, grids):
             grids_vm[k] = _grid_cache.get(g)
@@ -281,9 +284,17 @@ class _RenderFn(torch.autograd.Function):
         g_ro = torch.zeros((N, 3), dtype=torch.float32, device=dev) if need_rays else None
         g_rd = torch.zeros((N, 3), dtype=torch.float32, device=dev) if need_rays else None
         d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
-        L.check(lib.enslam_render_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                      _ptr(raw), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC), gg, gpk, _ptr(g_ro),
-                                      _ptr(g_rd), _ptr(d_raw), st), "enslam_render_bwd")
+        L.check(lib.enslam_composite_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
+                                         _ptr(d_raw), st), "enslam_composite_bwd")
+        ev = PROFILE.get('decoder_bwd')
+        if ev is not None:                      # bench.py: HIP events around the dominant kernel, on this stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        L.check(lib.enslam_decoder_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
+                                       _ptr(d_raw), gg, gpk, _ptr(g_ro), _ptr(g_rd), st), "enslam_decoder_bwd")
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         out = [None, g_ro if needs[1] else None, g_rd if needs[2] else None, None, None]
         for i, k in enumerate(plan.kinds):
             if need_grid[k]:
@@ -309,6 +320,9 @@ class _RenderFn(torch.autograd.Function):
             L.check(lib.enslam_unpack_mlp_grads(k, _ptr(g_packed[k]), ctypes.byref(ps), st), "unpack_mlp_grads")
             out += views
         return tuple(out)
+
+
+PROFILE = {}        # {'decoder_bwd': [(event_begin, event_end), ...]} when bench.py asks for per-kernel timing
 
 
 def render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params_flat):
@@ -369,7 +383,7 @@ def ray_points(rays_o, rays_d, z_vals, bound):
     return pts, mask.bool()
 
 
-def sample_rays(rays_o, rays_d, gt_depth, bound, n_lin, n_surf, lindisp=False, t_rand=None):
+def sample_rays(rays_o, rays_d, gt_depth, bound, n_lin, n_surf, lindisp=False, t_rand=None, depth_max=None):
     """z_vals float64 [N,S] (Renderer.py:83-171)."""
     lib = L.lib()
     _require_hip(rays_o, "rays")
@@ -380,8 +394,59 @@ def sample_rays(rays_o, rays_d, gt_depth, bound, n_lin, n_surf, lindisp=False, t
     z = torch.empty((N, S), dtype=torch.float64, device=dev)
     scratch = torch.empty(2, dtype=torch.float32, device=dev)
     gd = gt_depth.contiguous().float().reshape(-1) if gt_depth is not None else None
+    if depth_max is not None:
+        scratch = depth_max
     L.check(lib.enslam_sample_rays(N, n_lin, n_surf, _ptr(rays_o.contiguous().float()),
                                    _ptr(rays_d.contiguous().float()), _ptr(gd), bound6(bound), _ptr(t_lin),
-                                   _ptr(t_surf), int(bool(lindisp)), _ptr(t_rand), _ptr(scratch), _ptr(z), _stream()),
-            "enslam_sample_rays")
+                                   _ptr(t_surf), int(bool(lindisp)), _ptr(t_rand), _ptr(scratch),
+                                   int(depth_max is not None), _ptr(z), _stream()), "enslam_sample_rays")
     return z
+
+
+def batch_depth_max(gt_depth):
+    """{max(gt_depth), fl32(max*1.2)} float32 [2]: what a ray-sharded caller passes to every shard
+    (Renderer.py:110,145 take these maxima over the whole batch)."""
+    m = gt_depth.detach().float().max().reshape(1)
+    return torch.cat([m, m * 1.2]).contiguous()
+
+
+class _CompositeFn(torch.autograd.Function):
+    """raw2outputs_nerf_color with occupancy=True as one HIP kernel each way; gradient to `raw` only."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals):
+        lib = L.lib()
+        _require_hip(raw, "raw")
+        N, S = z_vals.shape
+        if S > 64:
+            raise L.EnslamError("composite kernels handle at most 64 samples per ray")
+        r = raw.detach().contiguous().float()
+        z = z_vals.detach().contiguous().double()
+        dev = raw.device
+        depth = torch.empty(N, dtype=torch.float64, device=dev)
+        var = torch.empty(N, dtype=torch.float64, device=dev)
+        rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        w = torch.empty((N, S), dtype=torch.float32, device=dev)
+        L.check(lib.enslam_composite_fwd(N, S, _ptr(r), _ptr(z), _ptr(depth), _ptr(var), _ptr(rgb), _ptr(w), _stream()),
+                "enslam_composite_fwd")
+        ctx.keep = (r, z, depth)
+        ctx.mark_non_differentiable(w)
+        return depth, var, rgb, w
+
+    @staticmethod
+    def backward(ctx, g_depth, g_var, g_rgb, _gw):
+        lib = L.lib()
+        r, z, depth = ctx.keep
+        N, S = z.shape
+        gD = g_depth.detach().double().contiguous() if g_depth is not None else None
+        gV = g_var.detach().double().contiguous() if g_var is not None else None
+        gC = g_rgb.detach().float().contiguous() if g_rgb is not None else None
+        d_raw = torch.empty((N, S, 4), dtype=torch.float32, device=r.device)
+        L.check(lib.enslam_composite_bwd(N, S, _ptr(r), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
+                                         _ptr(d_raw), _stream()), "enslam_composite_bwd")
+        return d_raw, None
+
+
+def composite(raw, z_vals):
+    """(depth f64 [N], var f64 [N], rgb f32 [N,3], weights f32 [N,S]) from raw [N,S,4], z_vals [N,S]."""
+    return _CompositeFn.apply(raw, z_vals)

@@ -25,6 +25,8 @@ class Renderer(object):
             raise NotImplementedError("the HIP path implements the NICE / occupancy configuration "
                                       "(configs/nice_slam.yaml: occupancy True); iMAP mode is out of scope")
         self._tvals = {}
+        # ray-sharded callers (parallel.ShardedRenderer) set this to functional.batch_depth_max(whole batch)
+        self.depth_max_override = None
 
     # ------------------------------------------------------------------ helpers
     def _t_vals(self, device, n_lin, n_surf):
@@ -75,7 +77,7 @@ class Renderer(object):
         kinds = EF.stage_kinds(stage)
         decs = {k: getattr(decoders, L.MLP_NAMES[k]) for k in kinds}
         plan = EF.RenderPlan(stage, self.bound, self._coarse_bound(decoders), n_lin, n_surf, self.lindisp, t_lin,
-                             t_surf, kinds, decs)
+                             t_surf, kinds, decs, depth_max=self.depth_max_override if gt_depth is not None else None)
         grids = [c[L.GRID_NAMES[k]] for k in kinds]
         params = []
         for k in kinds:

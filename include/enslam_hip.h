@@ -107,12 +107,16 @@ int enslam_grid_from_voxel_major(const float *src, float *dst, int64_t n_voxels,
  *   t_lin   float32 [n_lin]  = torch.linspace(0,1,n_lin)
  *   t_surf  float64 [n_surf] = torch.linspace(0,1,n_surf).double()   (ignored if n_surf == 0)
  *   t_rand  float32 [N,n_lin] or NULL (perturb == 0)
- *   scratch float32 [2]: receives max(gt_depth) (batch-global, Renderer.py:110,145)
+ *   scratch float32 [2]: {max(gt_depth), fl32(max(gt_depth)*1.2f)} (batch-global, Renderer.py:110,145).
+ *           depth_max_given == 0: computed here over this call's gt_depth and written to scratch;
+ *           depth_max_given != 0: read from scratch (a ray-sharded caller supplies the max of the WHOLE batch,
+ *           so that every shard samples exactly what the unsharded reference would).
  *   z_vals  float64 [N, n_lin + n_surf] (n_surf forced to 0 when gt_depth is NULL)
  * Bit-exact with the reference's float64/float32 evaluation order. */
 int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const float *rays_o, const float *rays_d,
                        const float *gt_depth, const double *bound_host, const float *t_lin, const double *t_surf,
-                       int32_t lindisp, const float *t_rand, float *scratch, double *z_vals, void *stream);
+                       int32_t lindisp, const float *t_rand, float *scratch, int32_t depth_max_given, double *z_vals,
+                       void *stream);
 
 /* Forward of Renderer.render_batch_ray lines 173-181 + eval_points (Renderer.py:24-62) +
  * NICE.forward (decoder.py:312-342) + raw2outputs_nerf_color (common.py:256-297, occupancy):
@@ -141,6 +145,22 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
                       const double *g_depth, const double *g_var, const float *g_rgb,
                       const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o, float *g_rays_d,
                       float *d_raw, void *stream);
+
+/* The two halves of enslam_render_bwd, callable on their own.
+ * enslam_composite_bwd: backward of raw2outputs_nerf_color (common.py:284-296): d(depth,var,rgb) -> d_raw [N*S,4].
+ * enslam_decoder_bwd  : everything upstream of raw (decoders, gather, points), consuming d_raw. */
+int enslam_composite_bwd(int32_t n_rays, int32_t n_samples, const float *raw, const double *z_vals,
+                         const double *depth, const double *g_depth, const double *g_var, const float *g_rgb,
+                         float *d_raw, void *stream);
+int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                       const double *z_vals, const enslam_scene *scene, const float *d_raw,
+                       const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o, float *g_rays_d,
+                       void *stream);
+
+/* raw2outputs_nerf_color (common.py:256-297, occupancy=True) on its own: raw float32 [N,S,4], z_vals float64 [N,S]
+ * -> depth/var float64 [N], rgb float32 [N,3], weights float32 [N,S] (may be NULL).  1 <= S <= 64. */
+int enslam_composite_fwd(int32_t n_rays, int32_t n_samples, const float *raw, const double *z_vals, double *depth,
+                         double *var, float *rgb, float *weights, void *stream);
 
 /* Parity helper: base voxel index and fractions the gather uses for points p float64 [P,3]
  * (normalize_3d_coordinate, common.py:342-357, then ATen grid_sampler unnormalize/clip/floor). */

@@ -1,0 +1,119 @@
+"""GPU parity at BASELINE configs[1] size: Replica room0 full 4-level grid, stage colour, 1000 rays x 48 samples,
+against the reference-generated golden (grids are regenerated from the seed; outputs, ray/decoder gradients and
+sampled grid-gradient entries are compared), plus size-independent properties of the path."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def room0():
+    import types
+    import bench
+    import evennicer_slam_amd as E
+    sc = bench.build_scene_cpu('room0', seed=0)
+    g = load("room0_color1000")
+    assert np.allclose([float(sc['grids'][k].double().sum()) for k in sc['grids']], g["grid_checksum"], rtol=0, atol=1e-9)
+    model = sc['model'].cuda()
+    bench.attach_bounds(model, sc['bound'])
+    grids = {k: v.cuda() for k, v in sc['grids'].items()}
+    renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **bench.CAM))
+    rays = {k: torch.from_numpy(g[k]).cuda() for k in ('rays_o', 'rays_d', 'gt_depth', 'gt_color')}
+    return sc, g, model, grids, renderer, rays
+
+
+def _step(room0, scale=1.0):
+    import bench
+    sc, g, model, grids, renderer, rays = room0
+    for p in model.parameters():
+        p.grad = None
+    cg = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+    ro = rays['rays_o'].clone().requires_grad_(True)
+    rd = rays['rays_d'].clone().requires_grad_(True)
+    depth, var, color = renderer.render_batch_ray(cg, model, rd, ro, 'cuda:0', 'color', gt_depth=rays['gt_depth'])
+    loss = bench.mapper_loss(depth, color, rays['gt_depth'], rays['gt_color'], 'color') * scale
+    loss.backward()
+    return cg, ro, rd, depth, var, color, loss
+
+
+def test_headline_forward_and_gradients(room0):
+    import evennicer_slam_amd.functional as EF
+    sc, g, model, grids, renderer, rays = room0
+    z = EF.sample_rays(rays['rays_o'], rays['rays_d'], rays['gt_depth'], sc['bound'], 32, 16)
+    assert np.array_equal(z.cpu().numpy(), g["z_vals"])                       # bit-exact, 48 000 samples
+    cg, ro, rd, depth, var, color, loss = _step(room0)
+    for name, got in (("depth", depth), ("var", var), ("color", color)):
+        a, b = got.detach().cpu().numpy().astype(np.float64), g[name].astype(np.float64)
+        assert np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-5 * np.abs(b).max()), name
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert rel_err(ro.grad.cpu().numpy(), g["g_rays_o"]) < 1e-3
+    assert rel_err(rd.grad.cpu().numpy(), g["g_rays_d"]) < 1e-3
+    n = 0
+    for name, p in model.named_parameters():
+        if "gp_" + name in g and np.abs(g["gp_" + name]).max() > 0:
+            assert rel_err(p.grad.cpu().numpy(), g["gp_" + name]) < 1e-3, name
+            n += 1
+    assert n >= 60
+    for key in ('grid_middle', 'grid_fine', 'grid_color'):
+        gg = cg[key].grad.reshape(-1)
+        ref_sum, ref_abs, ref_nnz, ref_size = g[f"gstat_{key}"]
+        assert gg.numel() == int(ref_size)
+        assert abs(float(gg.double().abs().sum()) - ref_abs) < 1e-3 * ref_abs
+        nnz = int((gg != 0).sum())
+        assert abs(nnz - ref_nnz) <= 0.001 * ref_nnz + 8, (key, nnz, ref_nnz)
+        idx = torch.from_numpy(g[f"gidx_{key}"]).cuda()
+        got = gg[idx].cpu().numpy()
+        assert rel_err(got, g[f"gval_{key}"]) < 1e-3, key
+
+
+def test_backward_is_linear_in_the_loss(room0):
+    a = _step(room0, 1.0)
+    b = _step(room0, 2.0)
+    assert torch.allclose(b[1].grad, 2 * a[1].grad, rtol=1e-4, atol=1e-6 * float(a[1].grad.abs().max()))
+    ga, gb = a[0]['grid_fine'].grad, b[0]['grid_fine'].grad
+    assert torch.allclose(gb, 2 * ga, rtol=1e-3, atol=1e-5 * float(ga.abs().max()))
+
+
+def test_composite_properties_full_size(room0):
+    """raw2outputs entry on 1000 x 48: weights in [0,1], sum <= 1, depth inside [z_min, z_max] scaled by sum w."""
+    from evennicer_slam_amd.common import raw2outputs_nerf_color
+    import evennicer_slam_amd.functional as EF
+    sc, g, model, grids, renderer, rays = room0
+    z = EF.sample_rays(rays['rays_o'], rays['rays_d'], rays['gt_depth'], sc['bound'], 32, 16)
+    assert bool((z[:, 1:] >= z[:, :-1]).all())                                 # sorted
+    raw = torch.randn(1000, 48, 4, device='cuda', requires_grad=True)
+    depth, var, rgb, w = raw2outputs_nerf_color(raw, z, rays['rays_d'], occupancy=True, device='cuda:0')
+    assert float(w.min()) >= 0 and float(w.sum(-1).max()) <= 1 + 1e-5
+    assert bool((depth <= z[:, -1] * w.sum(-1) + 1e-9).all()) and bool((var >= 0).all())
+    # against the torch formula
+    alpha = torch.sigmoid(10 * raw[..., 3])
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)[:, :-1]
+    assert torch.allclose(w, (alpha * T).detach(), rtol=1e-4, atol=1e-7)
+    (depth.sum() + rgb.sum()).backward()
+    ref = torch.autograd.grad(((alpha * T) * z).sum() + ((alpha * T)[..., None] * raw[..., :3]).sum(), raw)[0]
+    assert rel_err(raw.grad.cpu().numpy(), ref.cpu().numpy()) < 1e-4
+
+
+def test_render_img_rescale_and_render_img_shapes(room0):
+    sc, g, model, grids, renderer, rays = room0
+    c2w = sc['c2w'].cuda()
+    gt = sc['depth_img'].cuda()
+    d, u, c = renderer.render_img_rescale(grids, model, c2w, 'cuda:0', 'color', gt_depth=gt, scale_factor=0.15)
+    assert tuple(d.shape) == (102, 180) and tuple(c.shape) == (102, 180, 3) and d.dtype == torch.float64
+    c2w_g = c2w.clone().requires_grad_(True)
+    d, u, c = renderer.render_img_rescale(grids, model, c2w_g, 'cuda:0', 'color', gt_depth=gt, scale_factor=0.05)
+    c.sum().backward()                         # pose gradient through rays_o / rays_d (Tracker.py:150)
+    assert c2w_g.grad is not None and float(c2w_g.grad.abs().max()) > 0
+    old = renderer.ray_batch_size
+    renderer.ray_batch_size = 50000
+    try:
+        renderer.H, renderer.W = 120, 160      # smaller image: 19 200 rays, still chunked + concatenated
+        d, u, c = renderer.render_img(grids, model, c2w, 'cuda:0', 'color', gt_depth=gt[:120, :160])
+        assert tuple(d.shape) == (120, 160) and tuple(c.shape) == (120, 160, 3)
+    finally:
+        renderer.ray_batch_size = old
+        renderer.H, renderer.W = 680, 1200
