@@ -4,7 +4,7 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_double, c_int32, c_int64, c_size_t, c_void_p
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libenslam_hip.so")
+LIB_PATH = os.environ.get("ENSLAM_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libenslam_hip.so")
 
 STAGE = {'coarse': 0, 'middle': 1, 'fine': 2, 'color': 3}
 MLP_COARSE, MLP_MIDDLE, MLP_FINE, MLP_COLOR = 0, 1, 2, 3

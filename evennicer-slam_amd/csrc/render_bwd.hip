@@ -93,34 +93,58 @@ ENS_DEV void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-ENS_DEV void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// sacc[(16rt+4q+r)*ld + col0 + 16ct + p] += sum_samples Y[sample][16rt+i] * X[sample][16ct+j]
-// rows >= rows_valid / cols >= cols_valid are padding and skipped.
-template <int NR, int NC>
-ENS_DEV void outer_acc(float* sacc, int ld, int col0, const float* depY, int y0, const float* depX, int x0,
-                       int rows_valid, int cols_valid, int lane, int p, int q) {
-    f32x4 a[NR], b[NC];
+// ---- owner-computes weight gradients ----------------------------------------------------------
+// The 4 waves of a workgroup work in lockstep on 4 sample tiles.  Each wave deposits its tile's operands
+// in its own LDS slot; after a barrier every wave accumulates the dW output tiles IT OWNS (tile index
+// t = wave + 4*j of the matrix' row-major tile grid) over all 4 slots, i.e. over 64 samples, directly into
+// persistent MFMA accumulators.  No LDS atomics; one staged flush at the end of the kernel.
+//   acc[j] += sum_{slot, sample} Y[slot][sample][16*rt + i] * X[slot][sample][16*ct + j']
+template <int NJ>
+ENS_DEV void own_outer(f32x4 (&acc)[NJ], const float* slots, int slot_stride, int ytile0, int xtile0, int nc,
+                       int ntiles, int wave, int lane) {
 #pragma unroll
-    for (int rt = 0; rt < NR; ++rt) a[rt] = frag(depY, y0 + rt, lane);
+    for (int sl = 0; sl < 4; ++sl) {
+        const float* base = slots + sl * slot_stride;
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct) b[ct] = frag(depX, x0 + ct, lane);
+        for (int j = 0; j < NJ; ++j) {
+            const int t = wave + 4 * j;
+            if (t < ntiles) {                                   // wave-uniform
+                const int rt = t / nc, ct = t - rt * nc;
+                const f32x4 a = frag(base, ytile0 + rt, lane), b = frag(base, xtile0 + ct, lane);
 #pragma unroll
-    for (int rt = 0; rt < NR; ++rt) {
-#pragma unroll
-        for (int ct = 0; ct < NC; ++ct) {
-            f32x4 acc = splat4(0.f);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = MFMA16(a[rt][s], b[ct][s], acc);
-            const int col = 16 * ct + p;
-            if (col < cols_valid) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * rt + 4 * q + r;
-                    if (row < rows_valid) lds_add(sacc + row * ld + col0 + col, acc[r]);
-                }
+                for (int s = 0; s < 4; ++s) acc[j] = MFMA16(a[s], b[s], acc[j]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);          // keep the scheduler from hoisting all slots' fragment reads
+    }
+}
+// bias gradient: acc += sum_{slot, sample} Y[slot][sample][16*rt + i]   (every column of the tile identical)
+ENS_DEV void own_bias(f32x4& acc, const float* slots, int slot_stride, int ytile, int lane) {
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        const f32x4 a = frag(slots + sl * slot_stride, ytile, lane);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = MFMA16(a[s], 1.f, acc);
+    }
+}
+// stage an owned tile into the packed-layout LDS image (plain stores: every element has one owner)
+ENS_DEV void stage_tile(float* sacc, int ld, int col0, int nc, int t, const f32x4& acc, int rows_valid, int cols_valid,
+                        int p, int q) {
+    const int rt = t / nc, ct = t - rt * nc;
+    const int col = 16 * ct + p;
+    if (col < cols_valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + 4 * q + r;
+            if (row < rows_valid) sacc[row * ld + col0 + col] = acc[r];
+        }
+    }
+}
+ENS_DEV void stage_bias(float* sbias, int rt, const f32x4& acc, int n_valid, int p, int q) {
+    if (p == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (16 * rt + 4 * q + r < n_valid) sbias[16 * rt + 4 * q + r] = acc[r];
     }
 }
 
@@ -158,8 +182,8 @@ struct TileGeo {
 
 ENS_DEV TileGeo tile_geo(int64_t tile, int ntl, int S, const float* ro, const float* rd, const double* z, int p) {
     TileGeo g;
-    g.ray = (int)(tile / ntl);
-    const int tl = (int)(tile - (int64_t)g.ray * ntl);
+    g.ray = __builtin_amdgcn_readfirstlane((int)(tile / ntl));            // tile is wave-uniform
+    const int tl = __builtin_amdgcn_readfirstlane((int)(tile - (int64_t)g.ray * ntl));
     g.sidx = (int64_t)g.ray * S + 16 * tl + p;
     const double zz = z[g.sidx];
     g.zf = (float)zz;
@@ -251,44 +275,61 @@ struct BwdArgs {
 // ------------------------------------------------------------------------------------------------
 // MLP (middle / fine / color) backward for one workgroup role
 // ------------------------------------------------------------------------------------------------
+template <int CT>
+struct XyzSlots {                      // tile offsets inside one wave's LDS slot (1 tile = 256 floats)
+    static constexpr int EMB = 0;      // 6: embedding (later d_arg); followed by h2 so that W3's input [emb|h2] is contiguous
+    static constexpr int HX2 = 6, HX0 = 8, HX1 = 10, HX3 = 12, HX4 = 14;   // 2 each: hidden activations h_i (dW operands)
+    static constexpr int C = 16;       // CT: grid features
+    static constexpr int H0 = 16 + CT, H1 = 18 + CT;     // dh_i, double buffered by layer parity
+    static constexpr int P0 = 20 + CT, P1 = 22 + CT;     // dpre_i
+    static constexpr int Q = 24 + CT;                    // d_out / sample coordinates
+    static constexpr int STASH = 25 + CT;                // 6: wave-private stash of the partial d_emb (lane-linear)
+    static constexpr int TILES = 31 + CT;
+};
+
 template <int CT, int NOUT>
 ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem) {
     constexpr XyzLay L{CT * 16};
     constexpr int GF = L.fwd_floats();
-    constexpr int WSCR = (6 + CT + 2 + 2 + 2 + 1) * 256;           // emb, c, x, dh, dpre, coords tiles (floats)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+    using SL = XyzSlots<CT>;
+    constexpr int SLOT = SL::TILES * 256;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
     const float* __restrict__ pk = A.sc.packed[kind];
     const DevGrid grid = A.sc.grid[kind];
     const DevGrid ggrid = A.ggrid[kind];
     float* gpk = A.gpacked[kind];
     const bool want_w = gpk != nullptr, want_g = ggrid.data != nullptr, want_r = A.g_ro != nullptr;
     const bool want_c = want_g || want_r;
+    float* my = smem + wave * SLOT;                                 // this wave's deposit slot
 
-    float* sacc = smem;                                              // [GF] workgroup-wide dW accumulator
-    float* scr = smem + GF + wave * WSCR;
-    float* dEmb = scr;                       // 6 tiles: embedding (later d_arg)
-    float* dC = dEmb + 6 * 256;              // CT tiles: grid features
-    float* dX = dC + CT * 256;               // 2 tiles: layer input h_{i-1}
-    float* dH = dX + 2 * 256;                // 2 tiles: dh_i (also the [sample][32] scatter staging)
-    float* dP = dH + 2 * 256;                // 2 tiles: dpre_i
-    float* dQ = dP + 2 * 256;                // 1 tile : coordinates / d_out
-    for (int e = threadIdx.x; e < GF; e += 256) sacc[e] = 0.f;
-    __syncthreads();
-
-    f32x4 gb[5][2], gbc[5][2];               // bias gradients, per-lane partial sums over this wave's tiles
+    // owned weight-gradient accumulators (tile t = wave + 4*j of each matrix), persistent over all rounds
+    f32x4 aWc[5][CT / 2], aW[5][4], aB[5], aBT[2], aWo[1], aBo;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { gb[i][0] = gb[i][1] = gbc[i][0] = gbc[i][1] = splat4(0.f); }
-    f32x4 gbo = splat4(0.f);
+    for (int i = 0; i < 5; ++i) {
+        aB[i] = splat4(0.f);
+#pragma unroll
+        for (int j = 0; j < CT / 2; ++j) aWc[i][j] = splat4(0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aW[i][j] = splat4(0.f);
+    }
+    aBT[0] = aBT[1] = aWo[0] = aBo = splat4(0.f);
 
     const int64_t n_tiles = (int64_t)A.n_rays * A.ntl;
     const int S = 16 * A.ntl;
-    for (int64_t tile = (int64_t)wg * 4 + wave; tile < n_tiles; tile += (int64_t)n_wg * 4) {
+    const int64_t stride = (int64_t)n_wg * 4;
+    for (int64_t base = (int64_t)wg * 4; base < n_tiles; base += stride) {
+        const int64_t tile_raw = base + wave;
+        const bool tvalid = tile_raw < n_tiles;
+        const int tile = __builtin_amdgcn_readfirstlane((int)(tvalid ? tile_raw : n_tiles - 1));
         const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
-        const f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4);
+        f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4);
+        if (!tvalid) draw = splat4(0.f);
         // output gradient of this decoder as a D-layout tile (rows 0..NOUT-1 live on q == 0 lanes)
         f32x4 dout = splat4(0.f);
         if (q == 0) dout = NOUT == 4 ? f32x4{draw[0], draw[1], draw[2], 0.f} : f32x4{draw[3], 0.f, 0.f, 0.f};
-        if (!__any(dout[0] != 0.f || dout[1] != 0.f || dout[2] != 0.f)) continue;   // nothing flows into this tile
+        const int active = __any(dout[0] != 0.f || dout[1] != 0.f || dout[2] != 0.f) ? 1 : 0;
+        // nothing flows into the tile(s): skip.  With weight gradients the 4 waves stay in lockstep (barriers).
+        if (want_w ? !__syncthreads_or(active) : !active) continue;
 
         // ---- recompute the forward chain
         const float pc = q == 0 ? (float)G.pw[0] : (q == 1 ? (float)G.pw[1] : (q == 2 ? (float)G.pw[2] : 0.f));
@@ -299,18 +340,13 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
             const Vox vm = make_vox(G.pw, A.sc.lo, A.sc.hi, A.sc.grid[1]);
             gather8(vm, A.sc.grid[1], q, c[0][2], c[0][3]);
         }
-        f32x4 emb[1][6], cosv[6];
+        f32x4 emb[1][6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             const float a = pk[L.oBT() + (16 * t + p) * 4 + q];
             const f32x4 arg = MFMA16(a, pc, splat4(0.f));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float sv, cv;
-                ens_sincosf(arg[r], sv, cv);
-                emb[0][t][r] = sv;
-                cosv[t][r] = cv;
-            }
+            for (int r = 0; r < 4; ++r) emb[0][t][r] = ens_sinf(arg[r]);
         }
         f32x4 h[5][1][2];
         unsigned mbits[5];
@@ -333,22 +369,26 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
             linear32<CT, 1, CT>(acc, pk + L.oWc(i), CT * 16, c, 0, p, q);
             h[i][0][0] = acc[0][0];
             h[i][0][1] = acc[0][1];
+            __builtin_amdgcn_sched_barrier(0);
         };
         fwd_layer(IC(0)); fwd_layer(IC(1)); fwd_layer(IC(2)); fwd_layer(IC(3)); fwd_layer(IC(4));
 
         // ---- backward chain
         if (want_w) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) deposit(dEmb, t, emb[0][t], p, q);
+            for (int t = 0; t < 6; ++t) deposit(my, SL::EMB + t, emb[0][t], p, q);
 #pragma unroll
-            for (int t = 0; t < CT; ++t) deposit(dC, t, c[0][t], p, q);
-            deposit(dQ, 0, dout, p, q);
-            deposit(dX, 0, h[4][0][0], p, q);
-            deposit(dX, 1, h[4][0][1], p, q);
-            wave_lds_fence();
-            outer_acc<1, 2>(sacc + L.oWo(), 32, 0, dQ, 0, dX, 0, NOUT, 32, lane, p, q);       // dWo
-            gbo += dout;
-            wave_lds_fence();
+            for (int t = 0; t < CT; ++t) deposit(my, SL::C + t, c[0][t], p, q);
+            deposit(my, SL::Q, dout, p, q);
+            // hidden activations are only needed as dW operands: park them in LDS now, free the registers
+            deposit(my, SL::HX0, h[0][0][0], p, q); deposit(my, SL::HX0 + 1, h[0][0][1], p, q);
+            deposit(my, SL::HX1, h[1][0][0], p, q); deposit(my, SL::HX1 + 1, h[1][0][1], p, q);
+            deposit(my, SL::HX2, h[2][0][0], p, q); deposit(my, SL::HX2 + 1, h[2][0][1], p, q);
+            deposit(my, SL::HX3, h[3][0][0], p, q); deposit(my, SL::HX3 + 1, h[3][0][1], p, q);
+            deposit(my, SL::HX4, h[4][0][0], p, q); deposit(my, SL::HX4 + 1, h[4][0][1], p, q);
+            __syncthreads();
+            own_outer<1>(aWo, smem, SLOT, SL::Q, SL::HX4, 2, 2, wave, lane);           // dWo: waves 0,1
+            if (wave == 2) own_bias(aBo, smem, SLOT, SL::Q, lane);                       // dbo
         }
         f32x4 dh[2] = {splat4(0.f), splat4(0.f)};
         {   // dh4 = Wo^T d_out (K = 4: one step per row tile; k-slot q carries output q)
@@ -363,53 +403,71 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
         for (int t = 0; t < 6; ++t) demb[t] = splat4(0.f);
         auto bwd_layer = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
+            constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
+            constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);      // input h_{i-1} of layers 4, 2, 1
             f32x4 dpre[2] = {mask4(dh[0], mbits[i], 0), mask4(dh[1], mbits[i], 4)};
             if (want_w) {
-                gbc[i][0] += dh[0]; gbc[i][1] += dh[1];
-                gb[i][0] += dpre[0]; gb[i][1] += dpre[1];
-                deposit(dH, 0, dh[0], p, q); deposit(dH, 1, dh[1], p, q);
-                deposit(dP, 0, dpre[0], p, q); deposit(dP, 1, dpre[1], p, q);
-                if constexpr (i == 1 || i == 2 || i == 4) { deposit(dX, 0, h[i - 1][0][0], p, q); deposit(dX, 1, h[i - 1][0][1], p, q); }
-                if constexpr (i == 3) { deposit(dX, 0, h[2][0][0], p, q); deposit(dX, 1, h[2][0][1], p, q); }
-                wave_lds_fence();
-                outer_acc<2, CT>(sacc + L.oWc(i), CT * 16, 0, dH, 0, dC, 0, 32, CT * 16, lane, p, q);     // dWc_i
+                deposit(my, TH, dh[0], p, q); deposit(my, TH + 1, dh[1], p, q);
+                deposit(my, TP, dpre[0], p, q); deposit(my, TP + 1, dpre[1], p, q);
+                __syncthreads();
+                own_outer<CT / 2>(aWc[i], smem, SLOT, TH, SL::C, CT, 2 * CT, wave, lane);          // dWc_i
                 if constexpr (i == 0) {
-                    outer_acc<2, 6>(sacc + L.oW(0), 96, 0, dP, 0, dEmb, 0, 32, 96, lane, p, q);
+                    own_outer<3>(reinterpret_cast<f32x4(&)[3]>(aW[0]), smem, SLOT, TP, SL::EMB, 6, 12, wave, lane);
                 } else if constexpr (i == 3) {
-                    outer_acc<2, 6>(sacc + L.oW(3), 128, 0, dP, 0, dEmb, 0, 32, 96, lane, p, q);
-                    outer_acc<2, 2>(sacc + L.oW(3), 128, 96, dP, 0, dX, 0, 32, 32, lane, p, q);
+                    own_outer<4>(aW[3], smem, SLOT, TP, SL::EMB, 8, 16, wave, lane);             // [emb | h2] contiguous
                 } else {
-                    outer_acc<2, 2>(sacc + L.oW(i), 32, 0, dP, 0, dX, 0, 32, 32, lane, p, q);
+                    own_outer<1>(reinterpret_cast<f32x4(&)[1]>(aW[i]), smem, SLOT, TP, TX, 2, 4, wave, lane);
                 }
-                wave_lds_fence();
+                own_bias(aB[i], smem, SLOT, (wave < 2 ? TP : TH) + (wave & 1), lane);            // db_i | dbc_i
             }
+            __builtin_amdgcn_sched_barrier(0);
             if (want_c) linear_n<2, 2>(dc, pk + L.oWcT(i), 32, dh, p, q);                 // dC += Wc_i^T dh_i
             if constexpr (i == 0) {
-                if (want_r || want_w) linear_n<6, 2>(demb, pk + L.oWT(0), 32, dpre, p, q);
+                if (want_r || want_w) {
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) demb[t] = *reinterpret_cast<const f32x4*>(my + SL::STASH * 256 + t * 256 + lane * 4);
+                    linear_n<6, 2>(demb, pk + L.oWT(0), 32, dpre, p, q);
+                }
             } else if constexpr (i == 3) {
-                if (want_r || want_w) linear_n<6, 2>(demb, pk + L.oWT(3), 32, dpre, p, q);
+                if (want_r || want_w) {
+                    f32x4 de[6];
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) de[t] = splat4(0.f);
+                    linear_n<6, 2>(de, pk + L.oWT(3), 32, dpre, p, q);
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) *reinterpret_cast<f32x4*>(my + SL::STASH * 256 + t * 256 + lane * 4) = de[t];
+                }
                 dh[0] = dh[1] = splat4(0.f);
                 linear_n<2, 2>(dh, pk + L.oWT(3) + 96 * 32, 32, dpre, p, q);
             } else {
                 dh[0] = dh[1] = splat4(0.f);
                 linear_n<2, 2>(dh, pk + L.oWT(i), 32, dpre, p, q);
             }
+            __builtin_amdgcn_sched_barrier(0);
         };
         bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
         // ---- embedding: d_arg = d_emb * cos(arg);  dB^T += d_arg (x) p ;  dp += B d_arg
         float dpx = 0.f, dpy = 0.f, dpz = 0.f;
         if (want_r || want_w) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) demb[t] *= cosv[t];
-            if (want_w) {
+            for (int t = 0; t < 6; ++t) {                               // cos(arg) recomputed: cheaper than carrying it
+                const f32x4 arg = MFMA16(pk[L.oBT() + (16 * t + p) * 4 + q], pc, splat4(0.f));
 #pragma unroll
-                for (int t = 0; t < 6; ++t) deposit(dEmb, t, demb[t], p, q);
+                for (int r = 0; r < 4; ++r) {
+                    float sv, cv;
+                    ens_sincosf(arg[r], sv, cv);
+                    demb[t][r] *= cv;
+                }
+            }
+            if (want_w) {
+                __syncthreads();                                     // every wave is done reading EMB / Q
+#pragma unroll
+                for (int t = 0; t < 6; ++t) deposit(my, SL::EMB + t, demb[t], p, q);
                 f32x4 pt4 = splat4(0.f);
                 if (q == 0) pt4 = f32x4{(float)G.pw[0], (float)G.pw[1], (float)G.pw[2], 0.f};
-                deposit(dQ, 0, pt4, p, q);
-                wave_lds_fence();
-                outer_acc<6, 1>(sacc + L.oBT(), 4, 0, dEmb, 0, dQ, 0, 93, 3, lane, p, q);
-                wave_lds_fence();
+                deposit(my, SL::Q, pt4, p, q);
+                __syncthreads();
+                own_outer<2>(aBT, smem, SLOT, SL::EMB, SL::Q, 1, 6, wave, lane);                  // dB^T
             }
             if (want_r) {
                 f32x4 dpe[1] = {splat4(0.f)};
@@ -427,46 +485,49 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
                 gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
                 dpx += gx * v.gx; dpy += gy * v.gy; dpz += gz * v.gz;
             }
-            if (want_g) {
-                // stage dC as [sample][32 channels]
-                *reinterpret_cast<f32x4*>(dH + p * 32 + 4 * q) = dc[0];
-                *reinterpret_cast<f32x4*>(dH + p * 32 + 16 + 4 * q) = dc[1];
+            if (want_g && tvalid) {
+                // stage dC as [sample][32 channels] in this wave's H0 tiles: all reads of H0/H1 by other waves
+                // are behind a barrier already (want_w) or never happen (!want_w)
+                float* stg = my + SL::H0 * 256;
+                *reinterpret_cast<f32x4*>(stg + p * 32 + 4 * q) = dc[0];
+                *reinterpret_cast<f32x4*>(stg + p * 32 + 16 + 4 * q) = dc[1];
                 wave_lds_fence();
-                scatter_tile(dH, v, ggrid, lane);
+                scatter_tile(stg, v, ggrid, lane);
                 wave_lds_fence();
             }
         }
-        if (want_r) {
+        if (want_r && tvalid) {
             if (q != 0) { dpx = dpy = dpz = 0.f; }
             add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
         }
     }
 
-    // ---- bias gradients: reduce over the 16 sample lanes, add to the workgroup accumulator
+    // ---- flush: stage the owned tiles into a packed-layout LDS image, then coalesced global atomics
     if (want_w) {
+        float* sacc = smem;
+        __syncthreads();
+        for (int e = threadIdx.x; e < GF; e += 256) sacc[e] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int j = 0; j < CT / 2; ++j) stage_tile(sacc + L.oWc(i), CT * 16, 0, CT, wave + 4 * j, aWc[i][j], 32, CT * 16, p, q);
+            if (i == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float a = gb[i][rt][r], b = gbc[i][rt][r];
+                for (int j = 0; j < 3; ++j) stage_tile(sacc + L.oW(0), 96, 0, 6, wave + 4 * j, aW[0][j], 32, 96, p, q);
+            } else if (i == 3) {
 #pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-                    if (p == 0) {
-                        lds_add(sacc + L.ob(i) + 16 * rt + 4 * q + r, a);
-                        lds_add(sacc + L.obc(i) + 16 * rt + 4 * q + r, b);
-                    }
-                }
+                for (int j = 0; j < 4; ++j) stage_tile(sacc + L.oW(3), 128, 0, 8, wave + 4 * j, aW[3][j], 32, 128, p, q);
+            } else {
+                stage_tile(sacc + L.oW(i), 32, 0, 2, wave, aW[i][0], 32, 32, p, q);
             }
+            stage_bias(sacc + (wave < 2 ? L.ob(i) : L.obc(i)), wave & 1, aB[i], 32, p, q);
         }
+        if (wave < 2) stage_tile(sacc + L.oWo(), 32, 0, 2, wave, aWo[0], NOUT, 32, p, q);
+        if (wave == 2) stage_bias(sacc + L.obo(), 0, aBo, NOUT, p, q);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float a = gbo[r];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o);
-            if (lane == 0 && r < NOUT) lds_add(sacc + L.obo() + r, a);
-        }
+        for (int j = 0; j < 2; ++j)
+            if (wave + 4 * j < 6) stage_tile(sacc + L.oBT(), 4, 0, 1, wave + 4 * j, aBT[j], 93, 3, p, q);
         __syncthreads();
         for (int e = threadIdx.x; e < GF; e += 256) {
             const float vsum = sacc[e];
@@ -478,37 +539,46 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
 // ------------------------------------------------------------------------------------------------
 // MLP_no_xyz (coarse) backward role
 // ------------------------------------------------------------------------------------------------
+struct FeatSlots {
+    static constexpr int C = 0;        // 2: grid features; followed by X1 so that W3's input [c|h2] is contiguous
+    static constexpr int X1 = 2;       // 2: h2 / h0 / h4
+    static constexpr int X0 = 4;       // 2: h3 / h1
+    static constexpr int P0 = 6, P1 = 8;
+    static constexpr int Q = 10;
+    static constexpr int TILES = 11;
+};
+
 ENS_DEV void feat_role(const BwdArgs& A, int wg, int n_wg, float* smem) {
     constexpr FeatLay L{};
     constexpr int GF = L.fwd_floats();
-    constexpr int WSCR = (2 + 2 + 2 + 1) * 256;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+    using SL = FeatSlots;
+    constexpr int SLOT = SL::TILES * 256;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
     const float* __restrict__ pk = A.sc.packed[0];
     const DevGrid grid = A.sc.grid[0];
     const DevGrid ggrid = A.ggrid[0];
     float* gpk = A.gpacked[0];
     const bool want_w = gpk != nullptr, want_g = ggrid.data != nullptr, want_r = A.g_ro != nullptr;
-    float* sacc = smem;
-    float* scr = smem + GF + wave * WSCR;
-    float* dC = scr;                 // 2 tiles: grid features
-    float* dX = dC + 2 * 256;        // 2 tiles: layer input
-    float* dP = dX + 2 * 256;        // 2 tiles: dpre (also scatter staging)
-    float* dQ = dP + 2 * 256;        // 1 tile : d_out
-    for (int e = threadIdx.x; e < GF; e += 256) sacc[e] = 0.f;
-    __syncthreads();
-    f32x4 gb[5][2];
+    float* my = smem + wave * SLOT;
+    f32x4 aW[5][2], aB[5], aWo[1], aBo;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) gb[i][0] = gb[i][1] = splat4(0.f);
-    f32x4 gbo = splat4(0.f);
+    for (int i = 0; i < 5; ++i) { aW[i][0] = aW[i][1] = aB[i] = splat4(0.f); }
+    aWo[0] = aBo = splat4(0.f);
 
     const int64_t n_tiles = (int64_t)A.n_rays * A.ntl;
     const int S = 16 * A.ntl;
-    for (int64_t tile = (int64_t)wg * 4 + wave; tile < n_tiles; tile += (int64_t)n_wg * 4) {
+    const int64_t stride = (int64_t)n_wg * 4;
+    for (int64_t base = (int64_t)wg * 4; base < n_tiles; base += stride) {
+        const int64_t tile_raw = base + wave;
+        const bool tvalid = tile_raw < n_tiles;
+        const int tile = __builtin_amdgcn_readfirstlane((int)(tvalid ? tile_raw : n_tiles - 1));
         const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
-        const f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4);
+        f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4);
+        if (!tvalid) draw = splat4(0.f);
         f32x4 dout = splat4(0.f);
         if (q == 0) dout[0] = draw[3];
-        if (!__any(dout[0] != 0.f)) continue;
+        const int active = __any(dout[0] != 0.f) ? 1 : 0;
+        if (want_w ? !__syncthreads_or(active) : !active) continue;
         const Vox v = make_vox(G.pw, A.sc.clo, A.sc.chi, grid);
         f32x4 c[1][2];
         gather8(v, grid, q, c[0][0], c[0][1]);
@@ -533,13 +603,12 @@ ENS_DEV void feat_role(const BwdArgs& A, int wg, int n_wg, float* smem) {
         };
         fwd_layer(IC(0)); fwd_layer(IC(1)); fwd_layer(IC(2)); fwd_layer(IC(3)); fwd_layer(IC(4));
         if (want_w) {
-            deposit(dC, 0, c[0][0], p, q); deposit(dC, 1, c[0][1], p, q);
-            deposit(dQ, 0, dout, p, q);
-            deposit(dX, 0, h[4][0][0], p, q); deposit(dX, 1, h[4][0][1], p, q);
-            wave_lds_fence();
-            outer_acc<1, 2>(sacc + L.oWo(), 32, 0, dQ, 0, dX, 0, 1, 32, lane, p, q);
-            gbo += dout;
-            wave_lds_fence();
+            deposit(my, SL::C, c[0][0], p, q); deposit(my, SL::C + 1, c[0][1], p, q);
+            deposit(my, SL::Q, dout, p, q);
+            deposit(my, SL::X1, h[4][0][0], p, q); deposit(my, SL::X1 + 1, h[4][0][1], p, q);
+            __syncthreads();
+            own_outer<1>(aWo, smem, SLOT, SL::Q, SL::X1, 2, 2, wave, lane);
+            if (wave == 2) own_bias(aBo, smem, SLOT, SL::Q, lane);
         }
         f32x4 dh[2] = {splat4(0.f), splat4(0.f)};
         {
@@ -550,24 +619,23 @@ ENS_DEV void feat_role(const BwdArgs& A, int wg, int n_wg, float* smem) {
         f32x4 dc[2] = {splat4(0.f), splat4(0.f)};
         auto bwd_layer = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
+            constexpr int TP = (i & 1) ? SL::P1 : SL::P0, TX = (i & 1) ? SL::X1 : SL::X0;
             f32x4 dpre[2] = {mask4(dh[0], mbits[i], 0), mask4(dh[1], mbits[i], 4)};
             if (want_w) {
-                gb[i][0] += dpre[0]; gb[i][1] += dpre[1];
-                deposit(dP, 0, dpre[0], p, q); deposit(dP, 1, dpre[1], p, q);
+                deposit(my, TP, dpre[0], p, q); deposit(my, TP + 1, dpre[1], p, q);
                 if constexpr (i >= 1) {
                     constexpr int j = i == 3 ? 2 : i - 1;
-                    deposit(dX, 0, h[j][0][0], p, q); deposit(dX, 1, h[j][0][1], p, q);
+                    deposit(my, TX, h[j][0][0], p, q); deposit(my, TX + 1, h[j][0][1], p, q);
                 }
-                wave_lds_fence();
+                __syncthreads();
                 if constexpr (i == 0) {
-                    outer_acc<2, 2>(sacc + L.oW(0), 32, 0, dP, 0, dC, 0, 32, 32, lane, p, q);
+                    own_outer<1>(reinterpret_cast<f32x4(&)[1]>(aW[0]), smem, SLOT, TP, SL::C, 2, 4, wave, lane);
                 } else if constexpr (i == 3) {
-                    outer_acc<2, 2>(sacc + L.oW(3), 64, 0, dP, 0, dC, 0, 32, 32, lane, p, q);
-                    outer_acc<2, 2>(sacc + L.oW(3), 64, 32, dP, 0, dX, 0, 32, 32, lane, p, q);
+                    own_outer<2>(aW[3], smem, SLOT, TP, SL::C, 4, 8, wave, lane);                  // [c | h2] contiguous
                 } else {
-                    outer_acc<2, 2>(sacc + L.oW(i), 32, 0, dP, 0, dX, 0, 32, 32, lane, p, q);
+                    own_outer<1>(reinterpret_cast<f32x4(&)[1]>(aW[i]), smem, SLOT, TP, TX, 2, 4, wave, lane);
                 }
-                wave_lds_fence();
+                if (wave < 2) own_bias(aB[i], smem, SLOT, TP + wave, lane);
             }
             if constexpr (i == 0) {
                 linear_n<2, 2>(dc, pk + L.oWT(0), 32, dpre, p, q);
@@ -589,34 +657,35 @@ ENS_DEV void feat_role(const BwdArgs& A, int wg, int n_wg, float* smem) {
             gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
             float dpx = gx * v.gx, dpy = gy * v.gy, dpz = gz * v.gz;
             if (q != 0) { dpx = dpy = dpz = 0.f; }
-            add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
+            if (tvalid) add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
         }
-        if (want_g) {
-            *reinterpret_cast<f32x4*>(dP + p * 32 + 4 * q) = dc[0];
-            *reinterpret_cast<f32x4*>(dP + p * 32 + 16 + 4 * q) = dc[1];
+        if (want_g && tvalid) {
+            if (want_w) __syncthreads();                 // all waves are done reading this round's P tiles
+            float* stg = my + SL::P0 * 256;
+            *reinterpret_cast<f32x4*>(stg + p * 32 + 4 * q) = dc[0];
+            *reinterpret_cast<f32x4*>(stg + p * 32 + 16 + 4 * q) = dc[1];
             wave_lds_fence();
-            scatter_tile(dP, v, ggrid, lane);
+            scatter_tile(stg, v, ggrid, lane);
             wave_lds_fence();
         }
     }
     if (want_w) {
+        float* sacc = smem;
+        __syncthreads();
+        for (int e = threadIdx.x; e < GF; e += 256) sacc[e] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
+            if (i == 3) {
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float a = gb[i][rt][r];
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o);
-                    if (p == 0) lds_add(sacc + L.ob(i) + 16 * rt + 4 * q + r, a);
-                }
+                for (int j = 0; j < 2; ++j) stage_tile(sacc + L.oW(3), 64, 0, 4, wave + 4 * j, aW[3][j], 32, 64, p, q);
+            } else {
+                stage_tile(sacc + L.oW(i), 32, 0, 2, wave, aW[i][0], 32, 32, p, q);
             }
+            if (wave < 2) stage_bias(sacc + L.ob(i), wave, aB[i], 32, p, q);
         }
-        float a = gbo[0];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (lane == 0) lds_add(sacc + L.obo(), a);
+        if (wave < 2) stage_tile(sacc + L.oWo(), 32, 0, 2, wave, aWo[0], 1, 32, p, q);
+        if (wave == 2) stage_bias(sacc + L.obo(), 0, aBo, 1, p, q);
         __syncthreads();
         for (int e = threadIdx.x; e < GF; e += 256) {
             const float vsum = sacc[e];
@@ -642,8 +711,10 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(BwdArgs A) {
     }
 }
 
-constexpr int lds_bytes_xyz(int ct) { return (XyzLay{ct * 16}.fwd_floats() + 4 * (6 + ct + 2 + 2 + 2 + 1) * 256) * 4; }
-constexpr int lds_bytes_feat() { return (FeatLay{}.fwd_floats() + 4 * 7 * 256) * 4; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+// deposit slots of the 4 waves; the packed-layout flush image aliases them at the end of the kernel
+constexpr int lds_bytes_xyz(int ct) { return cmax(XyzLay{ct * 16}.fwd_floats(), 4 * (31 + ct) * 256) * 4; }
+constexpr int lds_bytes_feat() { return cmax(FeatLay{}.fwd_floats(), 4 * 11 * 256) * 4; }
 
 int device_cus() {
     static int cus = 0;
