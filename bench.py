@@ -79,8 +79,10 @@ def make_rays(sc, n_rays, seed):
 
 
 def mapper_loss(depth, color, gt_depth, gt_color, stage, w_color=0.2):
-    m = gt_depth > 0
-    loss = torch.abs(gt_depth[m] - depth[m]).sum()
+    """Mapper.py:553-562: L1 depth over pixels with valid depth (+ w_color * L1 colour in the colour stage).
+    Written with a multiplicative mask instead of boolean indexing: same sum, no device->host sync."""
+    m = (gt_depth > 0).to(depth.dtype)
+    loss = (torch.abs(gt_depth - depth) * m).sum()
     if stage == 'color':
         loss = loss + w_color * torch.abs(gt_color - color).sum()
     return loss
@@ -128,6 +130,7 @@ def main():
     ap.add_argument('--scene', default='room0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='time the plain Python-driven step instead of hipGraph replays')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -164,39 +167,93 @@ def main():
     for k in kinds:
         leaves += list(getattr(model, E._lib.MLP_NAMES[k]).parameters())
 
-    def step():
+    dmax_static = PAR.global_depth_max(gd) if (world > 1 and stage != 'coarse') else None
+    if dmax_static is not None:
+        renderer.depth_max_override = dmax_static
+
+    def pre():          # batch-global sampler maxima over all shards (tiny MAX all-reduce), kept outside the graph
+        if dmax_static is not None:
+            dmax_static.copy_(PAR.global_depth_max(gd))
+
+    def local_step():
+        # a mapper iteration follows an optimiser step: grids and decoders have changed, so the voxel-major
+        # copies and the packed decoders are rebuilt every step (no caching credit in the timed region)
+        EF.clear_caches()
         for t in leaves:
             t.grad = None
         ro.grad = None
         rd.grad = None
-        if world > 1 and stage != 'coarse':
-            renderer.depth_max_override = PAR.global_depth_max(gd)
         depth, var, color = renderer.render_batch_ray(grids, model, rd, ro, dev, stage, gt_depth=gd)
         loss = mapper_loss(depth, color, gd, gc, stage)
         loss.backward()
+        return loss
+
+    def post():         # one bucketed RCCL all-reduce of the leaf gradients
         if world > 1:
             PAR.allreduce_gradients(leaves)
+
+    def step():
+        pre()
+        loss = local_step()
+        post()
         return loss
 
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+
+    # per-kernel timing of the dominant kernel with HIP events on the launch stream (eager pass of the same step)
+    events = None
     if not args.no_kernel_events:
         EF.PROFILE['decoder_bwd'] = []
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    events = EF.PROFILE.pop('decoder_bwd', None)
+        for _ in range(min(args.steps, 50)):
+            step()
+        torch.cuda.synchronize()
+        events = EF.PROFILE.pop('decoder_bwd', None)
+
+    # eager (Python-driven) rate, always reported; the timed region below is graph replay unless --eager
+    def timed(fn, n):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    mode = 'eager'
+    if args.eager:
+        elapsed, loss = timed(step, args.steps)
+        eager_elapsed, eager_steps = elapsed, args.steps
+    else:
+        eager_steps = min(args.steps, 50)
+        eager_elapsed, _ = timed(step, eager_steps)
+        del _
+        from evennicer_slam_amd.graph import GraphedStep
+        import gc as _gcmod
+        for t in leaves:
+            t.grad = None
+        ro.grad = None
+        rd.grad = None
+        _gcmod.collect()            # no autograd graph of an earlier (default-stream) step may stay alive
+        gstep = GraphedStep(local_step)
+
+        def graph_step():
+            pre()
+            out = gstep.replay()
+            post()
+            return out
+
+        mode = 'hipgraph'
+        elapsed, loss = timed(graph_step, args.steps)
 
     S = 48 if stage != 'coarse' else 32
     n_points = args.rays * S
@@ -208,7 +265,8 @@ def main():
                                f"per GPU, render_batch_ray + mapper loss + backward (grads: grids, all decoder params, rays)",
                    "rays_per_gpu": args.rays, "samples_per_ray": S,
                    "parallelism": "1 GPU" if world == 1 else f"ray-sharded dp{world}, one bucketed RCCL all-reduce of leaf grads"},
-        "loss": float(loss.item()),
+        "loss": float(loss.item()), "mode": mode,
+        "eager_rays_per_s": world * args.rays * eager_steps / eager_elapsed,
     }
     if events:
         dur = np.array([a.elapsed_time(b) for a, b in events]) * 1e-3          # seconds

@@ -41,6 +41,10 @@ _SIGS = {
     "enslam_packed_grad_floats": (c_size_t, [ctypes.c_int]),
     "enslam_pack_mlp": (ctypes.c_int, [ctypes.c_int, POINTER(MlpParams), c_void_p, c_void_p]),
     "enslam_unpack_mlp_grads": (ctypes.c_int, [ctypes.c_int, c_void_p, POINTER(MlpParams), c_void_p]),
+    "enslam_unpack_mlp_grads_multi": (ctypes.c_int, [c_int32, POINTER(c_int32), POINTER(c_void_p), POINTER(MlpParams),
+                                                     c_void_p]),
+    "enslam_grids_convert": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int32,
+                                            c_void_p]),
     "enslam_grid_to_voxel_major": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "enslam_grid_from_voxel_major": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "enslam_sample_rays": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,

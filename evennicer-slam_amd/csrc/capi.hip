@@ -9,15 +9,18 @@ bool is_xyz(int kind) { return kind == ENSLAM_MLP_MIDDLE || kind == ENSLAM_MLP_F
 int cdim(int kind) { return kind == ENSLAM_MLP_FINE ? 64 : 32; }
 int nout(int kind) { return kind == ENSLAM_MLP_COLOR ? 4 : 1; }
 
+float* g_seg_packed = nullptr;     // packed buffer recorded in segments built next (multi-decoder jobs)
+
 void add(PackJob& j, float* src, int off, int rows, int cols, int src_ld, int dst_ld, int tr) {
     if (src == nullptr || j.n >= ENS_MAX_SEGS) return;
-    j.seg[j.n++] = PackSeg{src, off, rows, cols, src_ld, dst_ld, tr};
+    j.seg[j.n++] = PackSeg{src, g_seg_packed, off, rows, cols, src_ld, dst_ld, tr};
 }
 
 // Build the segment table of one decoder.  `with_transposed` adds the backward-only copies.
 // Returns false when a required pointer is missing.
-bool build_job(int kind, const enslam_mlp_params& P, bool with_transposed, PackJob& j) {
-    j.n = 0;
+bool build_job(int kind, const enslam_mlp_params& P, bool with_transposed, PackJob& j, bool append = false) {
+    if (!append) j.n = 0;
+    const int n0 = j.n;
     if (is_xyz(kind)) {
         const XyzLay L{cdim(kind)};
         const int CD = cdim(kind), NO = nout(kind);
@@ -50,7 +53,7 @@ bool build_job(int kind, const enslam_mlp_params& P, bool with_transposed, PackJ
             add(j, P.B, L.oBp(), 3, 93, 93, 96, 0);
         }
         const int need = with_transposed ? 24 + 13 : 24;
-        return j.n == need;
+        return j.n - n0 == need;
     }
     if (kind == ENSLAM_MLP_COARSE) {
         const FeatLay L{};
@@ -65,7 +68,7 @@ bool build_job(int kind, const enslam_mlp_params& P, bool with_transposed, PackJ
             for (int i = 0; i < 5; ++i) add(j, P.W[i], L.oWT(i), kin[i], 32, kin[i], 32, 1);
             add(j, P.Wo, L.oWoT(), 32, 1, 32, 4, 1);
         }
-        return j.n == (with_transposed ? 12 + 6 : 12);
+        return j.n - n0 == (with_transposed ? 12 + 6 : 12);
     }
     return false;
 }
@@ -127,6 +130,45 @@ int enslam_unpack_mlp_grads(int kind, const float* packed_grad, const enslam_mlp
     PackJob job;
     build_job(kind, *grads, false, job);        // NULL outputs are simply skipped
     return ens_launch_pack(job, const_cast<float*>(packed_grad), true, (hipStream_t)stream);
+}
+
+int enslam_unpack_mlp_grads_multi(int32_t n, const int32_t* kinds, const float* const* packed_grads,
+                                  const enslam_mlp_params* grads, void* stream) {
+    if (n < 0 || n > 4) return ENSLAM_EINVAL;
+    if (n == 0) return ENSLAM_OK;
+    if (!kinds || !packed_grads || !grads) return ENSLAM_EINVAL;
+    PackJob job;
+    job.n = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!packed_grads[i] || (!is_xyz(kinds[i]) && kinds[i] != ENSLAM_MLP_COARSE)) return ENSLAM_EINVAL;
+        g_seg_packed = const_cast<float*>(packed_grads[i]);
+        build_job(kinds[i], grads[i], false, job, true);
+    }
+    g_seg_packed = nullptr;
+    return ens_launch_pack(job, nullptr, true, (hipStream_t)stream);
+}
+
+int enslam_grids_convert(int32_t n, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                         int32_t to_voxel_major, void* stream) {
+    if (n < 0 || n > 4) return ENSLAM_EINVAL;
+    if (n == 0) return ENSLAM_OK;
+    if (!src || !dst || !n_voxels) return ENSLAM_EINVAL;
+    ConvJob job;
+    job.n = n;
+    int begin = 0;
+    for (int i = 0; i < 4; ++i) {
+        job.block_begin[i] = begin;
+        if (i < n) {
+            if (!src[i] || !dst[i] || n_voxels[i] < 0) return ENSLAM_EINVAL;
+            job.src[i] = src[i]; job.dst[i] = dst[i]; job.V[i] = n_voxels[i];
+            begin += (int)((n_voxels[i] + 63) / 64);
+        } else {
+            job.src[i] = nullptr; job.dst[i] = nullptr; job.V[i] = 0;
+        }
+    }
+    job.block_begin[4] = begin;
+    for (int i = n; i < 4; ++i) job.block_begin[i] = begin;
+    return ens_launch_convert(job, to_voxel_major != 0, (hipStream_t)stream);
 }
 
 int enslam_grid_to_voxel_major(const float* src, float* dst, int64_t n_voxels, void* stream) {

@@ -23,13 +23,14 @@ __global__ __launch_bounds__(1024) void depth_max_kernel(int n, const float* __r
     }
 }
 
-// ------------------------------------------------------------------ z sampling, one thread per ray
+// ------------------------------------------------------------------ z sampling, one wave per ray
+// Lane k < n_lin holds linear sample k, lanes n_lin .. n_lin+n_surf-1 the near-surface samples, the rest +inf;
+// a 64-lane bitonic network (shuffles) sorts them ascending like torch.sort (values only).
 // Follows the dtype promotion of Renderer.py:95-171 term by term:
 //   far_bb  float64: min_axis(max_side((bound - o)/d)) + 0.01
 //   near    float32: gt_depth*0.01f  (0.01f when no depth)
 //   z_lin   float64: (double)(near * (1.f - t)) + far * (double)t
 //   surface float64: (double)(0.95f*d) * (1 - ts) + (double)(1.05f*d) * ts   | 0.001*(1-ts) + (double)dmax*ts
-//   sort ascending (values only).
 constexpr int MAX_S = 64;
 __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n_surf, const float* __restrict__ ro,
                                                      const float* __restrict__ rd, const float* __restrict__ gd,
@@ -38,8 +39,7 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
                                                      const double* __restrict__ t_surf, int lindisp,
                                                      const float* __restrict__ t_rand,
                                                      const float* __restrict__ dmax, double* __restrict__ zout) {
-    const int ray = blockIdx.x * 64 + threadIdx.x;
-    if (ray >= n_rays) return;
+    const int ray = blockIdx.x, lane = threadIdx.x;
     const double lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
     double far_bb = INFINITY;
 #pragma unroll
@@ -60,44 +60,42 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
         far = far_bb < 0.0 ? 0.0 : far_bb;              // clamp(min=0, max=cap)
         far = far > cap ? cap : far;
     }
-    double z[MAX_S];
-    for (int k = 0; k < n_lin; ++k) {
-        const float t = t_lin[k];
+    const int S = n_lin + ((guided && n_surf > 0) ? n_surf : 0);
+    double z = INFINITY;
+    if (lane < n_lin) {
+        const float t = t_lin[lane];
         const float omt = 1.f - t;
         if (!lindisp) {
-            z[k] = (double)(near32 * omt) + far * (double)t;
+            z = (double)(near32 * omt) + far * (double)t;
         } else {
             const float inv_near = guided ? 1.f / near32 : 100.0f;
-            z[k] = 1.0 / ((double)(inv_near * omt) + (1.0 / far) * (double)t);
+            z = 1.0 / ((double)(inv_near * omt) + (1.0 / far) * (double)t);
         }
     }
-    if (t_rand != nullptr) {                             // Renderer.py:160-167
-        double lower[MAX_S], upper[MAX_S];
-        for (int k = 0; k < n_lin; ++k) {
-            const double mid_hi = k + 1 < n_lin ? 0.5 * (z[k + 1] + z[k]) : z[n_lin - 1];
-            const double mid_lo = k > 0 ? 0.5 * (z[k] + z[k - 1]) : z[0];
-            upper[k] = mid_hi;
-            lower[k] = mid_lo;
-        }
-        for (int k = 0; k < n_lin; ++k) z[k] = lower[k] + (upper[k] - lower[k]) * (double)t_rand[(int64_t)ray * n_lin + k];
+    if (t_rand != nullptr) {                             // Renderer.py:160-167 (linear samples only)
+        const double zn = __shfl_down(z, 1), zp = __shfl_up(z, 1);
+        const double upper = lane + 1 < n_lin ? 0.5 * (zn + z) : z;
+        const double lower = lane > 0 ? 0.5 * (z + zp) : z;
+        if (lane < n_lin) z = lower + (upper - lower) * (double)t_rand[(int64_t)ray * n_lin + lane];
     }
-    int S = n_lin;
-    if (guided && n_surf > 0) {
-        const float a32 = 0.95f * g, b32 = 1.05f * g;
-        const double dm = (double)dmax[0];
-        for (int k = 0; k < n_surf; ++k) {
-            const double ts = t_surf[k];
-            z[n_lin + k] = g > 0.f ? (double)a32 * (1.0 - ts) + (double)b32 * ts : 0.001 * (1.0 - ts) + dm * ts;
+    if (S > n_lin) {
+        if (lane >= n_lin && lane < S) {
+            const float a32 = 0.95f * g, b32 = 1.05f * g;
+            const double ts = t_surf[lane - n_lin];
+            z = g > 0.f ? (double)a32 * (1.0 - ts) + (double)b32 * ts : 0.001 * (1.0 - ts) + (double)dmax[0] * ts;
         }
-        S = n_lin + n_surf;
-        for (int i = 1; i < S; ++i) {                    // insertion sort (inputs are two sorted runs)
-            const double v = z[i];
-            int j = i - 1;
-            while (j >= 0 && z[j] > v) { z[j + 1] = z[j]; --j; }
-            z[j + 1] = v;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {              // bitonic sort, ascending over the 64 lanes
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const double other = __shfl_xor(z, j);
+                const bool asc = (lane & k) == 0, low = (lane & j) == 0;
+                const double mn = other < z ? other : z, mx = other < z ? z : other;
+                z = (low == asc) ? mn : mx;
+            }
         }
     }
-    for (int k = 0; k < S; ++k) zout[(int64_t)ray * S + k] = z[k];
+    if (lane < S) zout[(int64_t)ray * S + lane] = z;
 }
 
 // ------------------------------------------------------------------ parity helpers
@@ -132,10 +130,30 @@ __global__ void voxel_index_kernel(int64_t n, const double* __restrict__ pts, do
 
 // ------------------------------------------------------------------ [32][V] <-> [V][32]
 // 64 voxels per block through a padded LDS tile; both sides move 256-byte rows.
+ENS_DEV void to_vm_block(const float* __restrict__ src, float* __restrict__ dst, int64_t V, int64_t blk);
+ENS_DEV void from_vm_block(const float* __restrict__ src, float* __restrict__ dst, int64_t V, int64_t blk);
+
+__global__ __launch_bounds__(256) void convert_kernel(ConvJob job, int to_vm) {
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) g = (i < job.n && (int)blockIdx.x >= job.block_begin[i]) ? i : g;
+    const int64_t blk = blockIdx.x - job.block_begin[g];
+    if (to_vm) to_vm_block(job.src[g], job.dst[g], job.V[g], blk);
+    else from_vm_block(job.src[g], job.dst[g], job.V[g], blk);
+}
+
 __global__ __launch_bounds__(256) void to_voxel_major_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                               int64_t V) {
+    to_vm_block(src, dst, V, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void from_voxel_major_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                int64_t V) {
+    from_vm_block(src, dst, V, blockIdx.x);
+}
+
+ENS_DEV void to_vm_block(const float* __restrict__ src, float* __restrict__ dst, int64_t V, int64_t blk) {
     __shared__ float tile[32][65];
-    const int64_t v0 = (int64_t)blockIdx.x * 64;
+    const int64_t v0 = blk * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int c = ty; c < 32; c += 4) {
@@ -151,10 +169,9 @@ __global__ __launch_bounds__(256) void to_voxel_major_kernel(const float* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void from_voxel_major_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                                int64_t V) {
+ENS_DEV void from_vm_block(const float* __restrict__ src, float* __restrict__ dst, int64_t V, int64_t blk) {
     __shared__ float tile[32][65];
-    const int64_t v0 = (int64_t)blockIdx.x * 64;
+    const int64_t v0 = blk * 64;
     const int c = threadIdx.x & 31, vv = threadIdx.x >> 5;
 #pragma unroll
     for (int j = vv; j < 64; j += 8) {
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackJob job, float* __restric
     for (int e = threadIdx.x; e < n; e += 256) {
         const int r = e / s.cols, c = e - r * s.cols;
         float* src = s.src + (s.transpose ? (int64_t)c * s.src_ld + r : (int64_t)r * s.src_ld + c);
-        float* dst = packed + s.off + r * s.dst_ld + c;
+        float* dst = (s.packed ? s.packed : packed) + s.off + r * s.dst_ld + c;
         if (unpack) *src = *dst; else *dst = *src;
     }
 }
@@ -198,13 +215,19 @@ int ens_launch_transpose(const float* src, float* dst, int64_t V, bool to_vm, hi
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+int ens_launch_convert(const ConvJob& job, bool to_vm, hipStream_t st) {
+    if (job.n <= 0 || job.block_begin[job.n] <= 0) return 0;
+    convert_kernel<<<dim3(job.block_begin[job.n]), dim3(256), 0, st>>>(job, to_vm ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
                       const double* b, const float* t_lin, const double* t_surf, int lindisp, const float* t_rand,
                       float* scratch, int dmax_given, double* z, hipStream_t st) {
     if (n_rays <= 0) return 0;
     if (n_lin + n_surf > MAX_S || n_lin < 1) return -1;
     if (gd != nullptr && !dmax_given) depth_max_kernel<<<1, 1024, 0, st>>>(n_rays, gd, scratch);
-    sample_kernel<<<dim3((n_rays + 63) / 64), dim3(64), 0, st>>>(n_rays, n_lin, gd ? n_surf : 0, ro, rd, gd, b[0], b[1],
+    sample_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(n_rays, n_lin, gd ? n_surf : 0, ro, rd, gd, b[0], b[1],
                                                                  b[2], b[3], b[4], b[5], t_lin, t_surf, lindisp,
                                                                  t_rand, scratch, z);
     return hipGetLastError() == hipSuccess ? 0 : -2;

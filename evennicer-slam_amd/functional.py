@@ -21,7 +21,7 @@ def _require_hip(t, what):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _ptr(t):
@@ -37,16 +37,25 @@ def bound6(bound):
 # ------------------------------------------------------------------------------------------------
 # decoder parameters: ordering, packing cache
 # ------------------------------------------------------------------------------------------------
+_layer_cache = weakref.WeakKeyDictionary()     # decoder module -> its Linear sub-modules (+ embedder), ABI order
+
+
 def decoder_params(dec, kind):
     """Parameter tensors of one decoder in ABI order.  Works on this package's modules and on any
-    module with the reference's attribute names (pts_linears, fc_c, output_linear, embedder._B)."""
+    module with the reference's attribute names (pts_linears, fc_c, output_linear, embedder._B).
+    The sub-module list is cached (nn.ModuleList indexing is slow); parameters are re-read every call."""
+    mods = _layer_cache.get(dec)
+    if mods is None:
+        mods = [dec.pts_linears[i] for i in range(5)]
+        if kind != L.MLP_COARSE:
+            mods += [dec.fc_c[i] for i in range(5)]
+        mods.append(dec.output_linear)
+        _layer_cache[dec] = mods
     ps = []
-    for i in range(5):
-        ps += [dec.pts_linears[i].weight, dec.pts_linears[i].bias]
-    if kind != L.MLP_COARSE:
-        for i in range(5):
-            ps += [dec.fc_c[i].weight, dec.fc_c[i].bias]
-    ps += [dec.output_linear.weight, dec.output_linear.bias]
+    for m in mods:
+        p = m._parameters
+        ps.append(p['weight'])
+        ps.append(p['bias'])
     if kind != L.MLP_COARSE:
         ps.append(dec.embedder._B)
     return ps
@@ -120,11 +129,11 @@ class _PackCache:
 _pack_caches = weakref.WeakKeyDictionary()      # decoder module -> _PackCache
 
 
-def packed_decoder(dec, kind):
+def packed_decoder(dec, kind, params=None):
     cache = _pack_caches.get(dec)
     if cache is None:
         cache = _pack_caches[dec] = _PackCache()
-    return cache.get(kind, decoder_params(dec, kind))
+    return cache.get(kind, params if params is not None else decoder_params(dec, kind))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -155,6 +164,41 @@ class _GridCache:
         key, items = id(g), self.items
         self.items[key] = (weakref.ref(g, lambda _r, key=key, items=items: items.pop(key, None)), g._version, vm)
         return vm
+
+
+    def get_many(self, grids):
+        """Voxel-major copies of several grids; all cache misses are converted in ONE launch."""
+        out, miss = [], []
+        for i, g in enumerate(grids):
+            e = self.items.get(id(g))
+            if e is not None and e[0]() is g and e[1] == g._version:
+                out.append(e[2])
+            else:
+                out.append(None)
+                miss.append(i)
+        if len(miss) == 1:
+            out[miss[0]] = self.get(grids[miss[0]])
+        elif miss:
+            n = len(miss)
+            srcs, dsts, vs, keep = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), []
+            for j, i in enumerate(miss):
+                g = grids[i]
+                if g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32 or g.dtype != torch.float32:
+                    raise L.EnslamError(f"feature grid must be float32 [1,32,D,H,W], got {tuple(g.shape)} {g.dtype}")
+                _require_hip(g, "feature grids")
+                src = g.detach()
+                src = src if src.is_contiguous() else src.contiguous()
+                V = g.shape[2] * g.shape[3] * g.shape[4]
+                vm = torch.empty((V, 32), dtype=torch.float32, device=g.device)
+                srcs[j], dsts[j], vs[j] = src.data_ptr(), vm.data_ptr(), V
+                keep.append(src)
+                out[i] = vm
+            L.check(L.lib().enslam_grids_convert(n, srcs, dsts, vs, 1, _stream()), "enslam_grids_convert")
+            for i in miss:
+                g = grids[i]
+                key, items = id(g), self.items
+                items[key] = (weakref.ref(g, lambda _r, key=key, items=items: items.pop(key, None)), g._version, out[i])
+        return out
 
 
 _grid_cache = _GridCache()
@@ -225,10 +269,12 @@ class _RenderFn(torch.autograd.Function):
                                        _ptr(scratch), int(plan.depth_max is not None), _ptr(z), st),
                 "enslam_sample_rays")
         grids_vm, dims, packed = {}, {}, {}
-        for k, g in zip(plan.kinds, grids):
-            grids_vm[k] = _grid_cache.get(g)
+        po = nk
+        for k, g, vm in zip(plan.kinds, grids, _grid_cache.get_many(grids)):
+            grids_vm[k] = vm
             dims[k] = tuple(g.shape[2:])
-            packed[k] = packed_decoder(plan.decoders[k], k)
+            packed[k] = packed_decoder(plan.decoders[k], k, tensors[po:po + plan.n_params[k]])
+            po += plan.n_params[k]
         sc = _scene_struct(plan.stage, plan.bound6, plan.coarse_bound6, grids_vm, dims, packed)
         depth = torch.empty(N, dtype=torch.float64, device=dev)
         var = torch.empty(N, dtype=torch.float64, device=dev)
@@ -270,19 +316,34 @@ class _RenderFn(torch.autograd.Function):
         sc = _scene_struct(plan.stage, plan.bound6, plan.coarse_bound6, grids_vm, ctx.dims, packed)
         gg = (L.Grid * 4)()
         gpk = (ctypes.c_void_p * 4)()
-        g_grids_vm, g_packed = {}, {}
+        # ONE zero-filled buffer holds every accumulator the kernels add into
+        sizes = []
         for k in plan.kinds:
             D, H, W = ctx.dims[k]
             gg[k].D, gg[k].H, gg[k].W = D, H, W
-            # fine decoder's middle-feature concat gets no gradient: grid 1 only via the middle decoder
+            sizes.append(D * H * W * 32 if need_grid[k] else 0)
+        for k in plan.kinds:
+            sizes.append(lib.enslam_packed_grad_floats(k) if need_par[k] else 0)
+        sizes.append(6 * N if need_rays else 0)
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        base = flat.data_ptr()
+        g_grids_vm, g_packed = {}, {}
+        for i, k in enumerate(plan.kinds):
             if need_grid[k]:
-                g_grids_vm[k] = torch.zeros((D * H * W, 32), dtype=torch.float32, device=dev)
-                gg[k].data = g_grids_vm[k].data_ptr()
+                g_grids_vm[k] = base + 4 * offs[i]
+                gg[k].data = g_grids_vm[k]
             if need_par[k]:
-                g_packed[k] = torch.zeros(lib.enslam_packed_grad_floats(k), dtype=torch.float32, device=dev)
-                gpk[k] = g_packed[k].data_ptr()
-        g_ro = torch.zeros((N, 3), dtype=torch.float32, device=dev) if need_rays else None
-        g_rd = torch.zeros((N, 3), dtype=torch.float32, device=dev) if need_rays else None
+                g_packed[k] = base + 4 * offs[nk + i]
+                gpk[k] = g_packed[k]
+        g_ro = g_rd = None
+        p_ro = p_rd = ctypes.c_void_p(0)
+        if need_rays:
+            g_ro = flat[offs[2 * nk]:offs[2 * nk] + 3 * N].view(N, 3)
+            g_rd = flat[offs[2 * nk] + 3 * N:offs[2 * nk] + 6 * N].view(N, 3)
+            p_ro, p_rd = _ptr(g_ro), _ptr(g_rd)
         d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
         L.check(lib.enslam_composite_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
                                          _ptr(d_raw), st), "enslam_composite_bwd")
@@ -291,34 +352,46 @@ class _RenderFn(torch.autograd.Function):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         L.check(lib.enslam_decoder_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                       _ptr(d_raw), gg, gpk, _ptr(g_ro), _ptr(g_rd), st), "enslam_decoder_bwd")
+                                       _ptr(d_raw), gg, gpk, p_ro, p_rd, st), "enslam_decoder_bwd")
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
         out = [None, g_ro if needs[1] else None, g_rd if needs[2] else None, None, None]
-        for i, k in enumerate(plan.kinds):
-            if need_grid[k]:
+        # grid gradients back to the callers' [1,32,D,H,W] layout: one launch for all grids
+        conv = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k]]
+        grid_out = {}
+        if conv:
+            n = len(conv)
+            srcs, dsts, vs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)()
+            for j, (i, k) in enumerate(conv):
                 g = torch.empty(ctx.grid_shapes[i], dtype=torch.float32, device=dev)
-                V = g_grids_vm[k].shape[0]
-                L.check(lib.enslam_grid_from_voxel_major(_ptr(g_grids_vm[k]), _ptr(g), V, st), "grid_from_voxel_major")
-                out.append(g)
-            else:
-                out.append(None)
-        pm = iter(ctx.param_meta)
+                grid_out[k] = g
+                srcs[j], dsts[j], vs[j] = g_grids_vm[k], g.data_ptr(), sizes[i] // 32
+            L.check(lib.enslam_grids_convert(n, srcs, dsts, vs, 0, st), "enslam_grids_convert")
         for k in plan.kinds:
-            shapes = [next(pm) for _ in range(plan.n_params[k])]
-            if not need_par[k]:
-                out += [None] * len(shapes)
-                continue
-            sizes = [int(torch.Size(s).numel()) for s in shapes]
-            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-            views, o = [], 0
-            for s, n in zip(shapes, sizes):
-                views.append(flat[o:o + n].view(s))
-                o += n
-            ps = _fill_params_struct(k, views)
-            L.check(lib.enslam_unpack_mlp_grads(k, _ptr(g_packed[k]), ctypes.byref(ps), st), "unpack_mlp_grads")
-            out += views
+            out.append(grid_out.get(k))
+        # decoder gradients: one flat buffer, views shaped like the parameters, one unpack launch
+        pm = iter(ctx.param_meta)
+        shapes_by_kind = {k: [next(pm) for _ in range(plan.n_params[k])] for k in plan.kinds}
+        kinds_p = [k for k in plan.kinds if need_par[k]]
+        views_by_kind = {}
+        if kinds_p:
+            all_sizes = [int(torch.Size(sh).numel()) for k in kinds_p for sh in shapes_by_kind[k]]
+            pflat = torch.empty(sum(all_sizes), dtype=torch.float32, device=dev)
+            pieces = pflat.split(all_sizes)
+            it = iter(pieces)
+            n = len(kinds_p)
+            kind_arr, pk_arr, structs = (ctypes.c_int32 * n)(), (ctypes.c_void_p * n)(), (L.MlpParams * n)()
+            for j, k in enumerate(kinds_p):
+                views = [next(it).view(sh) for sh in shapes_by_kind[k]]
+                views_by_kind[k] = views
+                kind_arr[j], pk_arr[j] = k, g_packed[k]
+                structs[j] = _fill_params_struct(k, views)
+            L.check(lib.enslam_unpack_mlp_grads_multi(n, kind_arr, pk_arr, structs, st), "unpack_mlp_grads_multi")
+        for k in plan.kinds:
+            out += views_by_kind.get(k, [None] * plan.n_params[k])
+        ctx.keep = None
+        del flat
         return tuple(out)
 
 

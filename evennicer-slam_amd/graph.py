@@ -1,0 +1,31 @@
+"""HIP-graph capture of a whole optimisation step (render + caller's loss + backward).
+
+The reference's loops issue several hundred tiny device launches per iteration from Python; on MI355X the
+kernels of this path finish faster than Python can enqueue them.  Capturing the step once (torch.cuda.graphs
+drives hipGraph on ROCm; the library's launches are ordinary stream-ordered launches and are captured with
+everything else) makes an iteration a single hipGraphLaunch.
+
+Requirements on `step_fn`: it reads and writes only tensors that stay allocated (static inputs: update them
+in place with .copy_ between replays), performs no host synchronisation (.item(), boolean-mask indexing), and
+leaves gradients in `.grad` of the leaves.  The ray count is fixed at capture time."""
+import torch
+
+
+class GraphedStep:
+    def __init__(self, step_fn, warmup=3):
+        self.step_fn = step_fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):             # first-use work (module loading, attribute calls) stays outside
+                out = step_fn()
+                del out
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = step_fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.out

@@ -94,12 +94,18 @@ int enslam_pack_mlp(int kind, const enslam_mlp_params *params, float *packed, vo
 /* Inverse for gradients: packed_grad (accumulated by enslam_render_bwd) -> tensors shaped like the
  * reference parameters.  Pointers in `grads` that are NULL are skipped. */
 int enslam_unpack_mlp_grads(int kind, const float *packed_grad, const enslam_mlp_params *grads, void *stream);
+/* The same for several decoders in ONE launch (host arrays of length n <= 4). */
+int enslam_unpack_mlp_grads_multi(int32_t n, const int32_t *kinds, const float *const *packed_grads,
+                                  const enslam_mlp_params *grads, void *stream);
 
 /* [C,V] -> [V,C] and back (C = 32).  Replaces the implicit layout of F.grid_sample's input
  * (decoder.py:173-174).  `to` reads the caller's grid; `from` writes a gradient the caller's
  * autograd expects ([1,32,D,H,W]). */
 int enslam_grid_to_voxel_major(const float *src, float *dst, int64_t n_voxels, void *stream);
 int enslam_grid_from_voxel_major(const float *src, float *dst, int64_t n_voxels, void *stream);
+/* The same for up to 4 grids in ONE launch (n <= 4; src/dst/n_voxels are host arrays of length n). */
+int enslam_grids_convert(int32_t n, const float *const *src, float *const *dst, const int64_t *n_voxels,
+                         int32_t to_voxel_major, void *stream);
 
 /* Sample distances along rays.  Replaces Renderer.render_batch_ray lines 83-171
  * (src/utils/Renderer.py): near/far from gt_depth and the AABB exit, n_lin linear samples,
