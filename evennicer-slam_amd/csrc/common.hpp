@@ -19,6 +19,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 ENS_DEV f32x4 ld4(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
+#ifdef ENS_EXP_L1WEIGHTS      // timing experiment only (wrong results): all weight fragments from one 4 KB window
+#define ldw(base, off) ld4((base) + ((off) & 1020))
+#else
+#define ldw(base, off) ld4((base) + (off))
+#endif
 ENS_DEV f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
 ENS_DEV f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
 
@@ -158,7 +163,7 @@ ENS_DEV void linear32(f32x4 (&acc)[NTL][2], const float* __restrict__ W, int ld,
     for (int t = 0; t < KT; ++t) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            const f32x4 a = ld4(W + (16 * rt + p) * ld + 16 * t + 4 * q);
+            const f32x4 a = ldw(W, (16 * rt + p) * ld + 16 * t + 4 * q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll

@@ -22,7 +22,25 @@
 
 #define IC(n) std::integral_constant<int, n>{}
 
+// Diagnostic build only (-DENS_STAMPS): per-segment cycle counts of each wave (s_memtime), written to a
+// buffer of their own; never compiled into the shipped library.
+#ifdef ENS_STAMPS
+#define ENS_NSEG 12
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define STAMP_DECL unsigned long long st_acc[ENS_NSEG] = {}; unsigned long long st_prev = 0;
+#define STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP(k) { unsigned long long st_now; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); __builtin_amdgcn_sched_barrier(0); st_acc[k] += st_now - st_prev; st_prev = st_now; }
+#define STAMP_FLUSH { if (g_stamp_buf && lane == 0) { for (int k_ = 0; k_ < ENS_NSEG; ++k_) g_stamp_buf[((size_t)blockIdx.x * 4 + wave) * ENS_NSEG + k_] = st_acc[k_]; } }
+#else
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(k)
+#define STAMP_FLUSH
+#endif
+
 namespace {
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // ------------------------------------------------------------------------------------------------
 // composite backward
@@ -93,6 +111,8 @@ ENS_DEV void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+ENS_DEV void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // ---- owner-computes weight gradients ----------------------------------------------------------
 // The 4 waves of a workgroup work in lockstep on 4 sample tiles.  Each wave deposits its tile's operands
 // in its own LDS slot; after a barrier every wave accumulates the dW output tiles IT OWNS (tile index
@@ -117,6 +137,12 @@ ENS_DEV void own_outer(f32x4 (&acc)[NJ], const float* slots, int slot_stride, in
         }
         __builtin_amdgcn_sched_barrier(0);          // keep the scheduler from hoisting all slots' fragment reads
     }
+}
+ENS_DEV void own_outer_1(f32x4& acc, const float* slots, int slot_stride, int ytile0, int xtile0, int nc, int ntiles,
+                         int wave, int lane) {
+    f32x4 t[1] = {acc};
+    own_outer<1>(t, slots, slot_stride, ytile0, xtile0, nc, ntiles, wave, lane);
+    acc = t[0];
 }
 // bias gradient: acc += sum_{slot, sample} Y[slot][sample][16*rt + i]   (every column of the tile identical)
 ENS_DEV void own_bias(f32x4& acc, const float* slots, int slot_stride, int ytile, int lane) {
@@ -151,13 +177,19 @@ ENS_DEV void stage_bias(float* sbias, int rt, const f32x4& acc, int n_valid, int
 // acc[rt] += M[(16rt+p)*ld + 16t + 4q ..] * x[t]   (NR output row tiles, KT input tiles), single sample tile
 template <int NR, int KT>
 ENS_DEV void linear_n(f32x4 (&acc)[NR], const float* __restrict__ M, int ld, const f32x4 (&x)[KT], int p, int q) {
+    f32x4 a[KT][NR];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
 #pragma unroll
-        for (int rt = 0; rt < NR; ++rt) {
-            const f32x4 a = ld4(M + (16 * rt + p) * ld + 16 * t + 4 * q);
+        for (int rt = 0; rt < NR; ++rt) a[t][rt] = ldw(M, (16 * rt + p) * ld + 16 * t + 4 * q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rt] = MFMA16(a[r], x[t][r], acc[rt]);
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt) acc[rt] = MFMA16(a[t][rt][r], x[t][r], acc[rt]);
         }
     }
 }
@@ -276,23 +308,111 @@ struct BwdArgs {
 // MLP (middle / fine / color) backward for one workgroup role
 // ------------------------------------------------------------------------------------------------
 template <int CT>
-struct XyzSlots {                      // tile offsets inside one wave's LDS slot (1 tile = 256 floats)
+struct XyzSlots {                      // tile offsets inside one wave's LDS deposit slot (1 tile = 256 floats)
     static constexpr int EMB = 0;      // 6: embedding (later d_arg); followed by h2 so that W3's input [emb|h2] is contiguous
-    static constexpr int HX2 = 6, HX0 = 8, HX1 = 10, HX3 = 12, HX4 = 14;   // 2 each: hidden activations h_i (dW operands)
-    static constexpr int C = 16;       // CT: grid features
-    static constexpr int H0 = 16 + CT, H1 = 18 + CT;     // dh_i, double buffered by layer parity
-    static constexpr int P0 = 20 + CT, P1 = 22 + CT;     // dpre_i
-    static constexpr int Q = 24 + CT;                    // d_out / sample coordinates
-    static constexpr int STASH = 25 + CT;                // 6: wave-private stash of the partial d_emb (lane-linear)
-    static constexpr int TILES = 31 + CT;
+    static constexpr int HX2 = 6, HX0 = 8, HX1 = 10, HX3 = 12;            // 2 each: hidden activations h_i (dW operands)
+    static constexpr int C = 14;       // CT: grid features
+    static constexpr int H0 = 14 + CT, H1 = 16 + CT;     // dh_i, double buffered by layer parity
+    static constexpr int P0 = 18 + CT, P1 = 20 + CT;     // dpre_i
+    static constexpr int Q = 22 + CT;                    // sample coordinates (dB^T operand)
+    static constexpr int TILES = 23 + CT;
 };
+// weight ring: two buffers, each holds one layer's chunk (forward: W|b|Wc|bc ; backward: W^T|Wc^T)
+constexpr int ring_floats(int ct) { return cmax(32 * 128 + 32 + 32 * 16 * ct + 32, 128 * 32 + 1024); }
+
+// cooperative async copy global -> LDS of n4 float4 (all 256 threads; 1 KB per wave instruction, no VGPR staging)
+ENS_DEV void ring_load(float* dst_lds, const float* __restrict__ src, int n4, int wave, int lane) {
+    for (int j = 0; j * 256 < n4; ++j) {
+        const int e = j * 256 + wave * 64 + lane;
+        if (e < n4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * e),
+                                             (__attribute__((address_space(3))) void*)(dst_lds + 4 * (j * 256 + wave * 64)),
+                                             16, 0, 0);
+    }
+}
+
+// ---- explicit LDS addressing -------------------------------------------------------------------
+// Every LDS access of the xyz role is  (one per-lane base VGPR) + (compile-time byte offset): the offset folds
+// into the instruction's 16-bit offset field, so no address registers pile up (left to itself the compiler
+// hoists hundreds of loop-invariant addresses out of the tile loop, runs out of VGPRs and stops overlapping
+// loads with MFMAs).  The bases are made opaque once per round so they cannot be re-expanded and hoisted.
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+ENS_DEV f32x4 lds4(unsigned addr) { return *reinterpret_cast<const lds_f32x4*>(static_cast<uintptr_t>(addr)); }
+ENS_DEV void lds_st4(unsigned addr, const f32x4& v) { *reinterpret_cast<lds_f32x4*>(static_cast<uintptr_t>(addr)) = v; }
+ENS_DEV void lds_st1(unsigned addr, float v) { *reinterpret_cast<lds_float*>(static_cast<uintptr_t>(addr)) = v; }
+ENS_DEV void opaque(unsigned& v) { asm volatile("" : "+v"(v)); }
+
+// acc[rt] += W[(16rt+i)*LD + 16t + 4q ..] * x[t]; W at byte offset OFF behind the lane base  base = (p*LD + 4q)*4
+template <int NR, int KT, int LD, int OFF>
+ENS_DEV void lin_lds(f32x4 (&acc)[NR], unsigned base, const f32x4 (&x)[KT]) {
+    // all fragment reads first (independent, distinct registers), then the MFMAs with the accumulators
+    // alternating so that back-to-back issues never wait on their own result
+    f32x4 a[KT][NR];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt) a[t][rt] = lds4(base + OFF + (16 * rt * LD + 16 * t) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt) acc[rt] = MFMA16(a[t][rt][r], x[t][r], acc[rt]);
+        }
+    }
+}
+// deposit tile T (byte offset T*1024 behind dep = slot base + ((p>>2)*64 + (p&3) + 16q)*4)
+template <int T>
+ENS_DEV void dep_tile(unsigned dep, const f32x4& x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds_st1(dep + T * 1024 + 16 * r, x[r]);
+}
+// owned outer products with integer addressing: fb[sl] = slot sl base + lane*16
+template <int NJ>
+ENS_DEV void own_outer_a(f32x4 (&acc)[NJ], const unsigned (&fb)[4], int ytile0, int xtile0, int nc, int ntiles, int wave) {
+    // tiles t >= ntiles (only the 6-tile dB^T matrix has them) read tile 0 and are discarded by the caller's
+    // staging (it never stages t >= ntiles): no divergent control flow around the MFMAs
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        f32x4 a[NJ], b[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int t = wave + 4 * j;
+            t = t < ntiles ? t : 0;
+            const int rt = t / nc, ct = t - rt * nc;
+            a[j] = lds4(fb[sl] + (ytile0 + rt) * 1024);
+            b[j] = lds4(fb[sl] + (xtile0 + ct) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = MFMA16(a[j][s], b[j][s], acc[j]);
+        }
+    }
+}
+ENS_DEV void own_bias_a(f32x4& acc, const unsigned (&fb)[4], int ytile) {
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        const f32x4 a = lds4(fb[sl] + ytile * 1024);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = MFMA16(a[s], 1.f, acc);
+    }
+}
 
 template <int CT, int NOUT>
 ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem) {
     constexpr XyzLay L{CT * 16};
+    constexpr int CD = CT * 16;
     constexpr int GF = L.fwd_floats();
+    constexpr int NE = NOUT == 4 ? 3 : 1;                          // outputs that carry gradient
     using SL = XyzSlots<CT>;
-    constexpr int SLOT = SL::TILES * 256;
+    constexpr int SLOT = SL::TILES * 256;                          // floats
+    constexpr int RB = ring_floats(CT);                            // floats per ring buffer
+    constexpr int RING_BYTES = 2 * RB * 4;                         // LDS: [ring | 4 deposit slots]; flush image aliases the slots
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
     const float* __restrict__ pk = A.sc.packed[kind];
     const DevGrid grid = A.sc.grid[kind];
@@ -300,23 +420,49 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
     float* gpk = A.gpacked[kind];
     const bool want_w = gpk != nullptr, want_g = ggrid.data != nullptr, want_r = A.g_ro != nullptr;
     const bool want_c = want_g || want_r;
-    float* my = smem + wave * SLOT;                                 // this wave's deposit slot
+    float* ring = smem;
+    float* slots = smem + 2 * RB;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)smem;   // LDS byte address of the dynamic region
+
+    // chunk c of a round: 0..4 forward layers, 5..9 backward layers 4..0, 10 = layer 0 of the next round
+    auto prefetch = [&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        float* dst = ring + ((c & 1) ? RB : 0);
+        if constexpr (c < 5 || c == 10) {
+            constexpr int i = c == 10 ? 0 : c;
+            ring_load(dst, pk + L.oW(i), (L.oW(i + 1) - L.oW(i)) / 4, wave, lane);
+        } else {
+            constexpr int i = 9 - c;
+            ring_load(dst, pk + L.oWT(i), 8 * L.K(i), wave, lane);
+            ring_load(dst + 32 * L.K(i), pk + L.oWcT(i), 256, wave, lane);
+        }
+    };
 
     // owned weight-gradient accumulators (tile t = wave + 4*j of each matrix), persistent over all rounds
-    f32x4 aWc[5][CT / 2], aW[5][4], aB[5], aBT[2], aWo[1], aBo;
+    f32x4 aWc[5][CT / 2], aW0[3], aW1[1], aW2[1], aW3[4], aW4[1], aB[5], aBT[2];
+    float aWo[NE][8], aBo[NE];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         aB[i] = splat4(0.f);
 #pragma unroll
         for (int j = 0; j < CT / 2; ++j) aWc[i][j] = splat4(0.f);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) aW[i][j] = splat4(0.f);
     }
-    aBT[0] = aBT[1] = aWo[0] = aBo = splat4(0.f);
+    aW0[0] = aW0[1] = aW0[2] = aW1[0] = aW2[0] = aW4[0] = splat4(0.f);
+    aW3[0] = aW3[1] = aW3[2] = aW3[3] = splat4(0.f);
+    aBT[0] = aBT[1] = splat4(0.f);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        aBo[j] = 0.f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) aWo[j][f] = 0.f;
+    }
 
     const int64_t n_tiles = (int64_t)A.n_rays * A.ntl;
     const int S = 16 * A.ntl;
     const int64_t stride = (int64_t)n_wg * 4;
+    STAMP_DECL
+    STAMP_START
+    prefetch(IC(0));
     for (int64_t base = (int64_t)wg * 4; base < n_tiles; base += stride) {
         const int64_t tile_raw = base + wave;
         const bool tvalid = tile_raw < n_tiles;
@@ -324,131 +470,158 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
         const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
         f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4);
         if (!tvalid) draw = splat4(0.f);
-        // output gradient of this decoder as a D-layout tile (rows 0..NOUT-1 live on q == 0 lanes)
-        f32x4 dout = splat4(0.f);
-        if (q == 0) dout = NOUT == 4 ? f32x4{draw[0], draw[1], draw[2], 0.f} : f32x4{draw[3], 0.f, 0.f, 0.f};
-        const int active = __any(dout[0] != 0.f || dout[1] != 0.f || dout[2] != 0.f) ? 1 : 0;
-        // nothing flows into the tile(s): skip.  With weight gradients the 4 waves stay in lockstep (barriers).
-        if (want_w ? !__syncthreads_or(active) : !active) continue;
+        float dj[NE];                                               // d(loss)/d(output j) of this lane's sample
+        if constexpr (NOUT == 4) { dj[0] = draw[0]; dj[1] = draw[1]; dj[2] = draw[2]; } else { dj[0] = draw[3]; }
+        bool nz = false;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) nz = nz || dj[j] != 0.f;
+        // nothing flows into any of the 4 tiles: skip the round (the waves of a workgroup stay in lockstep)
+        if (!__syncthreads_or(__any(nz) ? 1 : 0)) continue;
+        STAMP(0)        // tile geometry + d_raw load + vote barrier
 
-        // ---- recompute the forward chain
+        // per-lane LDS bases of this round (opaque: see above)
+        unsigned w32 = lds0 + (p * 32 + 4 * q) * 4, w96 = lds0 + (p * 96 + 4 * q) * 4, w128 = lds0 + (p * 128 + 4 * q) * 4;
+        unsigned wcd = lds0 + (p * CD + 4 * q) * 4, wq = lds0 + q * 16;
+        unsigned dep = lds0 + RING_BYTES + (wave * SLOT + (p >> 2) * 64 + (p & 3) + 16 * q) * 4;
+        unsigned fb[4];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
+        opaque(w32); opaque(w96); opaque(w128); opaque(wcd); opaque(wq); opaque(dep);
+
+        // ---- recompute the forward chain (weights of layer i from ring buffer i&1, next chunk in flight)
         const float pc = q == 0 ? (float)G.pw[0] : (q == 1 ? (float)G.pw[1] : (q == 2 ? (float)G.pw[2] : 0.f));
         const Vox v = make_vox(G.pw, A.sc.lo, A.sc.hi, grid);
-        f32x4 c[1][CT];
-        gather8(v, grid, q, c[0][0], c[0][1]);
+        f32x4 c[CT];
+        gather8(v, grid, q, c[0], c[1]);
         if constexpr (CT == 4) {
             const Vox vm = make_vox(G.pw, A.sc.lo, A.sc.hi, A.sc.grid[1]);
-            gather8(vm, A.sc.grid[1], q, c[0][2], c[0][3]);
+            gather8(vm, A.sc.grid[1], q, c[2], c[3]);
         }
-        f32x4 emb[1][6];
+        STAMP(1)        // voxel setup + gather
+        f32x4 emb[6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             const float a = pk[L.oBT() + (16 * t + p) * 4 + q];
             const f32x4 arg = MFMA16(a, pc, splat4(0.f));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) emb[0][t][r] = ens_sinf(arg[r]);
+            for (int r = 0; r < 4; ++r) emb[t][r] = ens_sinf(arg[r]);
         }
-        f32x4 h[5][1][2];
+        STAMP(2)        // embedding
+        f32x4 h[5][2];
         unsigned mbits[5];
         auto fwd_layer = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            f32x4 acc[1][2];
-            acc[0][0] = ld4(pk + L.ob(i) + 4 * q);
-            acc[0][1] = ld4(pk + L.ob(i) + 16 + 4 * q);
+            constexpr int RO = (i & 1) ? RB * 4 : 0;                 // byte offset of this layer's ring buffer
+            constexpr int K = L.K(i);
+            constexpr int OB = RO + 32 * K * 4, OC = OB + 32 * 4, OBC = OC + 32 * CD * 4;
+            prefetch(IC(i + 1));
+            f32x4 acc[2];
+            acc[0] = lds4(wq + OB);
+            acc[1] = lds4(wq + OB + 64);
             if constexpr (i == 0) {
-                linear32<6, 1, 6>(acc, pk + L.oW(0), 96, emb, 0, p, q);
+                lin_lds<2, 6, 96, RO>(acc, w96, emb);
             } else if constexpr (i == 3) {
-                linear32<6, 1, 6>(acc, pk + L.oW(3), 128, emb, 0, p, q);
-                linear32<2, 1, 2>(acc, pk + L.oW(3) + 96, 128, h[2], 0, p, q);
+                lin_lds<2, 6, 128, RO>(acc, w128, emb);
+                lin_lds<2, 2, 128, RO + 96 * 4>(acc, w128, h[2]);
             } else {
-                linear32<2, 1, 2>(acc, pk + L.oW(i), 32, h[i - 1], 0, p, q);
+                lin_lds<2, 2, 32, RO>(acc, w32, h[i - 1]);
             }
-            mbits[i] = pos_bits(acc[0][0]) | (pos_bits(acc[0][1]) << 4);
-            acc[0][0] = relu4(acc[0][0]) + ld4(pk + L.obc(i) + 4 * q);
-            acc[0][1] = relu4(acc[0][1]) + ld4(pk + L.obc(i) + 16 + 4 * q);
-            linear32<CT, 1, CT>(acc, pk + L.oWc(i), CT * 16, c, 0, p, q);
-            h[i][0][0] = acc[0][0];
-            h[i][0][1] = acc[0][1];
-            __builtin_amdgcn_sched_barrier(0);
+            mbits[i] = pos_bits(acc[0]) | (pos_bits(acc[1]) << 4);
+            acc[0] = relu4(acc[0]) + lds4(wq + OBC);
+            acc[1] = relu4(acc[1]) + lds4(wq + OBC + 64);
+            lin_lds<2, CT, CD, OC>(acc, wcd, c);
+            h[i][0] = acc[0];
+            h[i][1] = acc[1];
+            if constexpr (i == 4) {
+                if (want_w) {       // dW operands that exist now: park them in LDS, free the registers
+                    dep_tile<SL::EMB + 0>(dep, emb[0]); dep_tile<SL::EMB + 1>(dep, emb[1]); dep_tile<SL::EMB + 2>(dep, emb[2]);
+                    dep_tile<SL::EMB + 3>(dep, emb[3]); dep_tile<SL::EMB + 4>(dep, emb[4]); dep_tile<SL::EMB + 5>(dep, emb[5]);
+                    dep_tile<SL::C + 0>(dep, c[0]); dep_tile<SL::C + 1>(dep, c[1]);
+                    if constexpr (CT == 4) { dep_tile<SL::C + 2>(dep, c[2]); dep_tile<SL::C + 3>(dep, c[3]); }
+                    dep_tile<SL::HX0>(dep, h[0][0]); dep_tile<SL::HX0 + 1>(dep, h[0][1]);
+                    dep_tile<SL::HX1>(dep, h[1][0]); dep_tile<SL::HX1 + 1>(dep, h[1][1]);
+                    dep_tile<SL::HX2>(dep, h[2][0]); dep_tile<SL::HX2 + 1>(dep, h[2][1]);
+                    dep_tile<SL::HX3>(dep, h[3][0]); dep_tile<SL::HX3 + 1>(dep, h[3][1]);
+                }
+            }
+            __syncthreads();            // next chunk has landed; everybody is done with this buffer
         };
         fwd_layer(IC(0)); fwd_layer(IC(1)); fwd_layer(IC(2)); fwd_layer(IC(3)); fwd_layer(IC(4));
+        STAMP(3)        // forward chain
 
-        // ---- backward chain
+        // ---- output layer: dWo, dbo on the VALU (n_out <= 4 rows: not worth an MFMA tile); dh4 = Wo^T d_out
         if (want_w) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) deposit(my, SL::EMB + t, emb[0][t], p, q);
+            for (int j = 0; j < NE; ++j) {
 #pragma unroll
-            for (int t = 0; t < CT; ++t) deposit(my, SL::C + t, c[0][t], p, q);
-            deposit(my, SL::Q, dout, p, q);
-            // hidden activations are only needed as dW operands: park them in LDS now, free the registers
-            deposit(my, SL::HX0, h[0][0][0], p, q); deposit(my, SL::HX0 + 1, h[0][0][1], p, q);
-            deposit(my, SL::HX1, h[1][0][0], p, q); deposit(my, SL::HX1 + 1, h[1][0][1], p, q);
-            deposit(my, SL::HX2, h[2][0][0], p, q); deposit(my, SL::HX2 + 1, h[2][0][1], p, q);
-            deposit(my, SL::HX3, h[3][0][0], p, q); deposit(my, SL::HX3 + 1, h[3][0][1], p, q);
-            deposit(my, SL::HX4, h[4][0][0], p, q); deposit(my, SL::HX4 + 1, h[4][0][1], p, q);
-            __syncthreads();
-            own_outer<1>(aWo, smem, SLOT, SL::Q, SL::HX4, 2, 2, wave, lane);           // dWo: waves 0,1
-            if (wave == 2) own_bias(aBo, smem, SLOT, SL::Q, lane);                       // dbo
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) aWo[j][4 * t + r] = fmaf(dj[j], h[4][t][r], aWo[j][4 * t + r]);
+                }
+                if (q == 0) aBo[j] += dj[j];
+            }
         }
         f32x4 dh[2] = {splat4(0.f), splat4(0.f)};
-        {   // dh4 = Wo^T d_out (K = 4: one step per row tile; k-slot q carries output q)
+        {   // K = 4: one MFMA step per row tile; k-slot q carries output q
             const float dq = NOUT == 4 ? (q == 0 ? draw[0] : (q == 1 ? draw[1] : (q == 2 ? draw[2] : 0.f)))
                                        : (q == 0 ? draw[3] : 0.f);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) dh[rt] = MFMA16(pk[L.oWoT() + (16 * rt + p) * 4 + q], dq, dh[rt]);
         }
         f32x4 dc[2] = {splat4(0.f), splat4(0.f)};
-        f32x4 demb[6];
+        f32x4 demb[6], dpre3[2] = {splat4(0.f), splat4(0.f)};
 #pragma unroll
         for (int t = 0; t < 6; ++t) demb[t] = splat4(0.f);
         auto bwd_layer = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
+            constexpr int cidx = 9 - i;
+            constexpr int RO = (cidx & 1) ? RB * 4 : 0;              // W_i^T [K][32] | Wc_i^T [32][32]
+            constexpr int OCT = RO + 32 * L.K(i) * 4;
             constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
             constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);      // input h_{i-1} of layers 4, 2, 1
             f32x4 dpre[2] = {mask4(dh[0], mbits[i], 0), mask4(dh[1], mbits[i], 4)};
             if (want_w) {
-                deposit(my, TH, dh[0], p, q); deposit(my, TH + 1, dh[1], p, q);
-                deposit(my, TP, dpre[0], p, q); deposit(my, TP + 1, dpre[1], p, q);
-                __syncthreads();
-                own_outer<CT / 2>(aWc[i], smem, SLOT, TH, SL::C, CT, 2 * CT, wave, lane);          // dWc_i
-                if constexpr (i == 0) {
-                    own_outer<3>(reinterpret_cast<f32x4(&)[3]>(aW[0]), smem, SLOT, TP, SL::EMB, 6, 12, wave, lane);
-                } else if constexpr (i == 3) {
-                    own_outer<4>(aW[3], smem, SLOT, TP, SL::EMB, 8, 16, wave, lane);             // [emb | h2] contiguous
-                } else {
-                    own_outer<1>(reinterpret_cast<f32x4(&)[1]>(aW[i]), smem, SLOT, TP, TX, 2, 4, wave, lane);
-                }
-                own_bias(aB[i], smem, SLOT, (wave < 2 ? TP : TH) + (wave & 1), lane);            // db_i | dbc_i
+                dep_tile<TH>(dep, dh[0]); dep_tile<TH + 1>(dep, dh[1]);
+                dep_tile<TP>(dep, dpre[0]); dep_tile<TP + 1>(dep, dpre[1]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (want_c) linear_n<2, 2>(dc, pk + L.oWcT(i), 32, dh, p, q);                 // dC += Wc_i^T dh_i
+            STAMP(6)    // layer deposits (+ tail of previous dX)
+            __syncthreads();            // deposits visible; this layer's W^T chunk has landed
+            STAMP(5)    // barrier wait
+            prefetch(IC(cidx + 1));
+            if (want_w) {
+                own_outer_a<CT / 2>(aWc[i], fb, TH, SL::C, CT, 2 * CT, wave);                     // dWc_i
+                if constexpr (i == 0) {
+                    own_outer_a<3>(aW0, fb, TP, SL::EMB, 6, 12, wave);
+                } else if constexpr (i == 3) {
+                    own_outer_a<4>(aW3, fb, TP, SL::EMB, 8, 16, wave);                           // [emb | h2] contiguous
+                } else if constexpr (i == 1) {
+                    own_outer_a<1>(aW1, fb, TP, TX, 2, 4, wave);
+                } else if constexpr (i == 2) {
+                    own_outer_a<1>(aW2, fb, TP, TX, 2, 4, wave);
+                } else {
+                    own_outer_a<1>(aW4, fb, TP, TX, 2, 4, wave);
+                }
+                own_bias_a(aB[i], fb, (wave < 2 ? TP : TH) + (wave & 1));                        // db_i | dbc_i
+                STAMP(7)    // owned dW MFMAs
+            }
+            if (want_c) lin_lds<2, 2, 32, OCT>(dc, w32, dh);                              // dC += Wc_i^T dh_i
             if constexpr (i == 0) {
-                if (want_r || want_w) {
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) demb[t] = *reinterpret_cast<const f32x4*>(my + SL::STASH * 256 + t * 256 + lane * 4);
-                    linear_n<6, 2>(demb, pk + L.oWT(0), 32, dpre, p, q);
-                }
+                if (want_r || want_w) lin_lds<6, 2, 32, RO>(demb, w32, dpre);
             } else if constexpr (i == 3) {
-                if (want_r || want_w) {
-                    f32x4 de[6];
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) de[t] = splat4(0.f);
-                    linear_n<6, 2>(de, pk + L.oWT(3), 32, dpre, p, q);
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) *reinterpret_cast<f32x4*>(my + SL::STASH * 256 + t * 256 + lane * 4) = de[t];
-                }
+                dpre3[0] = dpre[0]; dpre3[1] = dpre[1];              // its embedding part is applied in the tail
                 dh[0] = dh[1] = splat4(0.f);
-                linear_n<2, 2>(dh, pk + L.oWT(3) + 96 * 32, 32, dpre, p, q);
+                lin_lds<2, 2, 32, RO + 96 * 32 * 4>(dh, w32, dpre);
             } else {
                 dh[0] = dh[1] = splat4(0.f);
-                linear_n<2, 2>(dh, pk + L.oWT(i), 32, dpre, p, q);
+                lin_lds<2, 2, 32, RO>(dh, w32, dpre);
             }
-            __builtin_amdgcn_sched_barrier(0);
         };
         bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
-        // ---- embedding: d_arg = d_emb * cos(arg);  dB^T += d_arg (x) p ;  dp += B d_arg
+        STAMP(8)        // dX chain of the last layer
+        // ---- embedding: d_emb += W3^T[:96] dpre3;  d_arg = d_emb * cos(arg);  dB^T += d_arg (x) p ;  dp += B d_arg
         float dpx = 0.f, dpy = 0.f, dpz = 0.f;
         if (want_r || want_w) {
+            linear_n<6, 2>(demb, pk + L.oWT(3), 32, dpre3, p, q);
 #pragma unroll
             for (int t = 0; t < 6; ++t) {                               // cos(arg) recomputed: cheaper than carrying it
                 const f32x4 arg = MFMA16(pk[L.oBT() + (16 * t + p) * 4 + q], pc, splat4(0.f));
@@ -460,14 +633,14 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
                 }
             }
             if (want_w) {
-                __syncthreads();                                     // every wave is done reading EMB / Q
-#pragma unroll
-                for (int t = 0; t < 6; ++t) deposit(my, SL::EMB + t, demb[t], p, q);
+                __syncthreads();                                     // every wave is done reading EMB
+                dep_tile<SL::EMB + 0>(dep, demb[0]); dep_tile<SL::EMB + 1>(dep, demb[1]); dep_tile<SL::EMB + 2>(dep, demb[2]);
+                dep_tile<SL::EMB + 3>(dep, demb[3]); dep_tile<SL::EMB + 4>(dep, demb[4]); dep_tile<SL::EMB + 5>(dep, demb[5]);
                 f32x4 pt4 = splat4(0.f);
                 if (q == 0) pt4 = f32x4{(float)G.pw[0], (float)G.pw[1], (float)G.pw[2], 0.f};
-                deposit(my, SL::Q, pt4, p, q);
+                dep_tile<SL::Q>(dep, pt4);
                 __syncthreads();
-                own_outer<2>(aBT, smem, SLOT, SL::EMB, SL::Q, 1, 6, wave, lane);                  // dB^T
+                own_outer_a<2>(aBT, fb, SL::EMB, SL::Q, 1, 6, wave);                              // dB^T
             }
             if (want_r) {
                 f32x4 dpe[1] = {splat4(0.f)};
@@ -475,6 +648,7 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
                 dpx = dpe[0][0]; dpy = dpe[0][1]; dpz = dpe[0][2];      // valid on q == 0 lanes
             }
         }
+        STAMP(9)        // embedding tail (cos recompute, dB^T, dp)
         // ---- grid: coordinate gradient and feature-gradient scatter
         if (want_c) {
             if (want_r) {
@@ -486,9 +660,9 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
                 dpx += gx * v.gx; dpy += gy * v.gy; dpz += gz * v.gz;
             }
             if (want_g && tvalid) {
-                // stage dC as [sample][32 channels] in this wave's H0 tiles: all reads of H0/H1 by other waves
-                // are behind a barrier already (want_w) or never happen (!want_w)
-                float* stg = my + SL::H0 * 256;
+                // stage dC as [sample][32 channels] in this wave's H1 tiles (layer 1 was their last reader, two
+                // barriers ago; the next writer is the next round's layer 3, behind further barriers)
+                float* stg = slots + wave * SLOT + SL::H1 * 256;
                 *reinterpret_cast<f32x4*>(stg + p * 32 + 4 * q) = dc[0];
                 *reinterpret_cast<f32x4*>(stg + p * 32 + 16 + 4 * q) = dc[1];
                 wave_lds_fence();
@@ -500,11 +674,13 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
             if (q != 0) { dpx = dpy = dpz = 0.f; }
             add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
         }
+        STAMP(10)       // coordinate gradient + scatter + ray grads
     }
+    STAMP_FLUSH
 
     // ---- flush: stage the owned tiles into a packed-layout LDS image, then coalesced global atomics
     if (want_w) {
-        float* sacc = smem;
+        float* sacc = slots;
         __syncthreads();
         for (int e = threadIdx.x; e < GF; e += 256) sacc[e] = 0.f;
         __syncthreads();
@@ -512,22 +688,31 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
         for (int i = 0; i < 5; ++i) {
 #pragma unroll
             for (int j = 0; j < CT / 2; ++j) stage_tile(sacc + L.oWc(i), CT * 16, 0, CT, wave + 4 * j, aWc[i][j], 32, CT * 16, p, q);
-            if (i == 0) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) stage_tile(sacc + L.oW(0), 96, 0, 6, wave + 4 * j, aW[0][j], 32, 96, p, q);
-            } else if (i == 3) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) stage_tile(sacc + L.oW(3), 128, 0, 8, wave + 4 * j, aW[3][j], 32, 128, p, q);
-            } else {
-                stage_tile(sacc + L.oW(i), 32, 0, 2, wave, aW[i][0], 32, 32, p, q);
-            }
             stage_bias(sacc + (wave < 2 ? L.ob(i) : L.obc(i)), wave & 1, aB[i], 32, p, q);
         }
-        if (wave < 2) stage_tile(sacc + L.oWo(), 32, 0, 2, wave, aWo[0], NOUT, 32, p, q);
-        if (wave == 2) stage_bias(sacc + L.obo(), 0, aBo, NOUT, p, q);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) stage_tile(sacc + L.oW(0), 96, 0, 6, wave + 4 * j, aW0[j], 32, 96, p, q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_tile(sacc + L.oW(3), 128, 0, 8, wave + 4 * j, aW3[j], 32, 128, p, q);
+        stage_tile(sacc + L.oW(1), 32, 0, 2, wave, aW1[0], 32, 32, p, q);
+        stage_tile(sacc + L.oW(2), 32, 0, 2, wave, aW2[0], 32, 32, p, q);
+        stage_tile(sacc + L.oW(4), 32, 0, 2, wave, aW4[0], 32, 32, p, q);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             if (wave + 4 * j < 6) stage_tile(sacc + L.oBT(), 4, 0, 1, wave + 4 * j, aBT[j], 93, 3, p, q);
+        // output layer: per-lane partial sums -> reduce over the 16 sample lanes; the 4 waves add in LDS
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                float a = aWo[j][f];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                if (p == 0) lds_add(sacc + L.oWo() + j * 32 + 16 * (f >> 2) + 4 * q + (f & 3), a);
+            }
+            float bsum = wave_sum(aBo[j]);
+            if (lane == 0) lds_add(sacc + L.obo() + j, bsum);
+        }
         __syncthreads();
         for (int e = threadIdx.x; e < GF; e += 256) {
             const float vsum = sacc[e];
@@ -629,11 +814,11 @@ ENS_DEV void feat_role(const BwdArgs& A, int wg, int n_wg, float* smem) {
                 }
                 __syncthreads();
                 if constexpr (i == 0) {
-                    own_outer<1>(reinterpret_cast<f32x4(&)[1]>(aW[0]), smem, SLOT, TP, SL::C, 2, 4, wave, lane);
+                    own_outer_1(aW[0][0], smem, SLOT, TP, SL::C, 2, 4, wave, lane);
                 } else if constexpr (i == 3) {
                     own_outer<2>(aW[3], smem, SLOT, TP, SL::C, 4, 8, wave, lane);                  // [c | h2] contiguous
                 } else {
-                    own_outer<1>(reinterpret_cast<f32x4(&)[1]>(aW[i]), smem, SLOT, TP, TX, 2, 4, wave, lane);
+                    own_outer_1(aW[i][0], smem, SLOT, TP, TX, 2, 4, wave, lane);
                 }
                 if (wave < 2) own_bias(aB[i], smem, SLOT, TP + wave, lane);
             }
@@ -711,9 +896,8 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(BwdArgs A) {
     }
 }
 
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // deposit slots of the 4 waves; the packed-layout flush image aliases them at the end of the kernel
-constexpr int lds_bytes_xyz(int ct) { return cmax(XyzLay{ct * 16}.fwd_floats(), 4 * (31 + ct) * 256) * 4; }
+constexpr int lds_bytes_xyz(int ct) { return (cmax(XyzLay{ct * 16}.fwd_floats(), 4 * (23 + ct) * 256) + 2 * ring_floats(ct)) * 4; }
 constexpr int lds_bytes_feat() { return cmax(FeatLay{}.fwd_floats(), 4 * 11 * 256) * 4; }
 
 int device_cus() {
@@ -728,6 +912,13 @@ int device_cus() {
 }
 
 }  // namespace
+
+#ifdef ENS_STAMPS
+extern "C" int enslam_debug_set_stamp_buffer(void* p) {
+    unsigned long long* v = (unsigned long long*)p;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &v, sizeof(v)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* z, const double* depth,
                              const double* g_depth, const double* g_var, const float* g_rgb, float* d_raw,

@@ -113,25 +113,31 @@ ENS_DEV float to_sample_lane(const f32x4 (&o)[NTL], int comp, int lane) {
     return r;
 }
 
+// MODE 0: one wave per ray (S = 16*NTL samples), compositing fused.
+// MODE 1: explicit points (eval_points), 16*NTL points per wave, raw only.
+// MODE 2: one wave per 16-sample tile of a ray (NTL == 1, tiles_per_ray > 0): raw only; compositing runs as its
+//         own kernel.  3x the waves of MODE 0 at less than half the registers: latency is hidden by occupancy.
 template <int STAGE, int NTL>
 __global__ __launch_bounds__(64) void render_fwd_kernel(int64_t n_units, const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const double* __restrict__ z_vals,
                                                         const double* __restrict__ points, int64_t n_points,
-                                                        int apply_mask, DevScene sc, double* __restrict__ depth,
+                                                        int apply_mask, int tiles_per_ray, DevScene sc, double* __restrict__ depth,
                                                         double* __restrict__ var, float* __restrict__ rgb,
                                                         float* __restrict__ raw_out) {
     constexpr int S = 16 * NTL;
     const int lane = threadIdx.x, p = lane & 15, q = lane >> 4;
+    const bool tile_mode = tiles_per_ray > 0;
     const int64_t unit = blockIdx.x;
-    const bool ray_mode = (points == nullptr);
+    const bool ray_mode = (points == nullptr) && !tile_mode;
+    const int64_t ray = tile_mode ? unit / tiles_per_ray : unit;           // wave-uniform
 
     double pw[NTL][3];
     float pc[NTL];
-    if (ray_mode) {
+    if (points == nullptr) {
         double o[3], d[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { o[a] = (double)rays_o[unit * 3 + a]; d[a] = (double)rays_d[unit * 3 + a]; }
+        for (int a = 0; a < 3; ++a) { o[a] = (double)rays_o[ray * 3 + a]; d[a] = (double)rays_d[ray * 3 + a]; }
 #pragma unroll
         for (int tl = 0; tl < NTL; ++tl) {
             const double z = z_vals[unit * S + 16 * tl + p];
@@ -207,10 +213,10 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(int64_t n_units, const f
     double zk = 0.0;
     {   // strict in-bound test of this lane's own sample (Renderer.py:44-47); outside -> occ = 100 (:58)
         double pk3[3] = {0.0, 0.0, 0.0};
-        if (ray_mode) {
+        if (points == nullptr) {
             zk = valid ? z_vals[sidx] : 0.0;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) pk3[a] = (double)rays_o[unit * 3 + a] + (double)rays_d[unit * 3 + a] * zk;
+            for (int a = 0; a < 3; ++a) pk3[a] = (double)rays_o[ray * 3 + a] + (double)rays_d[ray * 3 + a] * zk;
         } else {
             const int64_t i = sidx < n_points ? sidx : n_points - 1;
 #pragma unroll
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(int64_t n_units, const f
         for (int a = 0; a < 3; ++a) in = in && (pk3[a] < sc.hi[a]) && (pk3[a] > sc.lo[a]);
         if (!in && apply_mask) occ_k = 100.f;
     }
-    if (raw_out != nullptr && valid && (ray_mode || sidx < n_points))
+    if (raw_out != nullptr && valid && (points == nullptr || sidx < n_points))
         *reinterpret_cast<f32x4*>(raw_out + sidx * 4) = f32x4{r_k, g_k, b_k, occ_k};
     if (!ray_mode) return;
 
@@ -287,14 +293,14 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(int S, const float* _
 
 template <int STAGE>
 int launch_stage(int ntl, int64_t n_units, const float* ro, const float* rd, const double* z, const double* pts,
-                 int64_t n_points, int apply_mask, const DevScene& sc, double* depth, double* var, float* rgb, float* raw,
+                 int64_t n_points, int apply_mask, int tpr, const DevScene& sc, double* depth, double* var, float* rgb, float* raw,
                  hipStream_t st) {
     if (n_units <= 0) return 0;
     const dim3 grid((unsigned)n_units), block(64);
     switch (ntl) {
-        case 1: render_fwd_kernel<STAGE, 1><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw); break;
-        case 2: render_fwd_kernel<STAGE, 2><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw); break;
-        case 3: render_fwd_kernel<STAGE, 3><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw); break;
+        case 1: render_fwd_kernel<STAGE, 1><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw); break;
+        case 2: render_fwd_kernel<STAGE, 2><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw); break;
+        case 3: render_fwd_kernel<STAGE, 3><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -312,11 +318,22 @@ int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* 
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
                           double* var, float* rgb, float* raw, hipStream_t st) {
+    // Ray mode with raw requested and a moderate ray count: tile-per-wave decoders + separate compositing (more
+    // waves in flight).  Large batches (full-image renders) already fill the chip with one wave per ray.
+    int tpr = 0;
+    if (pts == nullptr && raw != nullptr && n_units <= 32768) {
+        tpr = ntl;
+        n_units *= ntl;
+        ntl = 1;
+    }
+    int rc;
     switch (stage) {
-        case 0: return launch_stage<0>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw, st);
-        case 1: return launch_stage<1>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw, st);
-        case 2: return launch_stage<2>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw, st);
-        case 3: return launch_stage<3>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, sc, depth, var, rgb, raw, st);
+        case 0: rc = launch_stage<0>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, st); break;
+        case 1: rc = launch_stage<1>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, st); break;
+        case 2: rc = launch_stage<2>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, st); break;
+        case 3: rc = launch_stage<3>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, st); break;
         default: return -1;
     }
+    if (rc != 0 || tpr == 0) return rc;
+    return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st);
 }

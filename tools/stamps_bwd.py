@@ -1,0 +1,35 @@
+"""Run the stamps build of the backward kernel and print the share of wave cycles per segment, per role."""
+import ctypes, os, sys, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, bench
+import evennicer_slam_amd as E
+import evennicer_slam_amd.functional as EF
+NSEG = 12
+names = ["geom+d_raw+vote", "vox+gather", "embedding", "fwd chain", "deposits(fwd)", "barrier waits", "layer deposits(+prev dX)",
+         "owned dW MFMAs", "tail dX", "emb tail", "coord+scatter+rays", "-"]
+dev = torch.device('cuda', 0)
+lib = E._lib.lib()
+sc = bench.build_scene_cpu('room0', 0)
+rays = bench.make_rays(sc, 1000, 1000)
+model = sc['model'].to(dev); bench.attach_bounds(model, sc['bound'])
+grids = {k: v.to(dev).requires_grad_(True) for k, v in sc['grids'].items()}
+ro, rd, gd, gc = [t.to(dev) for t in rays]
+ro.requires_grad_(True); rd.requires_grad_(True)
+renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **bench.CAM))
+buf = torch.zeros(256 * 4 * NSEG, dtype=torch.int64, device=dev)
+handle = ctypes.CDLL(E.LIB_PATH)
+assert handle.enslam_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
+for i in range(5):
+    buf.zero_()
+    d, v, c = renderer.render_batch_ray(grids, model, rd, ro, dev, 'color', gt_depth=gd)
+    bench.mapper_loss(d, c, gd, gc, 'color').backward()
+torch.cuda.synchronize()
+st = buf.cpu().numpy().reshape(256, 4, NSEG).astype(np.float64)
+# role ranges as in ens_launch_decoder_bwd: 0.30 / 0.40 / 0.30 of 256 workgroups
+r0 = int(256 * 0.30 + 0.5); r1 = r0 + int(256 * 0.40 + 0.5)
+for name, sl in (("middle", slice(0, r0)), ("fine", slice(r0, r1)), ("color", slice(r1, 256))):
+    s = st[sl].reshape(-1, NSEG)
+    tot = s.sum(1)
+    print(f"role {name}: waves {s.shape[0]}, cycles per wave mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f}) = {tot.mean()/2.4e3:.0f} us @2.4GHz")
+    for k in range(NSEG - 1):
+        print(f"    {names[k]:28s} {s[:, k].mean():10.0f} cycles  {100 * s[:, k].mean() / tot.mean():5.1f} %")
