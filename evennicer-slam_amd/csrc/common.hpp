@@ -141,33 +141,48 @@ ENS_DEV void corner(const Vox& v, const DevGrid& g, int k, int64_t& idx, float& 
 ENS_DEV void gather8(const Vox& v, const DevGrid& g, int q, f32x4& c0, f32x4& c1) {
     c0 = splat4(0.f);
     c1 = splat4(0.f);
+    f32x4 a[8], b[8];
+    float w[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        int64_t idx; float w;
-        corner(v, g, k, idx, w);
+    for (int k = 0; k < 8; ++k) {                      // all 16 loads in flight before the first use
+        int64_t idx;
+        corner(v, g, k, idx, w[k]);
         const float* src = g.data + idx * 32 + 4 * q;
-        const f32x4 a = ld4(src), b = ld4(src + 16);
+        a[k] = ld4(src);
+        b[k] = ld4(src + 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { c0[r] = fmaf(a[r], w, c0[r]); c1[r] = fmaf(b[r], w, c1[r]); }
+    for (int k = 0; k < 8; ++k) {                      // ATen corner order tnw, tne, tsw, tse, bnw, bne, bsw, bse
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { c0[r] = fmaf(a[k][r], w[k], c0[r]); c1[r] = fmaf(b[k][r], w[k], c1[r]); }
     }
 }
 
 // ----------------------------------------------------------------------------------------------
 // MFMA building blocks
 // ----------------------------------------------------------------------------------------------
-// acc[tl][rt] += W[32 x 16*KT] (row-major, leading dim ld) * x[tl][0..KT)   for NTL point tiles
+// acc[tl][rt] += W[32 x 16*KT] (row-major, leading dim ld) * x[tl][0..KT)   for NTL point tiles.
+// All weight-fragment loads of the call are issued first (independent, distinct registers) and pinned there;
+// the MFMAs then alternate accumulators so that consecutive issues never wait on their own result.
 template <int KT, int NTL, int XS>
 ENS_DEV void linear32(f32x4 (&acc)[NTL][2], const float* __restrict__ W, int ld, const f32x4 (&x)[NTL][XS], int xoff,
                       int p, int q) {
+    f32x4 a[KT][2];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const f32x4 a = ldw(W, (16 * rt + p) * ld + 16 * t + 4 * q);
+        for (int rt = 0; rt < 2; ++rt) a[t][rt] = ldw(W, (16 * rt + p) * ld + 16 * t + 4 * q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+    for (int t = 0; t < KT; ++t) {
 #pragma unroll
-                for (int tl = 0; tl < NTL; ++tl) acc[tl][rt] = MFMA16(a[r], x[tl][xoff + t][r], acc[tl][rt]);
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                for (int tl = 0; tl < NTL; ++tl) acc[tl][rt] = MFMA16(a[t][rt][r], x[tl][xoff + t][r], acc[tl][rt]);
             }
         }
     }
@@ -178,16 +193,18 @@ template <int NTL>
 ENS_DEV void out_layer(f32x4 (&o)[NTL], const float* __restrict__ Wo, const float* __restrict__ bo,
                        const f32x4 (&h)[NTL][2], int p, int q) {
     const f32x4 b = ld4(bo + 4 * q);
+    const f32x4 a0 = ld4(Wo + p * 32 + 4 * q), a1 = ld4(Wo + p * 32 + 16 + 4 * q);
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) o[tl] = b;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const f32x4 a = ld4(Wo + p * 32 + 16 * t + 4 * q);
+    for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int tl = 0; tl < NTL; ++tl) o[tl] = MFMA16(a0[r], h[tl][0][r], o[tl]);
+    }
 #pragma unroll
-            for (int tl = 0; tl < NTL; ++tl) o[tl] = MFMA16(a[r], h[tl][t][r], o[tl]);
-        }
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) o[tl] = MFMA16(a1[r], h[tl][1][r], o[tl]);
     }
 }
 
