@@ -101,8 +101,9 @@ def image_rays(H, W, new_H, new_W, c2w, fx, fy, cx, cy):
 
 # ----------------------------------------------------------------------------- sampling
 def sample_depths(rays_o, rays_d, gt_depth, bound, n_samples, n_surface, stage,
-                  lindisp=False, t_rand=None):
-    """Sorted sample distances z [N, S] float64.  S = n_samples (+ n_surface if depth-guided)."""
+                  lindisp=False, t_rand=None, depth_max=None):
+    """Sorted sample distances z [N, S] float64.  S = n_samples (+ n_surface if depth-guided).
+    depth_max: optional 0-dim float32 tensor replacing max(gt_depth) (ray-sharded callers pass the batch's)."""
     if stage == 'coarse':
         gt_depth = None
     with torch.no_grad():
@@ -117,7 +118,8 @@ def sample_depths(rays_o, rays_d, gt_depth, bound, n_samples, n_surface, stage,
     else:
         gd = gt_depth.reshape(-1, 1)
         near = gd.repeat(1, n_samples) * 0.01                  # float32
-        far = torch.clamp(far_bb, 0, torch.max(gd * 1.2))      # batch-global max
+        dmax = torch.max(gd) if depth_max is None else depth_max.to(gd.dtype)
+        far = torch.clamp(far_bb, 0, dmax * 1.2)               # batch-global max (max(gd*1.2) == max(gd)*1.2 in float32)
     if lindisp:
         z = 1. / (1. / near * (1. - t_lin) + 1. / far * t_lin)
     else:
@@ -133,7 +135,7 @@ def sample_depths(rays_o, rays_d, gt_depth, bound, n_samples, n_surface, stage,
         zs = torch.zeros(gd.shape[0], n_surface, dtype=torch.float64)
         dh = gd[hit].reshape(-1, 1).repeat(1, n_surface)
         zs[hit] = 0.95 * dh * (1. - t_s) + 1.05 * dh * t_s
-        zs[~hit] = 0.001 * (1. - t_s) + torch.max(gd) * t_s
+        zs[~hit] = 0.001 * (1. - t_s) + dmax * t_s
         z = torch.sort(torch.cat([z, zs], -1), -1)[0]
     return z
 
