@@ -40,6 +40,7 @@ _SIGS = {
     "enslam_packed_floats": (c_size_t, [ctypes.c_int]),
     "enslam_packed_grad_floats": (c_size_t, [ctypes.c_int]),
     "enslam_pack_mlp": (ctypes.c_int, [ctypes.c_int, POINTER(MlpParams), c_void_p, c_void_p]),
+    "enslam_pack_mlp_multi": (ctypes.c_int, [c_int32, POINTER(c_int32), POINTER(MlpParams), POINTER(c_void_p), c_void_p]),
     "enslam_unpack_mlp_grads": (ctypes.c_int, [ctypes.c_int, c_void_p, POINTER(MlpParams), c_void_p]),
     "enslam_unpack_mlp_grads_multi": (ctypes.c_int, [c_int32, POINTER(c_int32), POINTER(c_void_p), POINTER(MlpParams),
                                                      c_void_p]),

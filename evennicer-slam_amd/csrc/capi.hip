@@ -124,6 +124,23 @@ int enslam_pack_mlp(int kind, const enslam_mlp_params* params, float* packed, vo
     return ens_launch_pack(job, packed, false, (hipStream_t)stream);
 }
 
+int enslam_pack_mlp_multi(int32_t n, const int32_t* kinds, const enslam_mlp_params* params, float* const* packed,
+                          void* stream) {
+    if (n < 0 || n > 2) return ENSLAM_EINVAL;
+    if (n == 0) return ENSLAM_OK;
+    if (!kinds || !params || !packed) return ENSLAM_EINVAL;
+    PackJob job;
+    job.n = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!packed[i]) return ENSLAM_EINVAL;
+        g_seg_packed = packed[i];
+        const bool ok = build_job(kinds[i], params[i], true, job, true);
+        g_seg_packed = nullptr;
+        if (!ok) return ENSLAM_EINVAL;
+    }
+    return ens_launch_pack(job, nullptr, false, (hipStream_t)stream);
+}
+
 int enslam_unpack_mlp_grads(int kind, const float* packed_grad, const enslam_mlp_params* grads, void* stream) {
     if (grads == nullptr || packed_grad == nullptr) return ENSLAM_EINVAL;
     if (!is_xyz(kind) && kind != ENSLAM_MLP_COARSE) return ENSLAM_EINVAL;

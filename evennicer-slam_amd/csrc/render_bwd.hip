@@ -249,9 +249,23 @@ ENS_DEV void coord_grad_partial(const Vox& v, const DevGrid& g, int q, const f32
 }
 
 // Scatter the tile's feature gradient (deposited as [sample][32] floats in `dep`) into the voxel-major grid
-// gradient: per sample 4 wave instructions, each 2 x-adjacent corners x 32 channels = 256 contiguous bytes.
+// gradient: 4 wave instructions per flush, each 2 x-adjacent corners x 32 channels = 256 contiguous bytes.
+// Consecutive samples of a ray that fall into the same voxel (all 16 near-surface samples share 1-3 voxels)
+// are combined in registers first, so they cost one flush instead of one each.
 ENS_DEV void scatter_tile(const float* dep, const Vox& v, const DevGrid& gg, int lane) {
     const int ch = lane & 31, dxb = lane >> 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int cx = -1, cy = -1, cz = -1;
+    auto flush = [&]() {
+        const int x = cx + dxb;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = cy + (k & 1), z = cz + (k >> 1);
+            const bool ok = (x < gg.W) && (y < gg.H) && (z < gg.D);
+            if (ok && acc[k] != 0.f) atomicAdd(gg.data + (((int64_t)z * gg.H + y) * gg.W + x) * 32 + ch, acc[k]);
+            acc[k] = 0.f;
+        }
+    };
 #pragma unroll
     for (int pt = 0; pt < 16; ++pt) {
         const float val = dep[pt * 32 + ch];
@@ -261,17 +275,18 @@ ENS_DEV void scatter_tile(const float* dep, const Vox& v, const DevGrid& gg, int
         const float fx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.fx), pt));
         const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.fy), pt));
         const float fz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.fz), pt));
-        const int x = ix + dxb;
+        if (ix != cx || iy != cy || iz != cz) {          // scalar comparison: new voxel
+            if (cx >= 0) flush();
+            cx = ix; cy = iy; cz = iz;
+        }
         const float wx = dxb ? fx : (1.f - fx);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int dy = k & 1, dz = k >> 1;
-            const int y = iy + dy, z = iz + dz;
-            const bool ok = (x < gg.W) && (y < gg.H) && (z < gg.D);
-            const float w = (wx * (dy ? fy : (1.f - fy))) * (dz ? fz : (1.f - fz));
-            if (ok) atomicAdd(gg.data + (((int64_t)z * gg.H + y) * gg.W + x) * 32 + ch, w * val);
+            const float w = (wx * ((k & 1) ? fy : (1.f - fy))) * ((k >> 1) ? fz : (1.f - fz));
+            acc[k] = fmaf(w, val, acc[k]);
         }
     }
+    if (cx >= 0) flush();
 }
 
 // reduce the per-sample position gradient over the tile and add it to the ray gradients
@@ -330,6 +345,8 @@ ENS_DEV void ring_load(float* dst_lds, const float* __restrict__ src, int n4, in
                                              16, 0, 0);
     }
 }
+
+__shared__ int ens_vote[2][4];      // per-round activity flags of the 4 waves (double buffered by round parity)
 
 // ---- explicit LDS addressing -------------------------------------------------------------------
 // Every LDS access of the xyz role is  (one per-lane base VGPR) + (compile-time byte offset): the offset folds
@@ -463,6 +480,7 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
     STAMP_DECL
     STAMP_START
     prefetch(IC(0));
+    unsigned round_no = 0;
     for (int64_t base = (int64_t)wg * 4; base < n_tiles; base += stride) {
         const int64_t tile_raw = base + wave;
         const bool tvalid = tile_raw < n_tiles;
@@ -475,8 +493,16 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
         bool nz = false;
 #pragma unroll
         for (int j = 0; j < NE; ++j) nz = nz || dj[j] != 0.f;
-        // nothing flows into any of the 4 tiles: skip the round (the waves of a workgroup stay in lockstep)
-        if (!__syncthreads_or(__any(nz) ? 1 : 0)) continue;
+        // nothing flows into any of the 4 tiles: skip the round (the waves of a workgroup stay in lockstep).
+        // One barrier: each wave posts its flag in a word of the round's parity set.
+        {
+            const int par = (int)(round_no & 1);
+            if (lane == 0) ens_vote[par][wave] = __any(nz) ? 1 : 0;
+            ++round_no;
+            __syncthreads();
+            const int any4 = ens_vote[par][0] | ens_vote[par][1] | ens_vote[par][2] | ens_vote[par][3];
+            if (!any4) continue;
+        }
         STAMP(0)        // tile geometry + d_raw load + vote barrier
 
         // per-lane LDS bases of this round (opaque: see above)
@@ -569,7 +595,7 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
             for (int rt = 0; rt < 2; ++rt) dh[rt] = MFMA16(pk[L.oWoT() + (16 * rt + p) * 4 + q], dq, dh[rt]);
         }
         f32x4 dc[2] = {splat4(0.f), splat4(0.f)};
-        f32x4 demb[6], dpre3[2] = {splat4(0.f), splat4(0.f)};
+        f32x4 demb[6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) demb[t] = splat4(0.f);
         auto bwd_layer = [&](auto ic) {
@@ -608,7 +634,7 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
             if constexpr (i == 0) {
                 if (want_r || want_w) lin_lds<6, 2, 32, RO>(demb, w32, dpre);
             } else if constexpr (i == 3) {
-                dpre3[0] = dpre[0]; dpre3[1] = dpre[1];              // its embedding part is applied in the tail
+                if (want_r || want_w) lin_lds<6, 2, 32, RO>(demb, w32, dpre);       // rows 0..95 of W3^T: embedding part
                 dh[0] = dh[1] = splat4(0.f);
                 lin_lds<2, 2, 32, RO + 96 * 32 * 4>(dh, w32, dpre);
             } else {
@@ -618,10 +644,9 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
         };
         bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
         STAMP(8)        // dX chain of the last layer
-        // ---- embedding: d_emb += W3^T[:96] dpre3;  d_arg = d_emb * cos(arg);  dB^T += d_arg (x) p ;  dp += B d_arg
+        // ---- embedding: d_arg = d_emb * cos(arg);  dB^T += d_arg (x) p ;  dp += B d_arg
         float dpx = 0.f, dpy = 0.f, dpz = 0.f;
         if (want_r || want_w) {
-            linear_n<6, 2>(demb, pk + L.oWT(3), 32, dpre3, p, q);
 #pragma unroll
             for (int t = 0; t < 6; ++t) {                               // cos(arg) recomputed: cheaper than carrying it
                 const f32x4 arg = MFMA16(pk[L.oBT() + (16 * t + p) * 4 + q], pc, splat4(0.f));
@@ -943,7 +968,7 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         case 0: kinds[nk] = 0; cost[nk++] = 1.f; break;
         case 1: kinds[nk] = 1; cost[nk++] = 1.f; break;
         case 2: kinds[nk] = 1; cost[nk++] = 0.44f; kinds[nk] = 2; cost[nk++] = 0.56f; break;
-        case 3: kinds[nk] = 1; cost[nk++] = 0.30f; kinds[nk] = 2; cost[nk++] = 0.40f; kinds[nk] = 3; cost[nk++] = 0.30f; break;
+        case 3: kinds[nk] = 1; cost[nk++] = 0.315f; kinds[nk] = 2; cost[nk++] = 0.365f; kinds[nk] = 3; cost[nk++] = 0.32f; break;
         default: return -1;
     }
     for (int k = 0; k < 4; ++k) { A.ggrid[k] = DevGrid{nullptr, 0, 0, 0}; A.gpacked[k] = nullptr; }

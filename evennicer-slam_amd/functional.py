@@ -129,6 +129,41 @@ class _PackCache:
 _pack_caches = weakref.WeakKeyDictionary()      # decoder module -> _PackCache
 
 
+def packed_decoders(items):
+    """Packed forms of several decoders [(module, kind, params)]; stale ones are rebuilt with ONE zero-fill and
+    at most two launches (a launch re-lays-out up to two decoders)."""
+    out, stale = [], []
+    for i, (dec, kind, ps) in enumerate(items):
+        cache = _pack_caches.get(dec)
+        if cache is None:
+            cache = _pack_caches[dec] = _PackCache()
+        key = tuple((id(p), p.data_ptr(), p._version) for p in ps)
+        if key == cache.key:
+            out.append(cache.packed)
+        else:
+            out.append(None)
+            stale.append((i, cache, key))
+    if stale:
+        lib = L.lib()
+        sizes = [lib.enslam_packed_floats(items[i][1]) for i, _, _ in stale]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=items[stale[0][0]][2][0].device)
+        pieces = flat.split(sizes)
+        for j, (i, cache, key) in enumerate(stale):
+            _check_params(items[i][1], items[i][2])
+            cache.key, cache.packed = key, pieces[j]
+            out[i] = pieces[j]
+        for g0 in range(0, len(stale), 2):
+            grp = stale[g0:g0 + 2]
+            n = len(grp)
+            kinds, structs, ptrs = (ctypes.c_int32 * n)(), (L.MlpParams * n)(), (ctypes.c_void_p * n)()
+            for j, (i, cache, key) in enumerate(grp):
+                kinds[j] = items[i][1]
+                structs[j] = _fill_params_struct(items[i][1], items[i][2])
+                ptrs[j] = cache.packed.data_ptr()
+            L.check(lib.enslam_pack_mlp_multi(n, kinds, structs, ptrs, _stream()), "enslam_pack_mlp_multi")
+    return out
+
+
 def packed_decoder(dec, kind, params=None):
     cache = _pack_caches.get(dec)
     if cache is None:
@@ -269,12 +304,14 @@ class _RenderFn(torch.autograd.Function):
                                        _ptr(scratch), int(plan.depth_max is not None), _ptr(z), st),
                 "enslam_sample_rays")
         grids_vm, dims, packed = {}, {}, {}
-        po = nk
+        po, items = nk, []
         for k, g, vm in zip(plan.kinds, grids, _grid_cache.get_many(grids)):
             grids_vm[k] = vm
             dims[k] = tuple(g.shape[2:])
-            packed[k] = packed_decoder(plan.decoders[k], k, tensors[po:po + plan.n_params[k]])
+            items.append((plan.decoders[k], k, tensors[po:po + plan.n_params[k]]))
             po += plan.n_params[k]
+        for k, pk in zip(plan.kinds, packed_decoders(items)):
+            packed[k] = pk
         sc = _scene_struct(plan.stage, plan.bound6, plan.coarse_bound6, grids_vm, dims, packed)
         depth = torch.empty(N, dtype=torch.float64, device=dev)
         var = torch.empty(N, dtype=torch.float64, device=dev)

@@ -90,6 +90,10 @@ size_t enslam_packed_grad_floats(int kind);
  * the backward).  `packed` must have been zero-filled once by the caller; padding is never written.
  * Replaces nothing in the reference (layout glue for decoder.py:149-159 parameters). */
 int enslam_pack_mlp(int kind, const enslam_mlp_params *params, float *packed, void *stream);
+/* The same for several decoders in ONE launch (host arrays of length n <= 2: the kernel argument holds at most
+ * 80 re-layout segments, 37 per xyz decoder). */
+int enslam_pack_mlp_multi(int32_t n, const int32_t *kinds, const enslam_mlp_params *params, float *const *packed,
+                          void *stream);
 
 /* Inverse for gradients: packed_grad (accumulated by enslam_render_bwd) -> tensors shaped like the
  * reference parameters.  Pointers in `grads` that are NULL are skipped. */

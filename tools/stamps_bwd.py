@@ -26,7 +26,7 @@ for i in range(5):
 torch.cuda.synchronize()
 st = buf.cpu().numpy().reshape(256, 4, NSEG).astype(np.float64)
 # role ranges as in ens_launch_decoder_bwd: 0.30 / 0.40 / 0.30 of 256 workgroups
-r0 = int(256 * 0.30 + 0.5); r1 = r0 + int(256 * 0.40 + 0.5)
+r0 = int(256 * 0.315 + 0.5); r1 = r0 + int(256 * 0.365 + 0.5)
 for name, sl in (("middle", slice(0, r0)), ("fine", slice(r0, r1)), ("color", slice(r1, 256))):
     s = st[sl].reshape(-1, NSEG)
     tot = s.sum(1)
