@@ -78,6 +78,18 @@ struct FeatLay {                // MLP_no_xyz (coarse): decoder.py:206-274
 };
 
 // ----------------------------------------------------------------------------------------------
+// Activation workspace written by the forward for the backward (one block per 16-sample tile and decoder slot):
+//   tiles in the backward's LDS "deposit" layout, in the order of its slot  [EMB 6 | h2 2 | h0 2 | h1 2 | h3 2 | C ct]
+//   (address of (tile T, feature i, sample pt) = T*256 + (pt>>2)*64 + i*4 + (pt&3) floats), then h4 in register
+//   layout (2 tiles, lane-linear) and the ReLU masks (2 words per lane).
+// ----------------------------------------------------------------------------------------------
+constexpr int ACT_DEP_TILES_MAX = 18;                       // 14 + ct, ct <= 4
+constexpr int ACT_H4 = ACT_DEP_TILES_MAX * 256;             // float offset of h4 (2 tiles)
+constexpr int ACT_MASK = ACT_H4 + 2 * 256;                  // float offset of the mask words (128 words)
+constexpr int ACT_STRIDE = ACT_MASK + 128;                  // floats per (tile, decoder slot)
+constexpr int ACT_SLOTS = 3;                                // decoder slots per tile: middle, fine, color
+
+// ----------------------------------------------------------------------------------------------
 // Scene description passed by value to kernels
 // ----------------------------------------------------------------------------------------------
 struct DevGrid {

@@ -309,6 +309,7 @@ struct BwdArgs {
     const float* rd;
     const double* z;
     const float* d_raw;
+    const float* act_ws;     // forward activations (render_fwd_kernel) or null: recompute
     DevScene sc;
     DevGrid ggrid[4];        // gradient accumulators (data may be null)
     float* gpacked[4];       // packed-layout gradient accumulators (may be null)
@@ -746,6 +747,290 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
     }
 }
 
+// Variant that takes the forward activations from the workspace written by render_fwd_kernel instead of
+// recomputing them: no gather / embedding / forward chain / forward barriers; the deposit slot is filled by one
+// async copy per tile.  Ring holds backward chunks only; its parity runs on across rounds (5 chunks per round).
+template <int CT, int NOUT>
+ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float* smem) {
+    constexpr XyzLay L{CT * 16};
+    constexpr int GF = L.fwd_floats();
+    constexpr int NE = NOUT == 4 ? 3 : 1;                          // outputs that carry gradient
+    using SL = XyzSlots<CT>;
+    constexpr int SLOT = SL::TILES * 256;                          // floats
+    constexpr int RB = 128 * 32 + 1024;                            // floats per ring buffer (largest W^T|Wc^T chunk)
+    constexpr int RING_BYTES = 2 * RB * 4;                         // LDS: [ring | 4 deposit slots]; flush image aliases the slots
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
+    const float* __restrict__ pk = A.sc.packed[kind];
+    const DevGrid grid = A.sc.grid[kind];
+    const DevGrid ggrid = A.ggrid[kind];
+    float* gpk = A.gpacked[kind];
+    const bool want_w = gpk != nullptr, want_g = ggrid.data != nullptr, want_r = A.g_ro != nullptr;
+    const bool want_c = want_g || want_r;
+    float* ring = smem;
+    float* slots = smem + 2 * RB;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)smem;   // LDS byte address of the dynamic region
+
+    const int slot_idx = kind - 1;                                  // decoder slot in the activation workspace
+    // backward layer i's chunk (W_i^T | Wc_i^T) into ring buffer `buf`
+    auto prefetch = [&](auto ic, int buf) {
+        constexpr int i = decltype(ic)::value;
+        float* dst = ring + (buf ? RB : 0);
+        ring_load(dst, pk + L.oWT(i), 8 * L.K(i), wave, lane);
+        ring_load(dst + 32 * L.K(i), pk + L.oWcT(i), 256, wave, lane);
+    };
+
+    // owned weight-gradient accumulators (tile t = wave + 4*j of each matrix), persistent over all rounds
+    f32x4 aWc[5][CT / 2], aW0[3], aW1[1], aW2[1], aW3[4], aW4[1], aB[5], aBT[2];
+    float aWo[NE][8], aBo[NE];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        aB[i] = splat4(0.f);
+#pragma unroll
+        for (int j = 0; j < CT / 2; ++j) aWc[i][j] = splat4(0.f);
+    }
+    aW0[0] = aW0[1] = aW0[2] = aW1[0] = aW2[0] = aW4[0] = splat4(0.f);
+    aW3[0] = aW3[1] = aW3[2] = aW3[3] = splat4(0.f);
+    aBT[0] = aBT[1] = splat4(0.f);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        aBo[j] = 0.f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) aWo[j][f] = 0.f;
+    }
+
+    const int64_t n_tiles = (int64_t)A.n_rays * A.ntl;
+    const int S = 16 * A.ntl;
+    const int64_t stride = (int64_t)n_wg * 4;
+    STAMP_DECL
+    STAMP_START
+    prefetch(IC(4), 0);
+    unsigned round_no = 0, rp = 0;                                  // rp: ring buffer of this round's first chunk
+    for (int64_t base = (int64_t)wg * 4; base < n_tiles; base += stride) {
+        const int64_t tile_raw = base + wave;
+        const bool tvalid = tile_raw < n_tiles;
+        const int tile = __builtin_amdgcn_readfirstlane((int)(tvalid ? tile_raw : n_tiles - 1));
+        const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
+        f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4);
+        if (!tvalid) draw = splat4(0.f);
+        float dj[NE];                                               // d(loss)/d(output j) of this lane's sample
+        if constexpr (NOUT == 4) { dj[0] = draw[0]; dj[1] = draw[1]; dj[2] = draw[2]; } else { dj[0] = draw[3]; }
+        bool nz = false;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) nz = nz || dj[j] != 0.f;
+        // nothing flows into any of the 4 tiles: skip the round (the waves of a workgroup stay in lockstep).
+        // One barrier: each wave posts its flag in a word of the round's parity set.
+        {
+            const int par = (int)(round_no & 1);
+            if (lane == 0) ens_vote[par][wave] = __any(nz) ? 1 : 0;
+            ++round_no;
+            __syncthreads();
+            const int any4 = ens_vote[par][0] | ens_vote[par][1] | ens_vote[par][2] | ens_vote[par][3];
+            if (!any4) continue;
+        }
+        STAMP(0)        // tile geometry + d_raw load + vote barrier
+
+        // per-lane LDS bases of this round (opaque: see above)
+        unsigned w32 = lds0 + (p * 32 + 4 * q) * 4;
+        unsigned dep = lds0 + RING_BYTES + (wave * SLOT + (p >> 2) * 64 + (p & 3) + 16 * q) * 4;
+        unsigned fb[4];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
+        opaque(w32); opaque(dep);
+
+        // ---- forward activations from the workspace: deposit tiles straight into this wave's LDS slot (async),
+        //      h4 and the ReLU masks into registers
+        const float* __restrict__ wsb = A.act_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * ACT_STRIDE;
+        if (want_w) {
+            float* myslot = slots + wave * SLOT;
+#pragma unroll
+            for (int t = 0; t < 14 + CT; ++t)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsb + t * 256 + lane * 4),
+                                                 (__attribute__((address_space(3))) void*)(myslot + t * 256), 16, 0, 0);
+        }
+        f32x4 h4[2];
+        h4[0] = ld4(wsb + ACT_H4 + lane * 4);
+        h4[1] = ld4(wsb + ACT_H4 + 256 + lane * 4);
+        const uint2 mw = *reinterpret_cast<const uint2*>(wsb + ACT_MASK + lane * 2);
+        unsigned mbits[5] = {mw.x & 255u, (mw.x >> 8) & 255u, (mw.x >> 16) & 255u, (mw.x >> 24) & 255u, mw.y & 255u};
+        const float pc = q == 0 ? (float)G.pw[0] : (q == 1 ? (float)G.pw[1] : (q == 2 ? (float)G.pw[2] : 0.f));
+        const Vox v = make_vox(G.pw, A.sc.lo, A.sc.hi, grid);
+        unsigned wr[2] = {w32, w32 + RB * 4};                         // lane bases into ring buffers 0 / 1
+        STAMP(3)
+
+        // ---- output layer: dWo, dbo on the VALU (n_out <= 4 rows: not worth an MFMA tile); dh4 = Wo^T d_out
+        if (want_w) {
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) aWo[j][4 * t + r] = fmaf(dj[j], h4[t][r], aWo[j][4 * t + r]);
+                }
+                if (q == 0) aBo[j] += dj[j];
+            }
+        }
+        f32x4 dh[2] = {splat4(0.f), splat4(0.f)};
+        {   // K = 4: one MFMA step per row tile; k-slot q carries output q
+            const float dq = NOUT == 4 ? (q == 0 ? draw[0] : (q == 1 ? draw[1] : (q == 2 ? draw[2] : 0.f)))
+                                       : (q == 0 ? draw[3] : 0.f);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) dh[rt] = MFMA16(pk[L.oWoT() + (16 * rt + p) * 4 + q], dq, dh[rt]);
+        }
+        f32x4 dc[2] = {splat4(0.f), splat4(0.f)};
+        f32x4 demb[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) demb[t] = splat4(0.f);
+        auto bwd_layer = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int kk = 4 - i;                                // chunk number inside the round
+            const int buf = (kk + rp) & 1;
+            const unsigned wb = wr[buf];
+            constexpr int RO = 0;                                    // W_i^T [K][32] | Wc_i^T [32][32]
+            constexpr int OCT = 32 * L.K(i) * 4;
+            constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
+            constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);      // input h_{i-1} of layers 4, 2, 1
+            f32x4 dpre[2] = {mask4(dh[0], mbits[i], 0), mask4(dh[1], mbits[i], 4)};
+            if (want_w) {
+                dep_tile<TH>(dep, dh[0]); dep_tile<TH + 1>(dep, dh[1]);
+                dep_tile<TP>(dep, dpre[0]); dep_tile<TP + 1>(dep, dpre[1]);
+            }
+            STAMP(6)    // layer deposits (+ tail of previous dX)
+            __syncthreads();            // deposits visible; this layer's W^T chunk has landed
+            STAMP(5)    // barrier wait
+            if constexpr (i > 0) prefetch(IC(i - 1), buf ^ 1); else prefetch(IC(4), buf ^ 1);
+            if (want_w) {
+                own_outer_a<CT / 2>(aWc[i], fb, TH, SL::C, CT, 2 * CT, wave);                     // dWc_i
+                if constexpr (i == 0) {
+                    own_outer_a<3>(aW0, fb, TP, SL::EMB, 6, 12, wave);
+                } else if constexpr (i == 3) {
+                    own_outer_a<4>(aW3, fb, TP, SL::EMB, 8, 16, wave);                           // [emb | h2] contiguous
+                } else if constexpr (i == 1) {
+                    own_outer_a<1>(aW1, fb, TP, TX, 2, 4, wave);
+                } else if constexpr (i == 2) {
+                    own_outer_a<1>(aW2, fb, TP, TX, 2, 4, wave);
+                } else {
+                    own_outer_a<1>(aW4, fb, TP, TX, 2, 4, wave);
+                }
+                own_bias_a(aB[i], fb, (wave < 2 ? TP : TH) + (wave & 1));                        // db_i | dbc_i
+                STAMP(7)    // owned dW MFMAs
+            }
+            if (want_c) lin_lds<2, 2, 32, OCT>(dc, wb, dh);                              // dC += Wc_i^T dh_i
+            if constexpr (i == 0) {
+                if (want_r || want_w) lin_lds<6, 2, 32, RO>(demb, wb, dpre);
+            } else if constexpr (i == 3) {
+                if (want_r || want_w) lin_lds<6, 2, 32, RO>(demb, wb, dpre);        // rows 0..95 of W3^T: embedding part
+                dh[0] = dh[1] = splat4(0.f);
+                lin_lds<2, 2, 32, RO + 96 * 32 * 4>(dh, wb, dpre);
+            } else {
+                dh[0] = dh[1] = splat4(0.f);
+                lin_lds<2, 2, 32, RO>(dh, wb, dpre);
+            }
+        };
+        bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
+        rp ^= 1;                                                    // 5 chunks per executed round
+        STAMP(8)        // dX chain of the last layer
+        // ---- embedding: d_arg = d_emb * cos(arg);  dB^T += d_arg (x) p ;  dp += B d_arg
+        float dpx = 0.f, dpy = 0.f, dpz = 0.f;
+        if (want_r || want_w) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {                               // cos(arg) recomputed: cheaper than carrying it
+                const f32x4 arg = MFMA16(pk[L.oBT() + (16 * t + p) * 4 + q], pc, splat4(0.f));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sv, cv;
+                    ens_sincosf(arg[r], sv, cv);
+                    demb[t][r] *= cv;
+                }
+            }
+            if (want_w) {
+                __syncthreads();                                     // every wave is done reading EMB
+                dep_tile<SL::EMB + 0>(dep, demb[0]); dep_tile<SL::EMB + 1>(dep, demb[1]); dep_tile<SL::EMB + 2>(dep, demb[2]);
+                dep_tile<SL::EMB + 3>(dep, demb[3]); dep_tile<SL::EMB + 4>(dep, demb[4]); dep_tile<SL::EMB + 5>(dep, demb[5]);
+                f32x4 pt4 = splat4(0.f);
+                if (q == 0) pt4 = f32x4{(float)G.pw[0], (float)G.pw[1], (float)G.pw[2], 0.f};
+                dep_tile<SL::Q>(dep, pt4);
+                __syncthreads();
+                own_outer_a<2>(aBT, fb, SL::EMB, SL::Q, 1, 6, wave);                              // dB^T
+            }
+            if (want_r) {
+                f32x4 dpe[1] = {splat4(0.f)};
+                linear_n<1, 6>(dpe, pk + L.oBp(), 96, demb, p, q);
+                dpx = dpe[0][0]; dpy = dpe[0][1]; dpz = dpe[0][2];      // valid on q == 0 lanes
+            }
+        }
+        STAMP(9)        // embedding tail (cos recompute, dB^T, dp)
+        // ---- grid: coordinate gradient and feature-gradient scatter
+        if (want_c) {
+            if (want_r) {
+                float gx, gy, gz;
+                coord_grad_partial(v, grid, q, dc[0], dc[1], gx, gy, gz);
+                gx += __shfl_xor(gx, 16); gx += __shfl_xor(gx, 32);
+                gy += __shfl_xor(gy, 16); gy += __shfl_xor(gy, 32);
+                gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
+                dpx += gx * v.gx; dpy += gy * v.gy; dpz += gz * v.gz;
+            }
+            if (want_g && tvalid) {
+                // stage dC as [sample][32 channels] in this wave's H1 tiles (layer 1 was their last reader, two
+                // barriers ago; the next writer is the next round's layer 3, behind further barriers)
+                float* stg = slots + wave * SLOT + SL::H1 * 256;
+                *reinterpret_cast<f32x4*>(stg + p * 32 + 4 * q) = dc[0];
+                *reinterpret_cast<f32x4*>(stg + p * 32 + 16 + 4 * q) = dc[1];
+                wave_lds_fence();
+                scatter_tile(stg, v, ggrid, lane);
+                wave_lds_fence();
+            }
+        }
+        if (want_r && tvalid) {
+            if (q != 0) { dpx = dpy = dpz = 0.f; }
+            add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
+        }
+        STAMP(10)       // coordinate gradient + scatter + ray grads
+    }
+    STAMP_FLUSH
+
+    // ---- flush: stage the owned tiles into a packed-layout LDS image, then coalesced global atomics
+    if (want_w) {
+        float* sacc = slots;
+        __syncthreads();
+        for (int e = threadIdx.x; e < GF; e += 256) sacc[e] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+#pragma unroll
+            for (int j = 0; j < CT / 2; ++j) stage_tile(sacc + L.oWc(i), CT * 16, 0, CT, wave + 4 * j, aWc[i][j], 32, CT * 16, p, q);
+            stage_bias(sacc + (wave < 2 ? L.ob(i) : L.obc(i)), wave & 1, aB[i], 32, p, q);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) stage_tile(sacc + L.oW(0), 96, 0, 6, wave + 4 * j, aW0[j], 32, 96, p, q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_tile(sacc + L.oW(3), 128, 0, 8, wave + 4 * j, aW3[j], 32, 128, p, q);
+        stage_tile(sacc + L.oW(1), 32, 0, 2, wave, aW1[0], 32, 32, p, q);
+        stage_tile(sacc + L.oW(2), 32, 0, 2, wave, aW2[0], 32, 32, p, q);
+        stage_tile(sacc + L.oW(4), 32, 0, 2, wave, aW4[0], 32, 32, p, q);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (wave + 4 * j < 6) stage_tile(sacc + L.oBT(), 4, 0, 1, wave + 4 * j, aBT[j], 93, 3, p, q);
+        // output layer: per-lane partial sums -> reduce over the 16 sample lanes; the 4 waves add in LDS
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                float a = aWo[j][f];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                if (p == 0) lds_add(sacc + L.oWo() + j * 32 + 16 * (f >> 2) + 4 * q + (f & 3), a);
+            }
+            float bsum = wave_sum(aBo[j]);
+            if (lane == 0) lds_add(sacc + L.obo() + j, bsum);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < GF; e += 256) {
+            const float vsum = sacc[e];
+            if (vsum != 0.f) atomicAdd(gpk + e, vsum);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // MLP_no_xyz (coarse) backward role
 // ------------------------------------------------------------------------------------------------
@@ -906,6 +1191,7 @@ ENS_DEV void feat_role(const BwdArgs& A, int wg, int n_wg, float* smem) {
 
 extern __shared__ __attribute__((aligned(16))) float ens_smem[];
 
+template <bool SAVED>
 __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(BwdArgs A) {
     int role = 0;
 #pragma unroll
@@ -914,9 +1200,9 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(BwdArgs A) {
     const int kind = A.role_kind[role];
     switch (kind) {
         case 0: feat_role(A, wg, n_wg, ens_smem); break;
-        case 1: xyz_role<2, 1>(A, 1, wg, n_wg, ens_smem); break;
-        case 2: xyz_role<4, 1>(A, 2, wg, n_wg, ens_smem); break;
-        case 3: xyz_role<2, 4>(A, 3, wg, n_wg, ens_smem); break;
+        case 1: if constexpr (SAVED) xyz_role_saved<2, 1>(A, 1, wg, n_wg, ens_smem); else xyz_role<2, 1>(A, 1, wg, n_wg, ens_smem); break;
+        case 2: if constexpr (SAVED) xyz_role_saved<4, 1>(A, 2, wg, n_wg, ens_smem); else xyz_role<4, 1>(A, 2, wg, n_wg, ens_smem); break;
+        case 3: if constexpr (SAVED) xyz_role_saved<2, 4>(A, 3, wg, n_wg, ens_smem); else xyz_role<2, 4>(A, 3, wg, n_wg, ens_smem); break;
         default: break;
     }
 }
@@ -954,10 +1240,11 @@ int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* 
 }
 
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
-                           const DevScene& sc, const float* d_raw, const DevGrid* grad_grids,
+                           const DevScene& sc, const float* d_raw, const float* act_ws, const DevGrid* grad_grids,
                            float* const* grad_packed, float* g_ro, float* g_rd, hipStream_t st) {
     if (n_rays <= 0) return 0;
     BwdArgs A;
+    A.act_ws = stage == 0 ? nullptr : act_ws;
     A.n_rays = n_rays; A.ntl = ntl; A.ro = ro; A.rd = rd; A.z = z; A.d_raw = d_raw; A.sc = sc;
     A.g_ro = (g_ro && g_rd) ? g_ro : nullptr;
     A.g_rd = (g_ro && g_rd) ? g_rd : nullptr;
@@ -1006,11 +1293,14 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
     for (int i = n2; i < 4; ++i) A.role_kind[i] = -1;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_xyz(4)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_xyz(4)) != hipSuccess)
             return -2;
         attr_set = true;
     }
-    decoder_bwd_kernel<<<dim3(total), dim3(256), lds, st>>>(A);
+    if (A.act_ws != nullptr) decoder_bwd_kernel<true><<<dim3(total), dim3(256), lds, st>>>(A);
+    else decoder_bwd_kernel<false><<<dim3(total), dim3(256), lds, st>>>(A);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

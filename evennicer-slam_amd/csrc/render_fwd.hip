@@ -11,12 +11,30 @@
 
 namespace {
 
+ENS_DEV unsigned fwd_pos_bits(const f32x4& v) {
+    return (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+}
+// Write one register tile to the workspace in the backward's deposit layout: transpose through a wave-private
+// 1 KB LDS tile, then one coalesced 16-byte store per lane.
+ENS_DEV void ws_store_dep(float* __restrict__ ws_tile, const f32x4& x, float* stage, int lane, int p, int q) {
+    float* d = stage + (p >> 2) * 64 + (p & 3) + 16 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[4 * r] = x[r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + lane * 4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<f32x4*>(ws_tile + lane * 4) = v;
+}
+
 ENS_DEV f32x4 sin4(f32x4 v) { return f32x4{ens_sinf(v[0]), ens_sinf(v[1]), ens_sinf(v[2]), ens_sinf(v[3])}; }
 
 // One block of MLP.forward (decoder.py:193-199): h = relu(W_i x + b_i) + (Wc_i c + bc_i).
 template <int I, int CT, int NTL>
 ENS_DEV void xyz_layer(const float* __restrict__ pk, const f32x4 (&emb)[NTL][6], const f32x4 (&c)[NTL][CT],
-                       f32x4 (&h)[NTL][2], int p, int q) {
+                       f32x4 (&h)[NTL][2], unsigned (&mb)[NTL][2], float* const (&ws)[NTL], float* stage, int lane, int p,
+                       int q) {
     constexpr XyzLay L{CT * 16};
     f32x4 acc[NTL][2];
 #pragma unroll
@@ -34,6 +52,11 @@ ENS_DEV void xyz_layer(const float* __restrict__ pk, const f32x4 (&emb)[NTL][6],
         linear32<2, NTL, 2>(acc, pk + L.oW(I), 32, h, 0, p, q);
     }
 #pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) {
+        const unsigned bits = fwd_pos_bits(acc[tl][0]) | (fwd_pos_bits(acc[tl][1]) << 4);
+        if (I < 4) mb[tl][0] |= bits << (8 * I); else mb[tl][1] = bits;
+    }
+#pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         const f32x4 bc = ld4(pk + L.obc(I) + 16 * rt + 4 * q);
 #pragma unroll
@@ -41,14 +64,29 @@ ENS_DEV void xyz_layer(const float* __restrict__ pk, const f32x4 (&emb)[NTL][6],
     }
     linear32<CT, NTL, CT>(acc, pk + L.oWc(I), CT * 16, c, 0, p, q);
 #pragma unroll
-    for (int tl = 0; tl < NTL; ++tl) { h[tl][0] = acc[tl][0]; h[tl][1] = acc[tl][1]; }
+    for (int tl = 0; tl < NTL; ++tl) {
+        h[tl][0] = acc[tl][0];
+        h[tl][1] = acc[tl][1];
+        if (ws[tl] != nullptr) {                    // backward operands: slot order EMB 0..5 | h2 6 | h0 8 | h1 10 | h3 12
+            constexpr int T = I == 2 ? 6 : (I == 0 ? 8 : (I == 1 ? 10 : 12));
+            if constexpr (I < 4) {
+                ws_store_dep(ws[tl] + T * 256, h[tl][0], stage, lane, p, q);
+                ws_store_dep(ws[tl] + (T + 1) * 256, h[tl][1], stage, lane, p, q);
+            } else {                                // h4 feeds the VALU dWo: register layout
+                *reinterpret_cast<f32x4*>(ws[tl] + ACT_H4 + lane * 4) = h[tl][0];
+                *reinterpret_cast<f32x4*>(ws[tl] + ACT_H4 + 256 + lane * 4) = h[tl][1];
+                *reinterpret_cast<uint2*>(ws[tl] + ACT_MASK + lane * 2) = make_uint2(mb[tl][0], mb[tl][1]);
+            }
+        }
+    }
 }
 
 // MLP (middle/fine/color), decoder.py:177-203.  c: CT feature tiles; o: output tile (rows 0..n_out-1
 // valid on lanes q == 0).
+// ws[tl]: activation-workspace block of (tile tl, this decoder) or nullptr (nothing saved)
 template <int CT, int NTL>
 ENS_DEV void mlp_xyz_fwd(const float* __restrict__ pk, const float (&pc)[NTL], const f32x4 (&c)[NTL][CT],
-                         f32x4 (&o)[NTL], int p, int q) {
+                         f32x4 (&o)[NTL], float* const (&ws)[NTL], float* stage, int lane, int p, int q) {
     constexpr XyzLay L{CT * 16};
     f32x4 emb[NTL][6];
 #pragma unroll
@@ -57,12 +95,24 @@ ENS_DEV void mlp_xyz_fwd(const float* __restrict__ pk, const float (&pc)[NTL], c
 #pragma unroll
         for (int tl = 0; tl < NTL; ++tl) emb[tl][t] = sin4(MFMA16(a, pc[tl], splat4(0.f)));
     }
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) {
+        if (ws[tl] != nullptr) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) ws_store_dep(ws[tl] + t * 256, emb[tl][t], stage, lane, p, q);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) ws_store_dep(ws[tl] + (14 + t) * 256, c[tl][t], stage, lane, p, q);
+        }
+    }
     f32x4 h[NTL][2];
-    xyz_layer<0, CT, NTL>(pk, emb, c, h, p, q);
-    xyz_layer<1, CT, NTL>(pk, emb, c, h, p, q);
-    xyz_layer<2, CT, NTL>(pk, emb, c, h, p, q);
-    xyz_layer<3, CT, NTL>(pk, emb, c, h, p, q);
-    xyz_layer<4, CT, NTL>(pk, emb, c, h, p, q);
+    unsigned mb[NTL][2];
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) mb[tl][0] = mb[tl][1] = 0u;
+    xyz_layer<0, CT, NTL>(pk, emb, c, h, mb, ws, stage, lane, p, q);
+    xyz_layer<1, CT, NTL>(pk, emb, c, h, mb, ws, stage, lane, p, q);
+    xyz_layer<2, CT, NTL>(pk, emb, c, h, mb, ws, stage, lane, p, q);
+    xyz_layer<3, CT, NTL>(pk, emb, c, h, mb, ws, stage, lane, p, q);
+    xyz_layer<4, CT, NTL>(pk, emb, c, h, mb, ws, stage, lane, p, q);
     out_layer<NTL>(o, pk + L.oWo(), pk + L.obo(), h, p, q);
 }
 
@@ -124,7 +174,8 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(int64_t n_units, const f
                                                         const double* __restrict__ points, int64_t n_points,
                                                         int apply_mask, int tiles_per_ray, DevScene sc, double* __restrict__ depth,
                                                         double* __restrict__ var, float* __restrict__ rgb,
-                                                        float* __restrict__ raw_out) {
+                                                        float* __restrict__ raw_out, float* __restrict__ act_ws) {
+    __shared__ __attribute__((aligned(16))) float ws_stage[256];
     constexpr int S = 16 * NTL;
     const int lane = threadIdx.x, p = lane & 15, q = lane >> 4;
     const bool tile_mode = tiles_per_ray > 0;
@@ -161,6 +212,17 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(int64_t n_units, const f
     f32x4 occ[NTL], col[NTL];
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) { occ[tl] = splat4(0.f); col[tl] = splat4(0.f); }
+    // activation workspace blocks of this wave's tiles (tile index = unit*NTL + tl), one per decoder slot
+    float* ws0[NTL];
+    float* ws1[NTL];
+    float* ws2[NTL];
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) {
+        float* b = (act_ws != nullptr && points == nullptr) ? act_ws + ((unit * NTL + tl) * ACT_SLOTS) * (int64_t)ACT_STRIDE : nullptr;
+        ws0[tl] = b;
+        ws1[tl] = b ? b + ACT_STRIDE : nullptr;
+        ws2[tl] = b ? b + 2 * ACT_STRIDE : nullptr;
+    }
 
     if constexpr (STAGE == 0) {
         f32x4 c[NTL][2];
@@ -177,7 +239,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(int64_t n_units, const f
             const Vox v = make_vox(pw[tl], sc.lo, sc.hi, sc.grid[1]);
             gather8(v, sc.grid[1], q, cm[tl][0], cm[tl][1]);
         }
-        mlp_xyz_fwd<2, NTL>(sc.packed[1], pc, cm, occ, p, q);
+        mlp_xyz_fwd<2, NTL>(sc.packed[1], pc, cm, occ, ws0, ws_stage, lane, p, q);
         if constexpr (STAGE >= 2) {
             f32x4 cf[NTL][4];
 #pragma unroll
@@ -188,7 +250,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(int64_t n_units, const f
                 cf[tl][3] = cm[tl][1];
             }
             f32x4 of[NTL];
-            mlp_xyz_fwd<4, NTL>(sc.packed[2], pc, cf, of, p, q);
+            mlp_xyz_fwd<4, NTL>(sc.packed[2], pc, cf, of, ws1, ws_stage, lane, p, q);
 #pragma unroll
             for (int tl = 0; tl < NTL; ++tl) occ[tl][0] = of[tl][0] + occ[tl][0];   // fine_occ + middle_occ
         }
@@ -199,7 +261,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(int64_t n_units, const f
                 const Vox v = make_vox(pw[tl], sc.lo, sc.hi, sc.grid[3]);
                 gather8(v, sc.grid[3], q, cc[tl][0], cc[tl][1]);
             }
-            mlp_xyz_fwd<2, NTL>(sc.packed[3], pc, cc, col, p, q);
+            mlp_xyz_fwd<2, NTL>(sc.packed[3], pc, cc, col, ws2, ws_stage, lane, p, q);
         }
     }
 
@@ -293,14 +355,14 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(int S, const float* _
 
 template <int STAGE>
 int launch_stage(int ntl, int64_t n_units, const float* ro, const float* rd, const double* z, const double* pts,
-                 int64_t n_points, int apply_mask, int tpr, const DevScene& sc, double* depth, double* var, float* rgb, float* raw,
+                 int64_t n_points, int apply_mask, int tpr, float* act_ws, const DevScene& sc, double* depth, double* var, float* rgb, float* raw,
                  hipStream_t st) {
     if (n_units <= 0) return 0;
     const dim3 grid((unsigned)n_units), block(64);
     switch (ntl) {
-        case 1: render_fwd_kernel<STAGE, 1><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw); break;
-        case 2: render_fwd_kernel<STAGE, 2><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw); break;
-        case 3: render_fwd_kernel<STAGE, 3><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw); break;
+        case 1: render_fwd_kernel<STAGE, 1><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, act_ws); break;
+        case 2: render_fwd_kernel<STAGE, 2><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, act_ws); break;
+        case 3: render_fwd_kernel<STAGE, 3><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, act_ws); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -317,7 +379,7 @@ int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* 
 
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
-                          double* var, float* rgb, float* raw, hipStream_t st) {
+                          double* var, float* rgb, float* raw, float* act_ws, hipStream_t st) {
     // Ray mode with raw requested and a moderate ray count: tile-per-wave decoders + separate compositing (more
     // waves in flight).  Large batches (full-image renders) already fill the chip with one wave per ray.
     int tpr = 0;
@@ -328,10 +390,10 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
     }
     int rc;
     switch (stage) {
-        case 0: rc = launch_stage<0>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, st); break;
-        case 1: rc = launch_stage<1>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, st); break;
-        case 2: rc = launch_stage<2>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, st); break;
-        case 3: rc = launch_stage<3>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, st); break;
+        case 0: rc = launch_stage<0>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, sc, depth, var, rgb, raw, st); break;
+        case 1: rc = launch_stage<1>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, sc, depth, var, rgb, raw, st); break;
+        case 2: rc = launch_stage<2>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, sc, depth, var, rgb, raw, st); break;
+        case 3: rc = launch_stage<3>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, sc, depth, var, rgb, raw, st); break;
         default: return -1;
     }
     if (rc != 0 || tpr == 0) return rc;

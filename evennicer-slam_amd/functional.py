@@ -317,10 +317,16 @@ class _RenderFn(torch.autograd.Function):
         var = torch.empty(N, dtype=torch.float64, device=dev)
         rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
         raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
+        # a backward will follow: let the forward park the backward's operands (else the backward recomputes them)
+        act = None
+        if any(ctx.needs_input_grad):
+            n_act = lib.enslam_activation_floats(L.STAGE[plan.stage], N, S)
+            if 0 < n_act * 4 <= ACT_WORKSPACE_LIMIT_BYTES:
+                act = torch.empty(n_act, dtype=torch.float32, device=dev)
         L.check(lib.enslam_render_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                      _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), st), "enslam_render_fwd")
+                                      _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), st), "enslam_render_fwd")
         ctx.plan, ctx.S, ctx.dims = plan, S, dims
-        ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed)
+        ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act)
         ctx.grid_shapes = [tuple(g.shape) for g in grids]
         ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
         return depth, var, rgb
@@ -329,7 +335,7 @@ class _RenderFn(torch.autograd.Function):
     def backward(ctx, g_depth, g_var, g_rgb):
         lib = L.lib()
         plan, S = ctx.plan, ctx.S
-        ro, rd, z, raw, depth, grids_vm, packed = ctx.keep
+        ro, rd, z, raw, depth, grids_vm, packed, act = ctx.keep
         N, dev, st = ro.shape[0], ro.device, _stream()
         nk = len(plan.kinds)
         needs = ctx.needs_input_grad            # (plan, ro, rd, gd, t_rand, grids..., params...)
@@ -389,7 +395,7 @@ class _RenderFn(torch.autograd.Function):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         L.check(lib.enslam_decoder_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                       _ptr(d_raw), gg, gpk, p_ro, p_rd, st), "enslam_decoder_bwd")
+                                       _ptr(d_raw), _ptr(act), gg, gpk, p_ro, p_rd, st), "enslam_decoder_bwd")
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
@@ -431,6 +437,10 @@ class _RenderFn(torch.autograd.Function):
         del flat
         return tuple(out)
 
+
+# The forward keeps the backward's operands (1.3 KB per sample and decoder: 172 MB at 1000 rays x 48, colour
+# stage) when their total stays under this limit; above it the backward recomputes them (slower, no extra memory).
+ACT_WORKSPACE_LIMIT_BYTES = 8 << 30
 
 PROFILE = {}        # {'decoder_bwd': [(event_begin, event_end), ...]} when bench.py asks for per-kernel timing
 

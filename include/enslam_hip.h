@@ -134,7 +134,14 @@ int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const floa
  * raw_out (may be NULL) receives the per-sample (r,g,b,occ) needed by enslam_render_bwd. */
 int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                       const double *z_vals, const enslam_scene *scene, double *depth, double *var, float *rgb,
-                      float *raw_out, void *stream);
+                      float *raw_out, float *act_ws, void *stream);
+
+/* float32 count of the activation workspace `act_ws` for a batch (0 for the coarse stage, which always
+ * recomputes).  When enslam_render_fwd is given a workspace of this size it also writes, per 16-sample tile and
+ * decoder, the operands the backward needs (embedding, grid features, hidden activations, ReLU masks), and
+ * enslam_decoder_bwd / enslam_render_bwd given the same buffer read them instead of recomputing the decoder
+ * forward.  NULL in both places selects recomputation (no extra memory, slower backward). */
+size_t enslam_activation_floats(int32_t stage, int32_t n_rays, int32_t n_samples);
 
 /* Forward of Renderer.eval_points (Renderer.py:24-62) on explicit points p float64 [P,3].
  * apply_mask = 0 gives the bare decoder call NICE.forward (decoder.py:312-342, as Mesher.py:308 uses it). */
@@ -154,7 +161,7 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
                       const double *z_vals, const enslam_scene *scene, const float *raw, const double *depth,
                       const double *g_depth, const double *g_var, const float *g_rgb,
                       const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o, float *g_rays_d,
-                      float *d_raw, void *stream);
+                      float *d_raw, const float *act_ws, void *stream);
 
 /* The two halves of enslam_render_bwd, callable on their own.
  * enslam_composite_bwd: backward of raw2outputs_nerf_color (common.py:284-296): d(depth,var,rgb) -> d_raw [N*S,4].
@@ -163,7 +170,7 @@ int enslam_composite_bwd(int32_t n_rays, int32_t n_samples, const float *raw, co
                          const double *depth, const double *g_depth, const double *g_var, const float *g_rgb,
                          float *d_raw, void *stream);
 int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
-                       const double *z_vals, const enslam_scene *scene, const float *d_raw,
+                       const double *z_vals, const enslam_scene *scene, const float *d_raw, const float *act_ws,
                        const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o, float *g_rays_d,
                        void *stream);
 
