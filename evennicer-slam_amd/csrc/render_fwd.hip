@@ -168,7 +168,7 @@ ENS_DEV float to_sample_lane(const f32x4 (&o)[NTL], int comp, int lane) {
 // MODE 2: one wave per 16-sample tile of a ray (NTL == 1, tiles_per_ray > 0): raw only; compositing runs as its
 //         own kernel.  3x the waves of MODE 0 at less than half the registers: latency is hidden by occupancy.
 template <int STAGE, int NTL>
-__global__ __launch_bounds__(64) void render_fwd_kernel(int64_t n_units, const float* __restrict__ rays_o,
+__global__ __launch_bounds__(64, NTL == 1 ? 3 : 1) void render_fwd_kernel(int64_t n_units, const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const double* __restrict__ z_vals,
                                                         const double* __restrict__ points, int64_t n_points,

@@ -122,3 +122,15 @@ def test_room0_coarse200_backward():
     for name, p in model.named_parameters():
         if "gp_" + name in g and np.abs(g["gp_" + name]).max() > 0:
             assert rel_err(p.grad.cpu().numpy(), g["gp_" + name]) < GTOL, name
+
+
+@pytest.mark.parametrize("stage", ["middle", "fine", "color"])
+def test_backward_recompute_fallback_matches(tiny, stage, monkeypatch):
+    """Without an activation workspace (limit 0) the backward recomputes the decoder forward: same gradients."""
+    import evennicer_slam_amd.functional as EF
+    g = load("tiny_" + stage)
+    cot = [torch.from_numpy(g[k]).cuda() for k in ("cot_depth", "cot_var", "cot_color")]
+    monkeypatch.setattr(EF, "ACT_WORKSPACE_LIMIT_BYTES", 0)
+    cg, ro, rd, model, loss = _run(tiny, stage, cot=cot)
+    worst = _check(g, cg, ro, rd, model)
+    assert len(worst) >= 4
