@@ -1,0 +1,49 @@
+// LDS helpers shared by the forward and backward kernels: explicit (base VGPR + immediate) addressing, the
+// layer-weight ring filled by async global_load_lds, and MFMA linear layers reading their A fragments from LDS.
+#pragma once
+#include "common.hpp"
+
+// ---- explicit LDS addressing -------------------------------------------------------------------
+// Every LDS access of the xyz role is  (one per-lane base VGPR) + (compile-time byte offset): the offset folds
+// into the instruction's 16-bit offset field, so no address registers pile up (left to itself the compiler
+// hoists hundreds of loop-invariant addresses out of the tile loop, runs out of VGPRs and stops overlapping
+// loads with MFMAs).  The bases are made opaque once per round so they cannot be re-expanded and hoisted.
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+ENS_DEV f32x4 lds4(unsigned addr) { return *reinterpret_cast<const lds_f32x4*>(static_cast<uintptr_t>(addr)); }
+ENS_DEV void lds_st4(unsigned addr, const f32x4& v) { *reinterpret_cast<lds_f32x4*>(static_cast<uintptr_t>(addr)) = v; }
+ENS_DEV void lds_st1(unsigned addr, float v) { *reinterpret_cast<lds_float*>(static_cast<uintptr_t>(addr)) = v; }
+ENS_DEV void opaque(unsigned& v) { asm volatile("" : "+v"(v)); }
+
+// acc[rt] += W[(16rt+i)*LD + 16t + 4q ..] * x[t]; W at byte offset OFF behind the lane base  base = (p*LD + 4q)*4
+template <int NR, int KT, int LD, int OFF>
+ENS_DEV void lin_lds(f32x4 (&acc)[NR], unsigned base, const f32x4 (&x)[KT]) {
+    // all fragment reads first (independent, distinct registers), then the MFMAs with the accumulators
+    // alternating so that back-to-back issues never wait on their own result
+    f32x4 a[KT][NR];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt) a[t][rt] = lds4(base + OFF + (16 * rt * LD + 16 * t) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt) acc[rt] = MFMA16(a[t][rt][r], x[t][r], acc[rt]);
+        }
+    }
+}
+
+// cooperative async copy global -> LDS of n4 float4 (all 256 threads; 1 KB per wave instruction, no VGPR staging)
+ENS_DEV void ring_load(float* dst_lds, const float* __restrict__ src, int n4, int wave, int lane) {
+    for (int j = 0; j * 256 < n4; ++j) {
+        const int e = j * 256 + wave * 64 + lane;
+        if (e < n4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * e),
+                                             (__attribute__((address_space(3))) void*)(dst_lds + 4 * (j * 256 + wave * 64)),
+                                             16, 0, 0);
+    }
+}

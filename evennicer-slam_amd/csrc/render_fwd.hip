@@ -6,8 +6,12 @@
 // Replaces (reference paths): src/utils/Renderer.py:173-181 (points, eval_points call),
 // Renderer.py:24-62 (bound mask), src/conv_onet/models/decoder.py:168-203,254-274,312-342
 // (grid_sample + MLPs + stage combine), src/common.py:256-297 (raw2outputs, occupancy branch).
+#include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
+#include "lds_util.hpp"
+
+#define IC(n) std::integral_constant<int, n>{}
 
 namespace {
 
@@ -318,6 +322,164 @@ __global__ __launch_bounds__(64, NTL == 1 ? 3 : 1) void render_fwd_kernel(int64_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tile-mode forward with a shared LDS weight ring: one workgroup = 4 waves = 4 tiles of 16 samples, in lockstep.
+// Each layer's chunk (W|b|Wc|bc of the packed decoder) is streamed into a 2-slot LDS ring by async global_load_lds
+// one layer ahead and read by all 4 waves with  base-VGPR + immediate  ds_read_b128; this replaces 3000 per-wave
+// passes over the 210 KB of weights through L2 by 750 per-workgroup passes and takes the L2 latency off every layer.
+// ------------------------------------------------------------------------------------------------
+constexpr int fwd_ring_floats(int stage) { return stage >= 2 ? 32 * 128 + 32 + 32 * 64 + 32 : 32 * 128 + 32 + 32 * 32 + 32; }
+constexpr int fwd_ring_lds_bytes(int stage) { return (2 * fwd_ring_floats(stage) + 4 * 256) * 4; }
+
+// decoder `kind` through the ring; its layer i is global chunk C0+i (buffer (C0+i)&1).  pk_next: packed decoder whose
+// layer 0 follows in the ring (nullptr: none).  NEXT_CD: its fc_c width.
+template <int CT, int C0, int RB, int NEXT_CD>
+ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict__ pk_next, float* ring, float pc,
+                          const f32x4 (&c)[CT], f32x4& o, float* ws, float* stage, unsigned w32, unsigned w96,
+                          unsigned w128, unsigned wcd, unsigned wq, int wave, int lane, int p, int q) {
+    constexpr XyzLay L{CT * 16};
+    constexpr int CD = CT * 16;
+    f32x4 emb[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const float a = pk[L.oBT() + (16 * t + p) * 4 + q];
+        emb[t] = sin4(MFMA16(a, pc, splat4(0.f)));
+    }
+    if (ws != nullptr) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) ws_store_dep(ws + t * 256, emb[t], stage, lane, p, q);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) ws_store_dep(ws + (14 + t) * 256, c[t], stage, lane, p, q);
+    }
+    f32x4 h[5][2];
+    unsigned mb0 = 0u, mb1 = 0u;
+    auto layer = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int RO = ((C0 + i) & 1) ? RB * 4 : 0;
+        constexpr int K = L.K(i);
+        constexpr int OB = RO + 32 * K * 4, OC = OB + 32 * 4, OBC = OC + 32 * CD * 4;
+        float* nxt = ring + (((C0 + i + 1) & 1) ? RB : 0);
+        if constexpr (i < 4) {
+            ring_load(nxt, pk + L.oW(i + 1), (L.oW(i + 2) - L.oW(i + 1)) / 4, wave, lane);
+        } else if constexpr (NEXT_CD > 0) {
+            constexpr XyzLay LN{NEXT_CD};
+            ring_load(nxt, pk_next + LN.oW(0), (LN.oW(1) - LN.oW(0)) / 4, wave, lane);
+        }
+        f32x4 acc[2];
+        acc[0] = lds4(wq + OB);
+        acc[1] = lds4(wq + OB + 64);
+        if constexpr (i == 0) {
+            lin_lds<2, 6, 96, RO>(acc, w96, emb);
+        } else if constexpr (i == 3) {
+            lin_lds<2, 6, 128, RO>(acc, w128, emb);
+            lin_lds<2, 2, 128, RO + 96 * 4>(acc, w128, h[2]);
+        } else {
+            lin_lds<2, 2, 32, RO>(acc, w32, h[i - 1]);
+        }
+        const unsigned bits = fwd_pos_bits(acc[0]) | (fwd_pos_bits(acc[1]) << 4);
+        if constexpr (i < 4) mb0 |= bits << (8 * i); else mb1 = bits;
+        acc[0] = relu4(acc[0]) + lds4(wq + OBC);
+        acc[1] = relu4(acc[1]) + lds4(wq + OBC + 64);
+        lin_lds<2, CT, CD, OC>(acc, wcd, c);
+        h[i][0] = acc[0];
+        h[i][1] = acc[1];
+        if (ws != nullptr) {
+            constexpr int T = i == 2 ? 6 : (i == 0 ? 8 : (i == 1 ? 10 : 12));
+            if constexpr (i < 4) {
+                ws_store_dep(ws + T * 256, h[i][0], stage, lane, p, q);
+                ws_store_dep(ws + (T + 1) * 256, h[i][1], stage, lane, p, q);
+            } else {
+                *reinterpret_cast<f32x4*>(ws + ACT_H4 + lane * 4) = h[4][0];
+                *reinterpret_cast<f32x4*>(ws + ACT_H4 + 256 + lane * 4) = h[4][1];
+                *reinterpret_cast<uint2*>(ws + ACT_MASK + lane * 2) = make_uint2(mb0, mb1);
+            }
+        }
+        __syncthreads();                // next chunk landed; all waves done with this buffer
+    };
+    layer(IC(0)); layer(IC(1)); layer(IC(2)); layer(IC(3)); layer(IC(4));
+    // output layer (tiny): weights straight from global
+    f32x4 oo[1], hh[1][2];
+    hh[0][0] = h[4][0];
+    hh[0][1] = h[4][1];
+    out_layer<1>(oo, pk + L.oWo(), pk + L.obo(), hh, p, q);
+    o = oo[0];
+}
+
+template <int STAGE>
+__global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles, int tiles_per_ray,
+                                                                 const float* __restrict__ rays_o,
+                                                                 const float* __restrict__ rays_d,
+                                                                 const double* __restrict__ z_vals, DevScene sc,
+                                                                 float* __restrict__ raw_out, float* __restrict__ act_ws) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    constexpr int RB = fwd_ring_floats(STAGE);
+    float* ring = fsm;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
+    float* stage = fsm + 2 * RB + wave * 256;
+    const int64_t tile_raw = (int64_t)blockIdx.x * 4 + wave;
+    const bool tvalid = tile_raw < n_tiles;
+    const int64_t tile = tvalid ? tile_raw : n_tiles - 1;
+    const int64_t ray = tile / tiles_per_ray;
+    const int64_t sidx = tile * 16 + p;
+
+    ring_load(ring, sc.packed[1] + XyzLay{32}.oW(0), (XyzLay{32}.oW(1) - XyzLay{32}.oW(0)) / 4, wave, lane);   // chunk 0
+
+    double pw[3];
+    {
+        const double z = z_vals[sidx];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pw[a] = (double)rays_o[ray * 3 + a] + (double)rays_d[ray * 3 + a] * z;
+    }
+    bool inb = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) inb = inb && (pw[a] < sc.hi[a]) && (pw[a] > sc.lo[a]);
+    const float pc = q == 0 ? (float)pw[0] : (q == 1 ? (float)pw[1] : (q == 2 ? (float)pw[2] : 0.f));
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)fsm;
+    unsigned w32 = lds0 + (p * 32 + 4 * q) * 4, w64 = lds0 + (p * 64 + 4 * q) * 4, w96 = lds0 + (p * 96 + 4 * q) * 4;
+    unsigned w128 = lds0 + (p * 128 + 4 * q) * 4, wq = lds0 + q * 16;
+    opaque(w32); opaque(w64); opaque(w96); opaque(w128); opaque(wq);
+
+    float* wsb = (act_ws != nullptr && tvalid) ? act_ws + (tile * ACT_SLOTS) * (int64_t)ACT_STRIDE : nullptr;
+    f32x4 occ = splat4(0.f), col = splat4(0.f);
+
+    f32x4 cm[2];
+    {
+        const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[1]);
+        gather8(v, sc.grid[1], q, cm[0], cm[1]);
+    }
+    __syncthreads();                                                                   // chunk 0 landed
+    mlp_xyz_ring<2, 0, RB, (STAGE >= 2 ? 64 : 0)>(sc.packed[1], STAGE >= 2 ? sc.packed[2] : nullptr, ring, pc, cm, occ, wsb,
+                                                   stage, w32, w96, w128, w32, wq, wave, lane, p, q);
+    if constexpr (STAGE >= 2) {
+        f32x4 cf[4];
+        {
+            const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[2]);
+            gather8(v, sc.grid[2], q, cf[0], cf[1]);
+        }
+        cf[2] = cm[0];
+        cf[3] = cm[1];
+        f32x4 of;
+        mlp_xyz_ring<4, 5, RB, (STAGE == 3 ? 32 : 0)>(sc.packed[2], STAGE == 3 ? sc.packed[3] : nullptr, ring, pc, cf, of,
+                                                      wsb ? wsb + ACT_STRIDE : nullptr, stage, w32, w96, w128, w64, wq, wave,
+                                                      lane, p, q);
+        occ[0] = of[0] + occ[0];                                                        // fine_occ + middle_occ
+    }
+    if constexpr (STAGE == 3) {
+        f32x4 cc[2];
+        {
+            const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[3]);
+            gather8(v, sc.grid[3], q, cc[0], cc[1]);
+        }
+        mlp_xyz_ring<2, 10, RB, 0>(sc.packed[3], nullptr, ring, pc, cc, col, wsb ? wsb + 2 * ACT_STRIDE : nullptr, stage,
+                                   w32, w96, w128, w32, wq, wave, lane, p, q);
+    }
+    if (q == 0 && tvalid) {                                                             // rows 0..3 live on q == 0 lanes
+        const float o = inb ? occ[0] : 100.f;                                           // Renderer.py:58
+        *reinterpret_cast<f32x4*>(raw_out + sidx * 4) = f32x4{col[0], col[1], col[2], o};
+    }
+}
+
 // raw2outputs_nerf_color on its own (common.py:256-297, occupancy branch): one wave per ray.
 __global__ __launch_bounds__(64) void composite_fwd_kernel(int S, const float* __restrict__ raw,
                                                            const double* __restrict__ z_vals,
@@ -389,6 +551,22 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
         ntl = 1;
     }
     int rc;
+    if (tpr > 0 && stage >= 1 && stage <= 3) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_fwd_ring_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, fwd_ring_lds_bytes(1)) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(render_fwd_ring_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, fwd_ring_lds_bytes(2)) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(render_fwd_ring_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, fwd_ring_lds_bytes(3)) != hipSuccess)
+                return -2;
+            attr_set = true;
+        }
+        const dim3 grid((unsigned)((n_units + 3) / 4)), block(256);
+        if (stage == 1) render_fwd_ring_kernel<1><<<grid, block, fwd_ring_lds_bytes(1), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws);
+        else if (stage == 2) render_fwd_ring_kernel<2><<<grid, block, fwd_ring_lds_bytes(2), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws);
+        else render_fwd_ring_kernel<3><<<grid, block, fwd_ring_lds_bytes(3), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws);
+        if (hipGetLastError() != hipSuccess) return -2;
+        return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st);
+    }
     switch (stage) {
         case 0: rc = launch_stage<0>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, sc, depth, var, rgb, raw, st); break;
         case 1: rc = launch_stage<1>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, sc, depth, var, rgb, raw, st); break;
