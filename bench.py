@@ -81,10 +81,13 @@ def make_rays(sc, n_rays, seed):
 def mapper_loss(depth, color, gt_depth, gt_color, stage, w_color=0.2):
     """Mapper.py:553-562: L1 depth over pixels with valid depth (+ w_color * L1 colour in the colour stage).
     Written with a multiplicative mask instead of boolean indexing: same sum, no device->host sync."""
-    m = (gt_depth > 0).to(depth.dtype)
-    loss = (torch.abs(gt_depth - depth) * m).sum()
+    m = gt_depth > 0
+    zero = torch.zeros((), dtype=depth.dtype, device=depth.device)
+    # sum over valid pixels of |gt - d|  ==  L1(sum) between the masked tensors (fused abs-diff-sum kernels)
+    loss = torch.nn.functional.l1_loss(torch.where(m, depth, zero), torch.where(m, gt_depth.to(depth.dtype), zero),
+                                       reduction='sum')
     if stage == 'color':
-        loss = loss + w_color * torch.abs(gt_color - color).sum()
+        loss = loss + w_color * torch.nn.functional.l1_loss(color, gt_color, reduction='sum')
     return loss
 
 
@@ -130,6 +133,7 @@ def main():
     ap.add_argument('--scene', default='room0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--torch-loss', action='store_true', help='compute the mapper loss with torch ops instead of the fused HIP loss')
     ap.add_argument('--eager', action='store_true', help='time the plain Python-driven step instead of hipGraph replays')
     args = ap.parse_args()
 
@@ -184,7 +188,10 @@ def main():
         ro.grad = None
         rd.grad = None
         depth, var, color = renderer.render_batch_ray(grids, model, rd, ro, dev, stage, gt_depth=gd)
-        loss = mapper_loss(depth, color, gd, gc, stage)
+        if args.torch_loss:
+            loss = mapper_loss(depth, color, gd, gc, stage)
+        else:
+            loss = E.losses.rgbd_loss(depth, color if stage == 'color' else None, gd, gc, 0.2)
         loss.backward()
         return loss
 
@@ -265,7 +272,7 @@ def main():
                                f"per GPU, render_batch_ray + mapper loss + backward (grads: grids, all decoder params, rays)",
                    "rays_per_gpu": args.rays, "samples_per_ray": S,
                    "parallelism": "1 GPU" if world == 1 else f"ray-sharded dp{world}, one bucketed RCCL all-reduce of leaf grads"},
-        "loss": float(loss.item()), "mode": mode,
+        "loss": float(loss.item()), "mode": mode, "loss_impl": "torch" if args.torch_loss else "fused HIP (losses.rgbd_loss)",
         "eager_rays_per_s": world * args.rays * eager_steps / eager_elapsed,
     }
     if events:

@@ -65,6 +65,10 @@ _SIGS = {
     "enslam_decoder_bwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
                                           c_void_p, c_void_p, POINTER(Grid), POINTER(c_void_p), c_void_p, c_void_p,
                                           c_void_p]),
+    "enslam_rgbd_loss_fwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,
+                                            c_void_p]),
+    "enslam_rgbd_loss_bwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,
+                                            c_void_p, c_void_p, c_void_p]),
     "enslam_voxel_index": (ctypes.c_int, [c_int64, c_void_p, POINTER(c_double), c_int32, c_int32, c_int32,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "enslam_ray_points": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(c_double),

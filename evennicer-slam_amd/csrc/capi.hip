@@ -289,6 +289,23 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
                               grad_packed, g_rays_o, g_rays_d, stream);
 }
 
+int enslam_rgbd_loss_fwd(int32_t n, const double* depth, const float* color, const float* gt_depth,
+                         const float* gt_color, float w_color, double* loss, void* stream) {
+    if (n < 0 || !loss || (n > 0 && (!depth || !gt_depth)) || ((color == nullptr) != (gt_color == nullptr)))
+        return ENSLAM_EINVAL;
+    return ens_launch_rgbd_loss(n, depth, color, gt_depth, gt_color, w_color, nullptr, loss, nullptr, nullptr,
+                                (hipStream_t)stream);
+}
+int enslam_rgbd_loss_bwd(int32_t n, const double* depth, const float* color, const float* gt_depth,
+                         const float* gt_color, float w_color, const double* g_loss, double* g_depth, float* g_color,
+                         void* stream) {
+    if (n < 0 || !g_loss || (n > 0 && (!depth || !gt_depth || !g_depth)) || ((color == nullptr) != (gt_color == nullptr)))
+        return ENSLAM_EINVAL;
+    if (n == 0) return ENSLAM_OK;
+    return ens_launch_rgbd_loss(n, depth, color, gt_depth, gt_color, w_color, g_loss, nullptr, g_depth, g_color,
+                                (hipStream_t)stream);
+}
+
 int enslam_voxel_index(int64_t n_points, const double* points, const double* bound_host, int32_t D, int32_t H,
                        int32_t W, int32_t* ix, int32_t* iy, int32_t* iz, float* fx, float* fy, float* fz,
                        void* stream) {

@@ -32,6 +32,8 @@ int ens_launch_convert(const ConvJob& job, bool to_voxel_major, hipStream_t st);
 int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
                       const double* bound, const float* t_lin, const double* t_surf, int lindisp,
                       const float* t_rand, float* scratch, int dmax_given, double* z, hipStream_t st);
+int ens_launch_rgbd_loss(int n, const double* depth, const float* color, const float* gd, const float* gc, float w,
+                         const double* g_loss, double* loss, double* g_depth, float* g_color, hipStream_t st);
 int ens_launch_ray_points(int n_rays, int S, const float* ro, const float* rd, const double* z, const double* bound,
                           double* pts, uint8_t* mask, hipStream_t st);
 int ens_launch_voxel_index(int64_t n, const double* pts, const double* bound, int D, int H, int W, int* ix, int* iy,

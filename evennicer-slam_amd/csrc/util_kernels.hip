@@ -98,6 +98,53 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
     if (lane < S) zout[(int64_t)ray * S + lane] = z;
 }
 
+// ------------------------------------------------------------------ mapper RGB-D loss (Mapper.py:553-562)
+__global__ __launch_bounds__(1024) void rgbd_loss_fwd_kernel(int n, const double* __restrict__ depth,
+                                                             const float* __restrict__ color,
+                                                             const float* __restrict__ gd, const float* __restrict__ gc,
+                                                             float w, double* __restrict__ loss) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float g = gd[i];
+        if (g > 0.f) acc += fabs((double)g - depth[i]);
+        if (color != nullptr) {
+            float c = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) c += fabsf(gc[i * 3 + a] - color[i * 3 + a]);
+            acc += (double)(w * c);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        acc = red[threadIdx.x];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (threadIdx.x == 0) loss[0] = acc;
+    }
+}
+ENS_DEV float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+__global__ __launch_bounds__(256) void rgbd_loss_bwd_kernel(int n, const double* __restrict__ depth,
+                                                            const float* __restrict__ color,
+                                                            const float* __restrict__ gd, const float* __restrict__ gc,
+                                                            float w, const double* __restrict__ g_loss,
+                                                            double* __restrict__ g_depth, float* __restrict__ g_color) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double g = g_loss[0];
+    const float t = gd[i];
+    const double diff = (double)t - depth[i];
+    g_depth[i] = t > 0.f ? (diff > 0.0 ? -g : (diff < 0.0 ? g : 0.0)) : 0.0;      // d|gt-d|/dd = -sign(gt-d)
+    if (color != nullptr && g_color != nullptr) {
+        const float gw = (float)g * w;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g_color[i * 3 + a] = -gw * sgnf(gc[i * 3 + a] - color[i * 3 + a]);
+    }
+}
+
 // ------------------------------------------------------------------ parity helpers
 __global__ void ray_points_kernel(int n_rays, int S, const float* __restrict__ ro, const float* __restrict__ rd,
                                   const double* __restrict__ z, double lo0, double hi0, double lo1, double hi1,
@@ -230,6 +277,16 @@ int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const 
     sample_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(n_rays, n_lin, gd ? n_surf : 0, ro, rd, gd, b[0], b[1],
                                                                  b[2], b[3], b[4], b[5], t_lin, t_surf, lindisp,
                                                                  t_rand, scratch, z);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_rgbd_loss(int n, const double* depth, const float* color, const float* gd, const float* gc, float w,
+                         const double* g_loss, double* loss, double* g_depth, float* g_color, hipStream_t st) {
+    if (g_loss == nullptr) {
+        rgbd_loss_fwd_kernel<<<1, 1024, 0, st>>>(n, depth, color, gd, gc, w, loss);
+    } else if (n > 0) {
+        rgbd_loss_bwd_kernel<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(n, depth, color, gd, gc, w, g_loss, g_depth, g_color);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -179,6 +179,16 @@ int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const f
 int enslam_composite_fwd(int32_t n_rays, int32_t n_samples, const float *raw, const double *z_vals, double *depth,
                          double *var, float *rgb, float *weights, void *stream);
 
+/* Mapper's RGB-D loss, Mapper.py:553-562:  sum_{gt_depth>0} |gt_depth - depth| + w_color * sum |gt_color - color|
+ * (colour term only when color/gt_color are given, i.e. in the colour stage).  One kernel each way, deterministic
+ * single-block reduction (n <= ray_batch_size).  loss: float64 [1]; g_loss: float64 [1] upstream gradient (device);
+ * g_depth float64 [n], g_color float32 [n,3] (NULL when there is no colour term). */
+int enslam_rgbd_loss_fwd(int32_t n, const double *depth, const float *color, const float *gt_depth,
+                         const float *gt_color, float w_color, double *loss, void *stream);
+int enslam_rgbd_loss_bwd(int32_t n, const double *depth, const float *color, const float *gt_depth,
+                         const float *gt_color, float w_color, const double *g_loss, double *g_depth,
+                         float *g_color, void *stream);
+
 /* Parity helper: base voxel index and fractions the gather uses for points p float64 [P,3]
  * (normalize_3d_coordinate, common.py:342-357, then ATen grid_sampler unnormalize/clip/floor). */
 int enslam_voxel_index(int64_t n_points, const double *points, const double *bound_host, int32_t D, int32_t H,

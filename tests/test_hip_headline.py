@@ -161,3 +161,24 @@ def test_graphed_step_matches_eager(room0):
         leaves['grid_color'].mul_(0.5)
     l2 = gs.replay().item()
     assert abs(l2 - loss_e) > 1e-6 * abs(loss_e)
+
+
+def test_fused_rgbd_loss_matches_torch(room0):
+    """losses.rgbd_loss == Mapper.py:553-562 (torch formulation), values and gradients."""
+    import evennicer_slam_amd as E
+    torch.manual_seed(0)
+    n = 1000
+    depth = (torch.rand(n, dtype=torch.float64, device='cuda') * 3).requires_grad_(True)
+    color = torch.rand(n, 3, device='cuda').requires_grad_(True)
+    gd = torch.rand(n, device='cuda') * 3
+    gd[::9] = 0
+    gc = torch.rand(n, 3, device='cuda')
+    for use_color in (True, False):
+        l1 = E.losses.rgbd_loss(depth, color if use_color else None, gd, gc, 0.2)
+        g1 = torch.autograd.grad(l1 * 1.5, [depth] + ([color] if use_color else []))
+        m = gd > 0
+        l2 = torch.abs(gd[m] - depth[m]).sum() + (0.2 * torch.abs(gc - color).sum() if use_color else 0)
+        g2 = torch.autograd.grad(l2 * 1.5, [depth] + ([color] if use_color else []))
+        assert abs(l1.item() - l2.item()) < 1e-6 * abs(l2.item())
+        for a, b in zip(g1, g2):
+            assert torch.allclose(a, b.to(a.dtype), rtol=1e-6, atol=1e-7)
