@@ -9,17 +9,22 @@ bool is_xyz(int kind) { return kind == ENSLAM_MLP_MIDDLE || kind == ENSLAM_MLP_F
 int cdim(int kind) { return kind == ENSLAM_MLP_FINE ? 64 : 32; }
 int nout(int kind) { return kind == ENSLAM_MLP_COLOR ? 4 : 1; }
 
-float* g_seg_packed = nullptr;     // packed buffer recorded in segments built next (multi-decoder jobs)
+int g_seg_dec = 0;                  // decoder slot recorded in segments built next (multi-decoder jobs)
 
 void add(PackJob& j, float* src, int off, int rows, int cols, int src_ld, int dst_ld, int tr) {
     if (src == nullptr || j.n >= ENS_MAX_SEGS) return;
-    j.seg[j.n++] = PackSeg{src, g_seg_packed, off, rows, cols, src_ld, dst_ld, tr};
+    j.seg[j.n++] = PackSeg{src, off, (unsigned short)rows, (unsigned short)cols, (unsigned short)src_ld,
+                           (unsigned short)dst_ld, (unsigned char)tr, (unsigned char)g_seg_dec};
+}
+void clear_job(PackJob& j) {
+    j.n = 0;
+    for (int i = 0; i < 4; ++i) j.packed[i] = nullptr;
 }
 
 // Build the segment table of one decoder.  `with_transposed` adds the backward-only copies.
 // Returns false when a required pointer is missing.
 bool build_job(int kind, const enslam_mlp_params& P, bool with_transposed, PackJob& j, bool append = false) {
-    if (!append) j.n = 0;
+    if (!append) clear_job(j);
     const int n0 = j.n;
     if (is_xyz(kind)) {
         const XyzLay L{cdim(kind)};
@@ -126,16 +131,17 @@ int enslam_pack_mlp(int kind, const enslam_mlp_params* params, float* packed, vo
 
 int enslam_pack_mlp_multi(int32_t n, const int32_t* kinds, const enslam_mlp_params* params, float* const* packed,
                           void* stream) {
-    if (n < 0 || n > 2) return ENSLAM_EINVAL;
+    if (n < 0 || n > 3) return ENSLAM_EINVAL;
     if (n == 0) return ENSLAM_OK;
     if (!kinds || !params || !packed) return ENSLAM_EINVAL;
     PackJob job;
-    job.n = 0;
+    clear_job(job);
     for (int i = 0; i < n; ++i) {
         if (!packed[i]) return ENSLAM_EINVAL;
-        g_seg_packed = packed[i];
+        g_seg_dec = i;
+        job.packed[i] = packed[i];
         const bool ok = build_job(kinds[i], params[i], true, job, true);
-        g_seg_packed = nullptr;
+        g_seg_dec = 0;
         if (!ok) return ENSLAM_EINVAL;
     }
     return ens_launch_pack(job, nullptr, false, (hipStream_t)stream);
@@ -155,37 +161,75 @@ int enslam_unpack_mlp_grads_multi(int32_t n, const int32_t* kinds, const float* 
     if (n == 0) return ENSLAM_OK;
     if (!kinds || !packed_grads || !grads) return ENSLAM_EINVAL;
     PackJob job;
-    job.n = 0;
+    clear_job(job);
     for (int i = 0; i < n; ++i) {
         if (!packed_grads[i] || (!is_xyz(kinds[i]) && kinds[i] != ENSLAM_MLP_COARSE)) return ENSLAM_EINVAL;
-        g_seg_packed = const_cast<float*>(packed_grads[i]);
+        g_seg_dec = i;
+        job.packed[i] = const_cast<float*>(packed_grads[i]);
         build_job(kinds[i], grads[i], false, job, true);
     }
-    g_seg_packed = nullptr;
+    g_seg_dec = 0;
     return ens_launch_pack(job, nullptr, true, (hipStream_t)stream);
 }
 
-int enslam_grids_convert(int32_t n, const float* const* src, float* const* dst, const int64_t* n_voxels,
-                         int32_t to_voxel_major, void* stream) {
-    if (n < 0 || n > 4) return ENSLAM_EINVAL;
-    if (n == 0) return ENSLAM_OK;
-    if (!src || !dst || !n_voxels) return ENSLAM_EINVAL;
-    ConvJob job;
+namespace {
+bool make_conv_job(int32_t n, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                   const uint8_t* const* need, uint8_t* const* valid, bool src_required, ConvJob& job) {
+    if (n < 0 || n > 4 || !dst || !n_voxels || (src_required && !src)) return false;
     job.n = n;
     int begin = 0;
     for (int i = 0; i < 4; ++i) {
         job.block_begin[i] = begin;
+        job.src[i] = nullptr; job.dst[i] = nullptr; job.V[i] = 0; job.need[i] = nullptr; job.valid[i] = nullptr;
         if (i < n) {
-            if (!src[i] || !dst[i] || n_voxels[i] < 0) return ENSLAM_EINVAL;
-            job.src[i] = src[i]; job.dst[i] = dst[i]; job.V[i] = n_voxels[i];
+            if ((src_required && !src[i]) || !dst[i] || n_voxels[i] < 0) return false;
+            job.src[i] = src ? src[i] : nullptr; job.dst[i] = dst[i]; job.V[i] = n_voxels[i];
+            job.need[i] = need ? need[i] : nullptr;
+            job.valid[i] = valid ? valid[i] : nullptr;
             begin += (int)((n_voxels[i] + 63) / 64);
-        } else {
-            job.src[i] = nullptr; job.dst[i] = nullptr; job.V[i] = 0;
         }
     }
     job.block_begin[4] = begin;
     for (int i = n; i < 4; ++i) job.block_begin[i] = begin;
+    return true;
+}
+}  // namespace
+
+int enslam_grids_convert(int32_t n, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                         int32_t to_voxel_major, void* stream) {
+    if (n == 0) return ENSLAM_OK;
+    ConvJob job;
+    if (!make_conv_job(n, src, dst, n_voxels, nullptr, nullptr, true, job)) return ENSLAM_EINVAL;
     return ens_launch_convert(job, to_voxel_major != 0, (hipStream_t)stream);
+}
+
+int enslam_grids_convert_sparse(int32_t n, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                                const uint8_t* const* need, uint8_t* const* valid, int32_t to_voxel_major,
+                                void* stream) {
+    if (n == 0) return ENSLAM_OK;
+    if (!need || n < 0 || n > 4) return ENSLAM_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (!need[i]) return ENSLAM_EINVAL;
+    ConvJob job;
+    if (!make_conv_job(n, src, dst, n_voxels, need, valid, true, job)) return ENSLAM_EINVAL;
+    return ens_launch_convert(job, to_voxel_major != 0, (hipStream_t)stream);
+}
+
+int enslam_zero_blocks(int32_t n, float* const* dst, const int64_t* n_voxels, const uint8_t* const* need,
+                       void* stream) {
+    if (n == 0) return ENSLAM_OK;
+    ConvJob job;
+    if (!make_conv_job(n, nullptr, dst, n_voxels, need, nullptr, false, job)) return ENSLAM_EINVAL;
+    return ens_launch_zero_blocks(job, (hipStream_t)stream);
+}
+
+int enslam_mark_blocks(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                       const double* z_vals, const enslam_scene* scene, uint8_t* const* flags, void* stream) {
+    if (n_rays < 0 || n_samples < 1 || stage < 0 || stage > 3) return ENSLAM_EINVAL;
+    if (n_rays == 0) return ENSLAM_OK;
+    DevScene d;
+    if (!to_dev_scene(scene, d) || !rays_o || !rays_d || !z_vals || !flags) return ENSLAM_EINVAL;
+    return ens_launch_mark_blocks(stage, n_rays, n_samples, rays_o, rays_d, z_vals, d, flags, (hipStream_t)stream);
 }
 
 int enslam_grid_to_voxel_major(const float* src, float* dst, int64_t n_voxels, void* stream) {

@@ -6,22 +6,24 @@
 
 // one segment of a decoder re-layout: dst[r*dst_ld + c] = T ? src[c*src_ld + r] : src[r*src_ld + c]
 struct PackSeg {
-    float* src;          // caller tensor (input of pack, output of unpack)
-    float* packed;       // packed buffer of this segment's decoder (multi-decoder jobs); NULL = kernel argument
-    int off;             // float offset in the packed buffer
-    int rows, cols;      // extent in packed orientation
-    int src_ld, dst_ld;
-    int transpose;
+    float* src;                              // caller tensor (input of pack, output of unpack)
+    int off;                                 // float offset in the packed buffer
+    unsigned short rows, cols;               // extent in packed orientation
+    unsigned short src_ld, dst_ld;
+    unsigned char transpose, dec;            // dec: index into PackJob::packed
 };
-#define ENS_MAX_SEGS 80
+#define ENS_MAX_SEGS 120
 struct PackJob {
     PackSeg seg[ENS_MAX_SEGS];
+    float* packed[4];                        // packed buffers of the decoders of this job
     int n;
 };
 struct ConvJob {                 // up to 4 grids converted in one launch
     const float* src[4];
     float* dst[4];
     int64_t V[4];
+    const uint8_t* need[4];      // sparse path: per-64-voxel-block flags (null: dense)
+    uint8_t* valid[4];           // sparse to-voxel-major: blocks already converted
     int block_begin[5];
     int n;
 };
@@ -29,6 +31,9 @@ struct ConvJob {                 // up to 4 grids converted in one launch
 int ens_launch_pack(const PackJob& job, float* packed, bool unpack, hipStream_t st);
 int ens_launch_transpose(const float* src, float* dst, int64_t n_vox, bool to_voxel_major, hipStream_t st);
 int ens_launch_convert(const ConvJob& job, bool to_voxel_major, hipStream_t st);
+int ens_launch_zero_blocks(const ConvJob& job, hipStream_t st);
+int ens_launch_mark_blocks(int stage, int n_rays, int S, const float* ro, const float* rd, const double* z,
+                           const DevScene& sc, uint8_t* const* flags, hipStream_t st);
 int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
                       const double* bound, const float* t_lin, const double* t_surf, int lindisp,
                       const float* t_rand, float* scratch, int dmax_given, double* z, hipStream_t st);

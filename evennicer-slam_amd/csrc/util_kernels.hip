@@ -185,8 +185,66 @@ __global__ __launch_bounds__(256) void convert_kernel(ConvJob job, int to_vm) {
 #pragma unroll
     for (int i = 1; i < 4; ++i) g = (i < job.n && (int)blockIdx.x >= job.block_begin[i]) ? i : g;
     const int64_t blk = blockIdx.x - job.block_begin[g];
+    const uint8_t* need = job.need[g];
+    if (need != nullptr) {                                   // sparse path (block-uniform decisions)
+        const bool needed = need[blk] != 0;
+        if (to_vm) {
+            uint8_t* valid = job.valid[g];
+            if (!needed || (valid != nullptr && valid[blk] != 0)) return;
+            to_vm_block(job.src[g], job.dst[g], job.V[g], blk);
+            if (valid != nullptr && threadIdx.x == 0) valid[blk] = 1;
+            return;
+        }
+        if (!needed) {                                       // untouched block of a gradient: zeros, nothing read
+            const int64_t v0 = blk * 64, V = job.V[g];
+            float* dst = job.dst[g];
+            const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+            for (int cc = ty; cc < 32; cc += 4)
+                if (v0 + tx < V) dst[(int64_t)cc * V + v0 + tx] = 0.f;
+            return;
+        }
+    }
     if (to_vm) to_vm_block(job.src[g], job.dst[g], job.V[g], blk);
     else from_vm_block(job.src[g], job.dst[g], job.V[g], blk);
+}
+
+// zero the flagged 64-voxel blocks (8 KB each) of voxel-major buffers
+__global__ __launch_bounds__(256) void zero_blocks_kernel(ConvJob job) {
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) g = (i < job.n && (int)blockIdx.x >= job.block_begin[i]) ? i : g;
+    const int64_t blk = blockIdx.x - job.block_begin[g];
+    if (job.need[g] != nullptr && job.need[g][blk] == 0) return;
+    const int64_t v0 = blk * 64, V = job.V[g];
+    f32x4* dst = reinterpret_cast<f32x4*>(job.dst[g] + v0 * 32);
+    const int64_t n4 = (V - v0 < 64 ? V - v0 : 64) * 8;
+    for (int e = threadIdx.x; e < n4; e += 256) dst[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// flag the blocks holding the 8 (clamped) corners of every sample in every grid the stage reads
+__global__ __launch_bounds__(256) void mark_blocks_kernel(int64_t n_samples_total, int S, const float* __restrict__ ro,
+                                                          const float* __restrict__ rd, const double* __restrict__ z,
+                                                          DevScene sc, int kmask, uint8_t* f0, uint8_t* f1, uint8_t* f2,
+                                                          uint8_t* f3) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_samples_total) return;
+    const int64_t ray = i / S;
+    double pw[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pw[a] = (double)ro[ray * 3 + a] + (double)rd[ray * 3 + a] * z[i];
+    uint8_t* fl[4] = {f0, f1, f2, f3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!((kmask >> k) & 1) || fl[k] == nullptr) continue;
+        const Vox v = make_vox(pw, k == 0 ? sc.clo : sc.lo, k == 0 ? sc.chi : sc.hi, sc.grid[k]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            int64_t idx; float w;
+            corner(v, sc.grid[k], c, idx, w);
+            fl[k][idx >> 6] = 1;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void to_voxel_major_kernel(const float* __restrict__ src, float* __restrict__ dst,
@@ -238,10 +296,10 @@ ENS_DEV void from_vm_block(const float* __restrict__ src, float* __restrict__ ds
 __global__ __launch_bounds__(256) void pack_kernel(PackJob job, float* __restrict__ packed, int unpack) {
     const PackSeg s = job.seg[blockIdx.x];
     const int n = s.rows * s.cols;
-    for (int e = threadIdx.x; e < n; e += 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < n; e += 256 * gridDim.y) {
         const int r = e / s.cols, c = e - r * s.cols;
         float* src = s.src + (s.transpose ? (int64_t)c * s.src_ld + r : (int64_t)r * s.src_ld + c);
-        float* dst = (s.packed ? s.packed : packed) + s.off + r * s.dst_ld + c;
+        float* dst = (job.packed[s.dec] ? job.packed[s.dec] : packed) + s.off + r * s.dst_ld + c;
         if (unpack) *src = *dst; else *dst = *src;
     }
 }
@@ -250,7 +308,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackJob job, float* __restric
 
 int ens_launch_pack(const PackJob& job, float* packed, bool unpack, hipStream_t st) {
     if (job.n <= 0) return 0;
-    pack_kernel<<<dim3(job.n), dim3(256), 0, st>>>(job, packed, unpack ? 1 : 0);
+    pack_kernel<<<dim3(job.n, 4), dim3(256), 0, st>>>(job, packed, unpack ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -265,6 +323,22 @@ int ens_launch_transpose(const float* src, float* dst, int64_t V, bool to_vm, hi
 int ens_launch_convert(const ConvJob& job, bool to_vm, hipStream_t st) {
     if (job.n <= 0 || job.block_begin[job.n] <= 0) return 0;
     convert_kernel<<<dim3(job.block_begin[job.n]), dim3(256), 0, st>>>(job, to_vm ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_zero_blocks(const ConvJob& job, hipStream_t st) {
+    if (job.n <= 0 || job.block_begin[job.n] <= 0) return 0;
+    zero_blocks_kernel<<<dim3(job.block_begin[job.n]), dim3(256), 0, st>>>(job);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_mark_blocks(int stage, int n_rays, int S, const float* ro, const float* rd, const double* z,
+                           const DevScene& sc, uint8_t* const* flags, hipStream_t st) {
+    const int64_t n = (int64_t)n_rays * S;
+    if (n <= 0) return 0;
+    const int kmask = stage == 0 ? 1 : (stage == 1 ? 2 : (stage == 2 ? 6 : 14));
+    mark_blocks_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, S, ro, rd, z, sc, kmask, flags[0], flags[1],
+                                                                               flags[2], flags[3]);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

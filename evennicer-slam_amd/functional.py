@@ -130,8 +130,8 @@ _pack_caches = weakref.WeakKeyDictionary()      # decoder module -> _PackCache
 
 
 def packed_decoders(items):
-    """Packed forms of several decoders [(module, kind, params)]; stale ones are rebuilt with ONE zero-fill and
-    at most two launches (a launch re-lays-out up to two decoders)."""
+    """Packed forms of several decoders [(module, kind, params)]; stale ones are rebuilt with ONE zero-fill and ONE
+    launch (up to three decoders per launch)."""
     out, stale = [], []
     for i, (dec, kind, ps) in enumerate(items):
         cache = _pack_caches.get(dec)
@@ -152,8 +152,8 @@ def packed_decoders(items):
             _check_params(items[i][1], items[i][2])
             cache.key, cache.packed = key, pieces[j]
             out[i] = pieces[j]
-        for g0 in range(0, len(stale), 2):
-            grp = stale[g0:g0 + 2]
+        for g0 in range(0, len(stale), 3):
+            grp = stale[g0:g0 + 3]
             n = len(grp)
             kinds, structs, ptrs = (ctypes.c_int32 * n)(), (L.MlpParams * n)(), (ctypes.c_void_p * n)()
             for j, (i, cache, key) in enumerate(grp):
@@ -187,7 +187,7 @@ class _GridCache:
             raise L.EnslamError(f"feature grid must be float32 [1,32,D,H,W], got {tuple(g.shape)} {g.dtype}")
         _require_hip(g, "feature grids")
         e = self.items.get(id(g))
-        if e is not None and e[0]() is g and e[1] == g._version:
+        if e is not None and e[0]() is g and e[1] == g._version and len(e) == 3:
             return e[2]
         src = g.detach()
         if not src.is_contiguous():
@@ -206,7 +206,7 @@ class _GridCache:
         out, miss = [], []
         for i, g in enumerate(grids):
             e = self.items.get(id(g))
-            if e is not None and e[0]() is g and e[1] == g._version:
+            if e is not None and e[0]() is g and e[1] == g._version and len(e) == 3:
                 out.append(e[2])
             else:
                 out.append(None)
@@ -233,6 +233,36 @@ class _GridCache:
                 g = grids[i]
                 key, items = id(g), self.items
                 items[key] = (weakref.ref(g, lambda _r, key=key, items=items: items.pop(key, None)), g._version, out[i])
+        return out
+
+
+    def get_many_sparse(self, grids, need):
+        """Voxel-major copies in which (at least) the 64-voxel blocks flagged in need[i] (uint8 tensors) are valid.
+        Every entry carries a `valid` bitmap; one launch converts the blocks that are needed and not yet valid."""
+        n = len(grids)
+        srcs, dsts, vs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)()
+        needs, valids, out, keep = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), [], []
+        for i, g in enumerate(grids):
+            e = self.items.get(id(g))
+            if e is not None and e[0]() is g and e[1] == g._version and len(e) == 4:
+                vm, valid = e[2], e[3]
+            else:
+                if g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32 or g.dtype != torch.float32:
+                    raise L.EnslamError(f"feature grid must be float32 [1,32,D,H,W], got {tuple(g.shape)} {g.dtype}")
+                _require_hip(g, "feature grids")
+                V = g.shape[2] * g.shape[3] * g.shape[4]
+                vm = torch.empty((V, 32), dtype=torch.float32, device=g.device)
+                valid = torch.zeros((V + 63) // 64, dtype=torch.uint8, device=g.device)
+                key, items = id(g), self.items
+                items[key] = (weakref.ref(g, lambda _r, key=key, items=items: items.pop(key, None)), g._version, vm, valid)
+            src = g.detach()
+            src = src if src.is_contiguous() else src.contiguous()
+            keep.append(src)
+            srcs[i], dsts[i], vs[i] = src.data_ptr(), vm.data_ptr(), vm.shape[0]
+            needs[i], valids[i] = need[i].data_ptr(), valid.data_ptr()
+            out.append(vm)
+        L.check(L.lib().enslam_grids_convert_sparse(n, srcs, dsts, vs, needs, valids, 1, _stream()),
+                "enslam_grids_convert_sparse")
         return out
 
 
@@ -303,11 +333,23 @@ class _RenderFn(torch.autograd.Function):
                                        _ptr(plan.t_lin), _ptr(plan.t_surf), plan.lindisp, _ptr(t_rand),
                                        _ptr(scratch), int(plan.depth_max is not None), _ptr(z), st),
                 "enslam_sample_rays")
-        grids_vm, dims, packed = {}, {}, {}
+        # blocks of 64 voxels this batch touches, per grid (one zeroed byte buffer for all grids)
+        dims = {k: tuple(g.shape[2:]) for k, g in zip(plan.kinds, grids)}
+        nblk = [(dims[k][0] * dims[k][1] * dims[k][2] + 63) // 64 for k in plan.kinds]
+        flag_buf = torch.zeros(sum(nblk), dtype=torch.uint8, device=dev)
+        flags = list(flag_buf.split(nblk))
+        fptr = (ctypes.c_void_p * 4)()
+        msc = L.Scene()
+        msc.bound, msc.coarse_bound = plan.bound6, plan.coarse_bound6
+        for k, fl in zip(plan.kinds, flags):
+            fptr[k] = fl.data_ptr()
+            msc.grids[k].D, msc.grids[k].H, msc.grids[k].W = dims[k]
+        L.check(lib.enslam_mark_blocks(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(msc), fptr, st),
+                "enslam_mark_blocks")
+        grids_vm, packed = {}, {}
         po, items = nk, []
-        for k, g, vm in zip(plan.kinds, grids, _grid_cache.get_many(grids)):
+        for k, g, vm in zip(plan.kinds, grids, _grid_cache.get_many_sparse(grids, flags)):
             grids_vm[k] = vm
-            dims[k] = tuple(g.shape[2:])
             items.append((plan.decoders[k], k, tensors[po:po + plan.n_params[k]]))
             po += plan.n_params[k]
         for k, pk in zip(plan.kinds, packed_decoders(items)):
@@ -326,7 +368,7 @@ class _RenderFn(torch.autograd.Function):
         L.check(lib.enslam_render_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                       _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), st), "enslam_render_fwd")
         ctx.plan, ctx.S, ctx.dims = plan, S, dims
-        ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act)
+        ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act, flags)
         ctx.grid_shapes = [tuple(g.shape) for g in grids]
         ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
         return depth, var, rgb
@@ -335,7 +377,7 @@ class _RenderFn(torch.autograd.Function):
     def backward(ctx, g_depth, g_var, g_rgb):
         lib = L.lib()
         plan, S = ctx.plan, ctx.S
-        ro, rd, z, raw, depth, grids_vm, packed, act = ctx.keep
+        ro, rd, z, raw, depth, grids_vm, packed, act, flags = ctx.keep
         N, dev, st = ro.shape[0], ro.device, _stream()
         nk = len(plan.kinds)
         needs = ctx.needs_input_grad            # (plan, ro, rd, gd, t_rand, grids..., params...)
@@ -368,24 +410,35 @@ class _RenderFn(torch.autograd.Function):
         for k in plan.kinds:
             sizes.append(lib.enslam_packed_grad_floats(k) if need_par[k] else 0)
         sizes.append(6 * N if need_rays else 0)
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         offs = [0]
         for n in sizes:
             offs.append(offs[-1] + n)
-        base = flat.data_ptr()
+        # grid-gradient accumulators: only the blocks this batch touches are zeroed (and later transposed back);
+        # decoder / ray accumulators are small and zero-filled whole
+        n_grid = offs[nk]
+        gbuf = torch.empty(max(n_grid, 1), dtype=torch.float32, device=dev)
+        zbuf = torch.zeros(max(offs[-1] - n_grid, 1), dtype=torch.float32, device=dev)
+        gbase, zbase = gbuf.data_ptr(), zbuf.data_ptr() - 4 * n_grid
         g_grids_vm, g_packed = {}, {}
-        for i, k in enumerate(plan.kinds):
-            if need_grid[k]:
-                g_grids_vm[k] = base + 4 * offs[i]
+        zl = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k]]
+        if zl:
+            n = len(zl)
+            dsts, vs, need_ptrs = (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), (ctypes.c_void_p * n)()
+            for j, (i, k) in enumerate(zl):
+                g_grids_vm[k] = gbase + 4 * offs[i]
                 gg[k].data = g_grids_vm[k]
+                dsts[j], vs[j], need_ptrs[j] = g_grids_vm[k], sizes[i] // 32, flags[i].data_ptr()
+            L.check(lib.enslam_zero_blocks(n, dsts, vs, need_ptrs, st), "enslam_zero_blocks")
+        for i, k in enumerate(plan.kinds):
             if need_par[k]:
-                g_packed[k] = base + 4 * offs[nk + i]
+                g_packed[k] = zbase + 4 * offs[nk + i]
                 gpk[k] = g_packed[k]
         g_ro = g_rd = None
         p_ro = p_rd = ctypes.c_void_p(0)
         if need_rays:
-            g_ro = flat[offs[2 * nk]:offs[2 * nk] + 3 * N].view(N, 3)
-            g_rd = flat[offs[2 * nk] + 3 * N:offs[2 * nk] + 6 * N].view(N, 3)
+            r0 = offs[2 * nk] - n_grid
+            g_ro = zbuf[r0:r0 + 3 * N].view(N, 3)
+            g_rd = zbuf[r0 + 3 * N:r0 + 6 * N].view(N, 3)
             p_ro, p_rd = _ptr(g_ro), _ptr(g_rd)
         d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
         L.check(lib.enslam_composite_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
@@ -406,11 +459,12 @@ class _RenderFn(torch.autograd.Function):
         if conv:
             n = len(conv)
             srcs, dsts, vs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)()
+            need_ptrs = (ctypes.c_void_p * n)()
             for j, (i, k) in enumerate(conv):
                 g = torch.empty(ctx.grid_shapes[i], dtype=torch.float32, device=dev)
                 grid_out[k] = g
-                srcs[j], dsts[j], vs[j] = g_grids_vm[k], g.data_ptr(), sizes[i] // 32
-            L.check(lib.enslam_grids_convert(n, srcs, dsts, vs, 0, st), "enslam_grids_convert")
+                srcs[j], dsts[j], vs[j], need_ptrs[j] = g_grids_vm[k], g.data_ptr(), sizes[i] // 32, flags[i].data_ptr()
+            L.check(lib.enslam_grids_convert_sparse(n, srcs, dsts, vs, need_ptrs, None, 0, st), "enslam_grids_convert_sparse")
         for k in plan.kinds:
             out.append(grid_out.get(k))
         # decoder gradients: one flat buffer, views shaped like the parameters, one unpack launch
@@ -434,7 +488,7 @@ class _RenderFn(torch.autograd.Function):
         for k in plan.kinds:
             out += views_by_kind.get(k, [None] * plan.n_params[k])
         ctx.keep = None
-        del flat
+        del gbuf, zbuf
         return tuple(out)
 
 

@@ -90,8 +90,7 @@ size_t enslam_packed_grad_floats(int kind);
  * the backward).  `packed` must have been zero-filled once by the caller; padding is never written.
  * Replaces nothing in the reference (layout glue for decoder.py:149-159 parameters). */
 int enslam_pack_mlp(int kind, const enslam_mlp_params *params, float *packed, void *stream);
-/* The same for several decoders in ONE launch (host arrays of length n <= 2: the kernel argument holds at most
- * 80 re-layout segments, 37 per xyz decoder). */
+/* The same for several decoders in ONE launch (host arrays of length n <= 3). */
 int enslam_pack_mlp_multi(int32_t n, const int32_t *kinds, const enslam_mlp_params *params, float *const *packed,
                           void *stream);
 
@@ -110,6 +109,21 @@ int enslam_grid_from_voxel_major(const float *src, float *dst, int64_t n_voxels,
 /* The same for up to 4 grids in ONE launch (n <= 4; src/dst/n_voxels are host arrays of length n). */
 int enslam_grids_convert(int32_t n, const float *const *src, float *const *dst, const int64_t *n_voxels,
                          int32_t to_voxel_major, void *stream);
+
+/* Sparse layout path.  A batch touches only a few percent of a grid; blocks of 64 consecutive voxels are the unit.
+ * enslam_mark_blocks: flags[k][b] = 1 for every block of grid k (stage's grids) holding a corner that a sample of
+ *   the batch reads (flags: uint8 [ceil(V_k/64)], caller-zeroed; entries of unused grids may be NULL).
+ * enslam_grids_convert_sparse, to_voxel_major != 0: converts blocks with need && !valid and sets valid (valid: uint8
+ *   bitmap that lives with the voxel-major copy; zero it when the source grid changes).
+ *   to_voxel_major == 0 (gradients back to [32,V]): blocks with need are transposed, all others written as zeros.
+ * enslam_zero_blocks: zero-fills the flagged blocks of voxel-major buffers (gradient accumulators). */
+int enslam_mark_blocks(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                       const double *z_vals, const enslam_scene *scene, uint8_t *const *flags, void *stream);
+int enslam_grids_convert_sparse(int32_t n, const float *const *src, float *const *dst, const int64_t *n_voxels,
+                                const uint8_t *const *need, uint8_t *const *valid, int32_t to_voxel_major,
+                                void *stream);
+int enslam_zero_blocks(int32_t n, float *const *dst, const int64_t *n_voxels, const uint8_t *const *need,
+                       void *stream);
 
 /* Sample distances along rays.  Replaces Renderer.render_batch_ray lines 83-171
  * (src/utils/Renderer.py): near/far from gt_depth and the AABB exit, n_lin linear samples,

@@ -121,3 +121,22 @@ def test_in_place_grid_update_is_seen(tiny):
         c = renderer.render_batch_ray(g2, *args, gt_depth=rays['gt_depth'])[2]
     assert not torch.allclose(a, b)
     assert torch.allclose(a, c, rtol=1e-5, atol=1e-6)
+
+
+def test_sparse_layout_cache_fills_incrementally(tiny):
+    """The voxel-major copy converts only blocks a batch touches; a second batch with other rays on the SAME grid
+    version must convert its own blocks (valid bitmap), and eval_points (dense path) must still be right."""
+    s, bound, model, grids, rays, renderer = tiny
+    params, ogrids, obound, _ = tiny_scene()
+    g2 = {k: v.clone() for k, v in grids.items()}
+    ro, rd, gd = [torch.from_numpy(s[k]) for k in ("rays_o", "rays_d", "gt_depth")]
+    with torch.no_grad():
+        for sl in (slice(0, 8), slice(40, 64), slice(0, 64)):
+            d, v, c = renderer.render_batch_ray(g2, model, rays['rays_d'][sl], rays['rays_o'][sl], 'cuda:0', 'color',
+                                                gt_depth=rays['gt_depth'][sl])
+            d0, v0, c0 = R.render_batch_ray(params, ogrids, rd[sl], ro[sl], 'color', obound, gt_depth=gd[sl])
+            assert rel_err(d.cpu().numpy(), d0.numpy()) < 1e-4 and rel_err(c.cpu().numpy(), c0.numpy()) < 1e-4
+        p = (torch.rand(300, 3, dtype=torch.float64) - 0.5) * 2.0
+        raw = renderer.eval_points(p.cuda(), model, g2, 'color', 'cuda:0')
+        ref = R.eval_points(params, ogrids, p, 'color', obound)
+        assert rel_err(raw.cpu().numpy(), ref.numpy()) < 1e-4
