@@ -251,16 +251,22 @@ def main():
         ro.grad = None
         rd.grad = None
         _gcmod.collect()            # no autograd graph of an earlier (default-stream) step may stay alive
-        gstep = GraphedStep(local_step)
+        try:
+            gstep = GraphedStep(local_step)
+        except Exception as exc:    # never lose the measurement to a capture problem: time the eager loop instead
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); timing the eager step", file=sys.stderr)
+            gstep = None
+        if gstep is None:
+            elapsed, loss = timed(step, args.steps)
+        else:
+            def graph_step():
+                pre()
+                out = gstep.replay()
+                post()
+                return out
 
-        def graph_step():
-            pre()
-            out = gstep.replay()
-            post()
-            return out
-
-        mode = 'hipgraph'
-        elapsed, loss = timed(graph_step, args.steps)
+            mode = 'hipgraph'
+            elapsed, loss = timed(graph_step, args.steps)
 
     S = 48 if stage != 'coarse' else 32
     n_points = args.rays * S

@@ -25,30 +25,58 @@ def global_depth_max(gt_depth_local, group=None):
     return torch.cat([m, m * 1.2]).contiguous()
 
 
-def allreduce_gradients(tensors, group=None):
+def _touched_ranges(grads, group):
+    """For feature-grid gradients [1,C,D,H,W] (nonzero only where this step's rays passed): the union over ranks
+    of the touched range [lo, hi) of the flattened voxel index (z-major).  One small MAX all-reduce + one host
+    read; lets the bucket carry only that slab of every channel row instead of the whole grid."""
+    if not grads:
+        return []
+    dev = grads[0].device
+    stats = []
+    for g in grads:
+        V = g.shape[2] * g.shape[3] * g.shape[4]
+        prof = g.reshape(g.shape[1], V).abs().amax(dim=0) > 0                 # [V] touched by this rank
+        idx = torch.arange(V, device=dev)
+        lo = torch.where(prof, idx, torch.full_like(idx, V)).min()
+        hi = torch.where(prof, idx + 1, torch.zeros_like(idx)).max()
+        stats += [-lo, hi]                                                      # MAX-reduce both
+    st = torch.stack(stats).to(torch.int64)
+    dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)
+    vals = st.tolist()
+    return [(max(0, -vals[2 * i]), vals[2 * i + 1]) for i in range(len(grads))]
+
+
+def allreduce_gradients(tensors, group=None, compact_grids=True):
     """Sum `.grad` of the given leaf tensors over ranks through one flat bucket (one collective per step).
-    Leaves whose grad is None on this rank contribute zeros, so every rank issues the same collective."""
+    Leaves whose grad is None on this rank contribute zeros, so every rank issues the same collectives.
+    compact_grids: 5-D feature-grid gradients contribute only the slab of voxels touched on any rank."""
     tensors = [t for t in tensors if t is not None and t.requires_grad]
     if not tensors or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 0
     dev = tensors[0].device
-    sizes = [t.numel() for t in tensors]
+    for t in tensors:
+        if t.grad is None:
+            t.grad = torch.zeros_like(t)
+    grid_ids = [i for i, t in enumerate(tensors) if compact_grids and t.dim() == 5 and t.shape[0] == 1]
+    ranges = dict(zip(grid_ids, _touched_ranges([tensors[i].grad for i in grid_ids], group)))
+    views = []
+    for i, t in enumerate(tensors):
+        if i in ranges:
+            lo, hi = ranges[i]
+            V = t.shape[2] * t.shape[3] * t.shape[4]
+            views.append(t.grad.reshape(t.shape[1], V)[:, lo:max(hi, lo)])       # strided slab of every channel row
+        else:
+            views.append(t.grad.reshape(-1))
+    sizes = [v.numel() for v in views]
     bucket = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
     o = 0
-    for t, n in zip(tensors, sizes):
-        if t.grad is None:
-            bucket[o:o + n].zero_()
-        else:
-            bucket[o:o + n].copy_(t.grad.reshape(-1))
+    for v, n in zip(views, sizes):
+        bucket[o:o + n].view(v.shape).copy_(v)
         o += n
     dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     o = 0
-    for t, n in zip(tensors, sizes):
-        g = bucket[o:o + n].view_as(t)
-        if t.grad is None:
-            t.grad = g.clone()
-        else:
-            t.grad.copy_(g)
+    for v, n in zip(views, sizes):
+        v.copy_(bucket[o:o + n].view(v.shape))
         o += n
     return bucket.numel() * 4
 

@@ -82,6 +82,8 @@ def test_two_rank_sharded_step_matches_unsharded():
     assert np.array_equal(got, depth.detach().numpy())          # shards sample exactly like the whole batch
     for o in outs:
         assert o['nbytes'] > 0 and o['g_coarse_is_none_or_zero']
+        dense_bytes = 4 * (sum(grids[k].numel() for k in GRID_KEYS) + sum(v.numel() for v in params.values()))
+        assert o['nbytes'] < dense_bytes          # only the touched voxel slab of each grid travels
         ref = grids['grid_fine'].grad.numpy()
         assert np.abs(o['g_fine'] - ref).max() <= 1e-5 * np.abs(ref).max()
         ref = params['color_decoder.pts_linears.0.weight'].grad.numpy()
