@@ -262,8 +262,16 @@ int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
     DevScene d;
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
     if (!rays_o || !rays_d || !z_vals || !depth || !var || !rgb) return ENSLAM_EINVAL;
+    if (act_ws != nullptr)                               // the saved cell records hold the voxel index in 29 bits
+        for (int k = 1; k < 4; ++k)
+            if (d.grid[k].data && (int64_t)d.grid[k].D * d.grid[k].H * d.grid[k].W >= ACT_MAX_VOXELS) return ENSLAM_EUNSUPPORTED;
     return ens_launch_render_fwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, nullptr, 0, 1, d, depth, var,
                                  rgb, raw_out, stage == ENSLAM_STAGE_COARSE ? nullptr : act_ws, (hipStream_t)stream);
+}
+
+size_t enslam_grid_handoff_floats(int32_t stage, int32_t n_rays, int32_t n_samples) {
+    if (stage == ENSLAM_STAGE_COARSE || n_rays <= 0 || n_samples <= 0) return 0;
+    return (size_t)n_rays * (size_t)(n_samples / 16) * ACT_SLOTS * DG_STRIDE;
 }
 
 size_t enslam_activation_floats(int32_t stage, int32_t n_rays, int32_t n_samples) {
@@ -302,14 +310,15 @@ int enslam_composite_bwd(int32_t n_rays, int32_t n_samples, const float* raw, co
 
 int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                        const double* z_vals, const enslam_scene* scene, const float* d_raw, const float* act_ws,
-                       const enslam_grid* grad_grids, float* const* grad_packed, float* g_rays_o, float* g_rays_d,
-                       void* stream) {
+                       float* dgrid_ws, const enslam_grid* grad_grids, float* const* grad_packed, float* g_rays_o,
+                       float* g_rays_d, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
     DevScene d;
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
     if (!rays_o || !rays_d || !z_vals || !d_raw || !grad_grids || !grad_packed) return ENSLAM_EINVAL;
+    if (act_ws != nullptr && g_rays_o != nullptr && dgrid_ws == nullptr && stage != ENSLAM_STAGE_COARSE) return ENSLAM_EINVAL;
     DevGrid gg[4];
     for (int k = 0; k < 4; ++k) {
         gg[k] = DevGrid{grad_grids[k].data, d.grid[k].D, d.grid[k].H, d.grid[k].W};
@@ -317,7 +326,7 @@ int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const f
             (grad_grids[k].D != d.grid[k].D || grad_grids[k].H != d.grid[k].H || grad_grids[k].W != d.grid[k].W))
             return ENSLAM_EINVAL;
     }
-    return ens_launch_decoder_bwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, d_raw, act_ws, gg,
+    return ens_launch_decoder_bwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, d_raw, act_ws, dgrid_ws, gg,
                                   grad_packed, g_rays_o, g_rays_d, (hipStream_t)stream);
 }
 
@@ -325,12 +334,12 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
                       const double* z_vals, const enslam_scene* scene, const float* raw, const double* depth,
                       const double* g_depth, const double* g_var, const float* g_rgb, const enslam_grid* grad_grids,
                       float* const* grad_packed, float* g_rays_o, float* g_rays_d, float* d_raw, const float* act_ws,
-                      void* stream) {
+                      float* dgrid_ws, void* stream) {
     if (!g_depth && !g_var && !g_rgb) return ENSLAM_EINVAL;
     const int rc = enslam_composite_bwd(n_rays, n_samples, raw, z_vals, depth, g_depth, g_var, g_rgb, d_raw, stream);
     if (rc != ENSLAM_OK) return rc;
-    return enslam_decoder_bwd(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, d_raw, act_ws, grad_grids,
-                              grad_packed, g_rays_o, g_rays_d, stream);
+    return enslam_decoder_bwd(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, d_raw, act_ws, dgrid_ws,
+                              grad_grids, grad_packed, g_rays_o, g_rays_d, stream);
 }
 
 int enslam_rgbd_loss_fwd(int32_t n, const double* depth, const float* color, const float* gt_depth,

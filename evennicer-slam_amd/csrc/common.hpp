@@ -79,15 +79,22 @@ struct FeatLay {                // MLP_no_xyz (coarse): decoder.py:206-274
 
 // ----------------------------------------------------------------------------------------------
 // Activation workspace written by the forward for the backward (one block per 16-sample tile and decoder slot):
-//   tiles in the backward's LDS "deposit" layout, in the order of its slot  [EMB 6 | h2 2 | h0 2 | h1 2 | h3 2 | C ct]
+//   tiles in the backward's LDS "deposit" layout, in the order of its slot
+//   [EMB 6 | h2 2 | h0 2 | h1 2 | h3 2 | C ct | XYZ 1 (sample coordinates as features 0..2)]
 //   (address of (tile T, feature i, sample pt) = T*256 + (pt>>2)*64 + i*4 + (pt&3) floats), then h4 in register
 //   layout (2 tiles, lane-linear) and the ReLU masks (2 words per lane).
 // ----------------------------------------------------------------------------------------------
-constexpr int ACT_DEP_TILES_MAX = 18;                       // 14 + ct, ct <= 4
+constexpr int ACT_DEP_TILES_MAX = 19;                       // 14 + ct + 1, ct <= 4
 constexpr int ACT_H4 = ACT_DEP_TILES_MAX * 256;             // float offset of h4 (2 tiles)
 constexpr int ACT_MASK = ACT_H4 + 2 * 256;                  // float offset of the mask words (128 words)
-constexpr int ACT_STRIDE = ACT_MASK + 128;                  // floats per (tile, decoder slot)
+constexpr int ACT_VOX = ACT_MASK + 128;                     // float offset of the 16 cell records (vox_record)
+constexpr int ACT_STRIDE = ACT_VOX + 64;                    // floats per (tile, decoder slot)
+constexpr int64_t ACT_MAX_VOXELS = (int64_t)1 << 29;        // a cell record keeps the linear voxel index in 29 bits
 constexpr int ACT_SLOTS = 3;                                // decoder slots per tile: middle, fine, color
+// Hand-off from decoder_bwd_kernel to grid_bwd_kernel, per (tile, decoder slot): dC in register layout (2 tiles,
+// lane-linear) and the embedding's position gradient (one float4 per lane, meaningful on q == 0 lanes).
+constexpr int DG_DPE = 2 * 256;
+constexpr int DG_STRIDE = 3 * 256;
 
 // ----------------------------------------------------------------------------------------------
 // Scene description passed by value to kernels
@@ -147,6 +154,14 @@ ENS_DEV void corner(const Vox& v, const DevGrid& g, int k, int64_t& idx, float& 
     const float wz = dz ? v.fz : (1.f - v.fz);
     w = ok ? (wx * wy) * wz : 0.f;
     idx = ((int64_t)z * g.H + y) * g.W + x;
+}
+
+// The trilinear cell of a sample as the backward's scatter wants it: linear index of corner (0,0,0) in bits 0..28,
+// "the +1 neighbour exists" flags of x, y, z in bits 29..31, then the three fractions.
+ENS_DEV f32x4 vox_record(const Vox& v, const DevGrid& g) {
+    unsigned lin = (unsigned)((v.iz * g.H + v.iy) * g.W + v.ix);
+    lin |= (v.ix + 1 < g.W ? 1u << 29 : 0u) | (v.iy + 1 < g.H ? 1u << 30 : 0u) | (v.iz + 1 < g.D ? 1u << 31 : 0u);
+    return f32x4{__builtin_bit_cast(float, lin), v.fx, v.fy, v.fz};
 }
 
 // Trilinear gather of the lane's 8 channels (16t+4q+r, t=0,1) of one sample.

@@ -52,5 +52,6 @@ int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* 
                              const double* g_depth, const double* g_var, const float* g_rgb, float* d_raw,
                              hipStream_t st);
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
-                           const DevScene& sc, const float* d_raw, const float* act_ws, const DevGrid* grad_grids,
-                           float* const* grad_packed, float* g_ro, float* g_rd, hipStream_t st);
+                           const DevScene& sc, const float* d_raw, const float* act_ws, float* dgrid_ws,
+                           const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,
+                           hipStream_t st);

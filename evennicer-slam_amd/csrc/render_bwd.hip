@@ -290,6 +290,49 @@ ENS_DEV void scatter_tile(const float* dep, const Vox& v, const DevGrid& gg, int
     if (cx >= 0) flush();
 }
 
+// Same scatter from the cell records the forward saved (vox_record): rec = this lane's sample p (any q).
+ENS_DEV void scatter_tile_rec(const float* dep, const f32x4& rec, const DevGrid& gg, int lane) {
+    const int ch = lane & 31, dxb = lane >> 5;
+    const int rowy = gg.W * 32, rowz = gg.H * gg.W * 32;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned cur = 0u;
+    bool open = false;
+    auto flush = [&]() {
+        const bool okx = !dxb || (cur >> 29 & 1u), oky = cur >> 30 & 1u, okz = cur >> 31;
+        float* base = gg.data + (int64_t)(cur & 0x1fffffffu) * 32 + dxb * 32 + ch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = okx && (!(k & 1) || oky) && (!(k >> 1) || okz);
+            if (ok && acc[k] != 0.f) atomicAdd(base + (k & 1) * rowy + (k >> 1) * rowz, acc[k]);
+            acc[k] = 0.f;
+        }
+    };
+    // (scalar copies first: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
+    const float r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+    const int ri = __builtin_bit_cast(int, r0), rx = __builtin_bit_cast(int, r1), ry = __builtin_bit_cast(int, r2),
+              rz = __builtin_bit_cast(int, r3);
+#pragma unroll
+    for (int pt = 0; pt < 16; ++pt) {
+        const float val = dep[pt * 32 + ch];
+        if (!__any(val != 0.f)) continue;                 // e.g. masked samples of an occupancy decoder
+        const unsigned lin = (unsigned)__builtin_amdgcn_readlane(ri, pt);
+        const float fx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rx, pt));
+        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ry, pt));
+        const float fz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rz, pt));
+        if (!open || lin != cur) {                        // scalar comparison: new cell
+            if (open) flush();
+            cur = lin; open = true;
+        }
+        const float wx = dxb ? fx : (1.f - fx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float w = (wx * ((k & 1) ? fy : (1.f - fy))) * ((k >> 1) ? fz : (1.f - fz));
+            acc[k] = fmaf(w, val, acc[k]);
+        }
+    }
+    if (open) flush();
+}
+
 // reduce the per-sample position gradient over the tile and add it to the ray gradients
 ENS_DEV void add_ray_grad(float dpx, float dpy, float dpz, float zf, int ray, float* g_ro, float* g_rd, int lane) {
     float v[6] = {dpx, dpy, dpz, dpx * zf, dpy * zf, dpz * zf};
@@ -311,6 +354,7 @@ struct BwdArgs {
     const double* z;
     const float* d_raw;
     const float* act_ws;     // forward activations (render_fwd_kernel) or null: recompute
+    float* dgrid_ws;         // decoder -> grid_bwd_kernel hand-off (saved path): [tile][slot][DG_STRIDE]
     DevScene sc;
     DevGrid ggrid[4];        // gradient accumulators (data may be null)
     float* gpacked[4];       // packed-layout gradient accumulators (may be null)
@@ -705,39 +749,52 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
     }
 }
 
-// Variant that takes the forward activations from the workspace written by render_fwd_kernel instead of
-// recomputing them: no gather / embedding / forward chain / forward barriers; the deposit slot is filled by one
-// async copy per tile.  Ring holds backward chunks only; its parity runs on across rounds (5 chunks per round).
+// Variant that takes the forward activations from the workspace written by the forward kernel instead of
+// recomputing them.  The feature-gradient scatter uses the cell records the forward saved (no geometry here); the
+// ray gradients (fp64 geometry, corner re-gather, coordinate gradient, ray reduction) are left to grid_bwd_kernel.  Per round and wave: d_raw -> vote -> async fill
+// of the LDS slot from the workspace -> output layer (VALU) -> 5 backward layers (W^T chunks from the ring, owned
+// dW tiles) -> embedding tail -> dC and the embedding's position gradient handed to grid_bwd_kernel.
+template <int CT>
+struct XyzSlotsS {                     // slot = workspace block order, then the in-kernel deposits
+    static constexpr int EMB = 0, HX2 = 6, HX0 = 8, HX1 = 10, HX3 = 12, C = 14, Q = 14 + CT;
+    static constexpr int FILL = 15 + CT;                             // tiles copied from the workspace
+    static constexpr int H0 = 15 + CT, H1 = 17 + CT, P0 = 19 + CT, P1 = 21 + CT;
+    static constexpr int TILES = 23 + CT;
+};
+constexpr int RB_SAVED = 96 * 32 + 1024 + 16 * 96 + 96 * 4;           // layer-0 chunk: W0^T | Wc0^T | B (padded) | B^T
+
 template <int CT, int NOUT>
 ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float* smem) {
     constexpr XyzLay L{CT * 16};
     constexpr int GF = L.fwd_floats();
     constexpr int NE = NOUT == 4 ? 3 : 1;                          // outputs that carry gradient
-    using SL = XyzSlots<CT>;
+    using SL = XyzSlotsS<CT>;
     constexpr int SLOT = SL::TILES * 256;                          // floats
-    constexpr int RB = 128 * 32 + 1024;                            // floats per ring buffer (largest W^T|Wc^T chunk)
-    constexpr int RING_BYTES = 2 * RB * 4;                         // LDS: [ring | 4 deposit slots]; flush image aliases the slots
+    constexpr int RB = RB_SAVED;
+    static_assert(RB_SAVED >= 128 * 32 + 1024, "ring buffer must hold the largest W^T|Wc^T chunk");
+    constexpr int RING_BYTES = 2 * RB * 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
     const float* __restrict__ pk = A.sc.packed[kind];
-    const DevGrid grid = A.sc.grid[kind];
-    const DevGrid ggrid = A.ggrid[kind];
     float* gpk = A.gpacked[kind];
-    const bool want_w = gpk != nullptr, want_g = ggrid.data != nullptr, want_r = A.g_ro != nullptr;
+    const bool want_w = gpk != nullptr, want_g = A.ggrid[kind].data != nullptr, want_r = A.g_ro != nullptr;
     const bool want_c = want_g || want_r;
     float* ring = smem;
     float* slots = smem + 2 * RB;
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)smem;   // LDS byte address of the dynamic region
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)smem;
+    const int slot_idx = kind - 1;                                  // decoder slot in the workspaces
 
-    const int slot_idx = kind - 1;                                  // decoder slot in the activation workspace
-    // backward layer i's chunk (W_i^T | Wc_i^T) into ring buffer `buf`
+    // backward layer i's chunk (W_i^T | Wc_i^T [| B | B^T for layer 0]) into ring buffer `buf`
     auto prefetch = [&](auto ic, int buf) {
         constexpr int i = decltype(ic)::value;
         float* dst = ring + (buf ? RB : 0);
         ring_load(dst, pk + L.oWT(i), 8 * L.K(i), wave, lane);
         ring_load(dst + 32 * L.K(i), pk + L.oWcT(i), 256, wave, lane);
+        if constexpr (i == 0) {
+            ring_load(dst + 96 * 32 + 1024, pk + L.oBp(), 16 * 96 / 4, wave, lane);
+            ring_load(dst + 96 * 32 + 1024 + 16 * 96, pk + L.oBT(), 96, wave, lane);
+        }
     };
 
-    // owned weight-gradient accumulators (tile t = wave + 4*j of each matrix), persistent over all rounds
     f32x4 aWc[5][CT / 2], aW0[3], aW1[1], aW2[1], aW3[4], aW4[1], aB[5], aBT[2];
     float aWo[NE][8], aBo[NE];
 #pragma unroll
@@ -757,51 +814,67 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     }
 
     const int64_t n_tiles = (int64_t)A.n_rays * A.ntl;
-    const int S = 16 * A.ntl;
     const int64_t stride = (int64_t)n_wg * 4;
     STAMP_DECL
     STAMP_START
     prefetch(IC(4), 0);
     unsigned round_no = 0, rp = 0;                                  // rp: ring buffer of this round's first chunk
+    // The feature-gradient scatter of a tile is deferred into the next executed round (after its first barrier): the
+    // ~30 atomics of a tile then drain under that round's MFMAs instead of in front of its loads (vmcnt is in order).
+    float* const stg = slots + wave * SLOT + SL::H1 * 256;          // dC as [sample][32]; H1 is idle until layer 3
+    f32x4 rec_prev = splat4(0.f);
+    bool pend = false;
+    auto scatter_pending = [&]() {
+        if (pend) {
+            scatter_tile_rec(stg, rec_prev, A.ggrid[kind], lane);
+            wave_lds_fence();
+            pend = false;
+        }
+    };
     for (int64_t base = (int64_t)wg * 4; base < n_tiles; base += stride) {
         const int64_t tile_raw = base + wave;
         const bool tvalid = tile_raw < n_tiles;
         const int tile = __builtin_amdgcn_readfirstlane((int)(tvalid ? tile_raw : n_tiles - 1));
-        const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
-        f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4);
+        f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + ((int64_t)tile * 16 + p) * 4);
         if (!tvalid) draw = splat4(0.f);
         float dj[NE];                                               // d(loss)/d(output j) of this lane's sample
         if constexpr (NOUT == 4) { dj[0] = draw[0]; dj[1] = draw[1]; dj[2] = draw[2]; } else { dj[0] = draw[3]; }
         bool nz = false;
 #pragma unroll
         for (int j = 0; j < NE; ++j) nz = nz || dj[j] != 0.f;
-        // nothing flows into any of the 4 tiles: skip the round (the waves of a workgroup stay in lockstep).
-        // One barrier: each wave posts its flag in a word of the round's parity set.
-        {
+        float* dgw = want_r ? A.dgrid_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * DG_STRIDE : nullptr;
+        {   // skip the round when nothing flows into any of its 4 tiles (one barrier; waves stay in lockstep)
             const int par = (int)(round_no & 1);
             if (lane == 0) ens_vote[par][wave] = __any(nz) ? 1 : 0;
             ++round_no;
             __syncthreads();
             const int any4 = ens_vote[par][0] | ens_vote[par][1] | ens_vote[par][2] | ens_vote[par][3];
-            if (!any4) continue;
+            if (!any4) {
+                if (want_r && tvalid) {                             // grid_bwd_kernel reads the hand-off of every tile
+                    *reinterpret_cast<f32x4*>(dgw + lane * 4) = splat4(0.f);
+                    *reinterpret_cast<f32x4*>(dgw + 256 + lane * 4) = splat4(0.f);
+                    *reinterpret_cast<f32x4*>(dgw + DG_DPE + lane * 4) = splat4(0.f);
+                }
+                scatter_pending();
+                continue;
+            }
         }
-        STAMP(0)        // tile geometry + d_raw load + vote barrier
+        STAMP(0)        // d_raw load + vote barrier
 
-        // per-lane LDS bases of this round (opaque: see above)
-        unsigned w32 = lds0 + (p * 32 + 4 * q) * 4;
+        unsigned w32 = lds0 + (p * 32 + 4 * q) * 4, w96 = lds0 + (p * 96 + 4 * q) * 4;
         unsigned dep = lds0 + RING_BYTES + (wave * SLOT + (p >> 2) * 64 + (p & 3) + 16 * q) * 4;
         unsigned fb[4];
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
-        opaque(w32); opaque(dep);
+        opaque(w32); opaque(w96); opaque(dep);
 
         // ---- forward activations from the workspace: deposit tiles straight into this wave's LDS slot (async),
         //      h4 and the ReLU masks into registers
         const float* __restrict__ wsb = A.act_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * ACT_STRIDE;
-        if (want_w) {
+        {
             float* myslot = slots + wave * SLOT;
 #pragma unroll
-            for (int t = 0; t < 14 + CT; ++t)
+            for (int t = 0; t < SL::FILL; ++t)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsb + t * 256 + lane * 4),
                                                  (__attribute__((address_space(3))) void*)(myslot + t * 256), 16, 0, 0);
         }
@@ -809,9 +882,9 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         h4[0] = ld4(wsb + ACT_H4 + lane * 4);
         h4[1] = ld4(wsb + ACT_H4 + 256 + lane * 4);
         const uint2 mw = *reinterpret_cast<const uint2*>(wsb + ACT_MASK + lane * 2);
+        f32x4 rec = splat4(0.f);
+        if (want_g) rec = ld4(wsb + ACT_VOX + p * 4);
         unsigned mbits[5] = {mw.x & 255u, (mw.x >> 8) & 255u, (mw.x >> 16) & 255u, (mw.x >> 24) & 255u, mw.y & 255u};
-        const float pc = q == 0 ? (float)G.pw[0] : (q == 1 ? (float)G.pw[1] : (q == 2 ? (float)G.pw[2] : 0.f));
-        const Vox v = make_vox(G.pw, A.sc.lo, A.sc.hi, grid);
         unsigned wr[2] = {w32, w32 + RB * 4};                         // lane bases into ring buffers 0 / 1
         STAMP(3)
 
@@ -838,13 +911,13 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         f32x4 demb[6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) demb[t] = splat4(0.f);
+        unsigned wb0 = 0;                                           // lane base of the layer-0 ring buffer (tail)
         auto bwd_layer = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int kk = 4 - i;                                // chunk number inside the round
             const int buf = (kk + rp) & 1;
             const unsigned wb = wr[buf];
-            constexpr int RO = 0;                                    // W_i^T [K][32] | Wc_i^T [32][32]
-            constexpr int OCT = 32 * L.K(i) * 4;
+            constexpr int OCT = 32 * L.K(i) * 4;                      // W_i^T [K][32] | Wc_i^T [32][32]
             constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
             constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);      // input h_{i-1} of layers 4, 2, 1
             f32x4 dpre[2] = {mask4(dh[0], mbits[i], 0), mask4(dh[1], mbits[i], 4)};
@@ -853,9 +926,10 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 dep_tile<TP>(dep, dpre[0]); dep_tile<TP + 1>(dep, dpre[1]);
             }
             STAMP(6)    // layer deposits (+ tail of previous dX)
-            __syncthreads();            // deposits visible; this layer's W^T chunk has landed
+            __syncthreads();            // deposits + slot fill visible; this layer's W^T chunk has landed
             STAMP(5)    // barrier wait
             if constexpr (i > 0) prefetch(IC(i - 1), buf ^ 1); else prefetch(IC(4), buf ^ 1);
+            if constexpr (i == 4) scatter_pending();                 // previous tile's atomics, behind this round's loads
             if (want_w) {
                 own_outer_a<CT / 2>(aWc[i], fb, TH, SL::C, CT, 2 * CT, wave);                     // dWc_i
                 if constexpr (i == 0) {
@@ -872,27 +946,36 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 own_bias_a(aB[i], fb, (wave < 2 ? TP : TH) + (wave & 1));                        // db_i | dbc_i
                 STAMP(7)    // owned dW MFMAs
             }
-            if (want_c) lin_lds<2, 2, 32, OCT>(dc, wb, dh);                              // dC += Wc_i^T dh_i
+            if (want_c) lin_lds<2, 2, 32, OCT>(dc, wb, dh);                               // dC += Wc_i^T dh_i
             if constexpr (i == 0) {
-                if (want_r || want_w) lin_lds<6, 2, 32, RO>(demb, wb, dpre);
+                wb0 = wb;
+                if (want_r || want_w) lin_lds<6, 2, 32, 0>(demb, wb, dpre);
             } else if constexpr (i == 3) {
-                if (want_r || want_w) lin_lds<6, 2, 32, RO>(demb, wb, dpre);        // rows 0..95 of W3^T: embedding part
+                if (want_r || want_w) lin_lds<6, 2, 32, 0>(demb, wb, dpre);         // rows 0..95 of W3^T: embedding part
                 dh[0] = dh[1] = splat4(0.f);
-                lin_lds<2, 2, 32, RO + 96 * 32 * 4>(dh, wb, dpre);
+                lin_lds<2, 2, 32, 96 * 32 * 4>(dh, wb, dpre);
             } else {
                 dh[0] = dh[1] = splat4(0.f);
-                lin_lds<2, 2, 32, RO>(dh, wb, dpre);
+                lin_lds<2, 2, 32, 0>(dh, wb, dpre);
             }
         };
         bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
         rp ^= 1;                                                    // 5 chunks per executed round
         STAMP(8)        // dX chain of the last layer
-        // ---- embedding: d_arg = d_emb * cos(arg);  dB^T += d_arg (x) p ;  dp += B d_arg
-        float dpx = 0.f, dpy = 0.f, dpz = 0.f;
+        // ---- embedding: d_arg = d_emb * cos(arg);  dB^T += d_arg (x) p ;  dp += B d_arg.  B and B^T ride in the
+        //      layer-0 ring chunk; the sample coordinates come from the XYZ tile of the slot.
+        f32x4 dpe[1] = {splat4(0.f)};
         if (want_r || want_w) {
+            constexpr int OBP = (96 * 32 + 1024) * 4, OBT = OBP + 16 * 96 * 4;
+            const unsigned ring0 = wb0 - (p * 32 + 4 * q) * 4;       // byte address of the layer-0 buffer
+            // coordinate q of sample p from the XYZ tile (feature i = q)
+            const float pc = q < 3 ? *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(
+                                         lds0 + RING_BYTES + (wave * SLOT + SL::Q * 256 + (p >> 2) * 64 + q * 4 + (p & 3)) * 4))
+                                   : 0.f;
 #pragma unroll
             for (int t = 0; t < 6; ++t) {                               // cos(arg) recomputed: cheaper than carrying it
-                const f32x4 arg = MFMA16(pk[L.oBT() + (16 * t + p) * 4 + q], pc, splat4(0.f));
+                const float a = *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(ring0 + OBT + ((16 * t + p) * 4 + q) * 4));
+                const f32x4 arg = MFMA16(a, pc, splat4(0.f));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float sv, cv;
@@ -904,46 +987,29 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 __syncthreads();                                     // every wave is done reading EMB
                 dep_tile<SL::EMB + 0>(dep, demb[0]); dep_tile<SL::EMB + 1>(dep, demb[1]); dep_tile<SL::EMB + 2>(dep, demb[2]);
                 dep_tile<SL::EMB + 3>(dep, demb[3]); dep_tile<SL::EMB + 4>(dep, demb[4]); dep_tile<SL::EMB + 5>(dep, demb[5]);
-                f32x4 pt4 = splat4(0.f);
-                if (q == 0) pt4 = f32x4{(float)G.pw[0], (float)G.pw[1], (float)G.pw[2], 0.f};
-                dep_tile<SL::Q>(dep, pt4);
                 __syncthreads();
                 own_outer_a<2>(aBT, fb, SL::EMB, SL::Q, 1, 6, wave);                              // dB^T
             }
-            if (want_r) {
-                f32x4 dpe[1] = {splat4(0.f)};
-                linear_n<1, 6>(dpe, pk + L.oBp(), 96, demb, p, q);
-                dpx = dpe[0][0]; dpy = dpe[0][1]; dpz = dpe[0][2];      // valid on q == 0 lanes
-            }
+            if (want_r) lin_lds<1, 6, 96, OBP>(dpe, ring0 + (p * 96 + 4 * q) * 4, demb);         // rows 0..2: dp (q == 0 lanes)
         }
         STAMP(9)        // embedding tail (cos recompute, dB^T, dp)
-        // ---- grid: coordinate gradient and feature-gradient scatter
-        if (want_c) {
-            if (want_r) {
-                float gx, gy, gz;
-                coord_grad_partial(v, grid, q, dc[0], dc[1], gx, gy, gz);
-                gx += __shfl_xor(gx, 16); gx += __shfl_xor(gx, 32);
-                gy += __shfl_xor(gy, 16); gy += __shfl_xor(gy, 32);
-                gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
-                dpx += gx * v.gx; dpy += gy * v.gy; dpz += gz * v.gz;
-            }
-            if (want_g && tvalid) {
-                // stage dC as [sample][32 channels] in this wave's H1 tiles (layer 1 was their last reader, two
-                // barriers ago; the next writer is the next round's layer 3, behind further barriers)
-                float* stg = slots + wave * SLOT + SL::H1 * 256;
-                *reinterpret_cast<f32x4*>(stg + p * 32 + 4 * q) = dc[0];
-                *reinterpret_cast<f32x4*>(stg + p * 32 + 16 + 4 * q) = dc[1];
-                wave_lds_fence();
-                scatter_tile(stg, v, ggrid, lane);
-                wave_lds_fence();
-            }
+        if (want_r && tvalid) {         // hand-off to grid_bwd_kernel: dC (register layout) + embedding's position gradient
+            *reinterpret_cast<f32x4*>(dgw + lane * 4) = dc[0];
+            *reinterpret_cast<f32x4*>(dgw + 256 + lane * 4) = dc[1];
+            *reinterpret_cast<f32x4*>(dgw + DG_DPE + lane * 4) = dpe[0];
         }
-        if (want_r && tvalid) {
-            if (q != 0) { dpx = dpy = dpz = 0.f; }
-            add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
+        if (want_g && tvalid) {
+            // dC of this tile -> [sample][32] in this wave's H1 tiles (last read before the layer-0 barrier); the
+            // 256-byte atomics per cell corner row are issued by scatter_pending() in the next round
+            *reinterpret_cast<f32x4*>(stg + p * 32 + 4 * q) = dc[0];
+            *reinterpret_cast<f32x4*>(stg + p * 32 + 16 + 4 * q) = dc[1];
+            wave_lds_fence();
+            rec_prev = rec;
+            pend = true;
         }
-        STAMP(10)       // coordinate gradient + scatter + ray grads
+        STAMP(10)
     }
+    scatter_pending();
     STAMP_FLUSH
 
     // ---- flush: stage the owned tiles into a packed-layout LDS image, then coalesced global atomics
@@ -968,7 +1034,6 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             if (wave + 4 * j < 6) stage_tile(sacc + L.oBT(), 4, 0, 1, wave + 4 * j, aBT[j], 93, 3, p, q);
-        // output layer: per-lane partial sums -> reduce over the 16 sample lanes; the 4 waves add in LDS
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
 #pragma unroll
@@ -987,6 +1052,35 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             if (vsum != 0.f) atomicAdd(gpk + e, vsum);
         }
     }
+}
+
+// Ray-gradient side of the backward for the saved-activation path: one wave per (16-sample tile, decoder slot).  Low
+// register count -> many waves per SIMD hide the latency of the fp64 geometry and of the corner re-gather.
+__global__ __launch_bounds__(64) void grid_bwd_kernel(BwdArgs A, int n_slots) {
+    const int lane = threadIdx.x, p = lane & 15, q = lane >> 4;
+    const int64_t unit = blockIdx.x;
+    const int64_t tile = unit / n_slots;
+    const int slot_idx = A.role_kind[unit - tile * n_slots] - 1;
+    const int kind = slot_idx + 1;
+    const DevGrid grid = A.sc.grid[kind];
+    const float* dgw = A.dgrid_ws + (tile * ACT_SLOTS + slot_idx) * DG_STRIDE;
+    const f32x4 dc0 = ld4(dgw + lane * 4), dc1 = ld4(dgw + 256 + lane * 4);
+    const f32x4 dpe = ld4(dgw + DG_DPE + lane * 4);
+    bool nz = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nz = nz || dc0[r] != 0.f || dc1[r] != 0.f || dpe[r] != 0.f;
+    if (!__any(nz)) return;
+    const int S = 16 * A.ntl;
+    const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
+    const Vox v = make_vox(G.pw, A.sc.lo, A.sc.hi, grid);
+    float gx, gy, gz;
+    coord_grad_partial(v, grid, q, dc0, dc1, gx, gy, gz);
+    gx += __shfl_xor(gx, 16); gx += __shfl_xor(gx, 32);
+    gy += __shfl_xor(gy, 16); gy += __shfl_xor(gy, 32);
+    gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
+    float dpx = gx * v.gx + dpe[0], dpy = gy * v.gy + dpe[1], dpz = gz * v.gz + dpe[2];
+    if (q != 0) { dpx = dpy = dpz = 0.f; }
+    add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1167,6 +1261,7 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(BwdArgs A) {
 
 // deposit slots of the 4 waves; the packed-layout flush image aliases them at the end of the kernel
 constexpr int lds_bytes_xyz(int ct) { return (cmax(XyzLay{ct * 16}.fwd_floats(), 4 * (23 + ct) * 256) + 2 * ring_floats(ct)) * 4; }
+constexpr int lds_bytes_xyz_saved(int ct) { return (cmax(XyzLay{ct * 16}.fwd_floats(), 4 * (23 + ct) * 256) + 2 * RB_SAVED) * 4; }
 constexpr int lds_bytes_feat() { return cmax(FeatLay{}.fwd_floats(), 4 * 11 * 256) * 4; }
 
 int device_cus() {
@@ -1198,11 +1293,13 @@ int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* 
 }
 
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
-                           const DevScene& sc, const float* d_raw, const float* act_ws, const DevGrid* grad_grids,
-                           float* const* grad_packed, float* g_ro, float* g_rd, hipStream_t st) {
+                           const DevScene& sc, const float* d_raw, const float* act_ws, float* dgrid_ws,
+                           const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,
+                           hipStream_t st) {
     if (n_rays <= 0) return 0;
     BwdArgs A;
     A.act_ws = stage == 0 ? nullptr : act_ws;
+    A.dgrid_ws = dgrid_ws;
     A.n_rays = n_rays; A.ntl = ntl; A.ro = ro; A.rd = rd; A.z = z; A.d_raw = d_raw; A.sc = sc;
     A.g_ro = (g_ro && g_rd) ? g_ro : nullptr;
     A.g_rd = (g_ro && g_rd) ? g_rd : nullptr;
@@ -1217,7 +1314,7 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         default: return -1;
     }
     for (int k = 0; k < 4; ++k) { A.ggrid[k] = DevGrid{nullptr, 0, 0, 0}; A.gpacked[k] = nullptr; }
-    int lds = 0;
+    int lds = 0, lds_saved = 0;
     // drop roles with nothing to produce
     int kk[3], n2 = 0;
     float cc[3], csum = 0.f;
@@ -1230,6 +1327,8 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         kk[n2] = k; cc[n2] = cost[i]; csum += cost[i]; ++n2;
         const int need = k == 0 ? lds_bytes_feat() : lds_bytes_xyz(k == 2 ? 4 : 2);
         lds = need > lds ? need : lds;
+        const int need_s = k == 0 ? lds_bytes_feat() : lds_bytes_xyz_saved(k == 2 ? 4 : 2);
+        lds_saved = need_s > lds_saved ? need_s : lds_saved;
     }
     if (n2 == 0) return 0;
     const int64_t n_tiles = (int64_t)n_rays * ntl;
@@ -1258,7 +1357,12 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
             return -2;
         attr_set = true;
     }
-    if (A.act_ws != nullptr) decoder_bwd_kernel<true><<<dim3(total), dim3(256), lds, st>>>(A);
-    else decoder_bwd_kernel<false><<<dim3(total), dim3(256), lds, st>>>(A);
+    if (A.act_ws != nullptr) {
+        decoder_bwd_kernel<true><<<dim3(total), dim3(256), lds_saved, st>>>(A);
+        if (A.g_ro != nullptr && hipGetLastError() == hipSuccess)
+            grid_bwd_kernel<<<dim3((unsigned)(n_tiles * n2)), dim3(64), 0, st>>>(A, n2);
+    } else {
+        decoder_bwd_kernel<false><<<dim3(total), dim3(256), lds, st>>>(A);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -106,6 +106,9 @@ ENS_DEV void mlp_xyz_fwd(const float* __restrict__ pk, const float (&pc)[NTL], c
             for (int t = 0; t < 6; ++t) ws_store_dep(ws[tl] + t * 256, emb[tl][t], stage, lane, p, q);
 #pragma unroll
             for (int t = 0; t < CT; ++t) ws_store_dep(ws[tl] + (14 + t) * 256, c[tl][t], stage, lane, p, q);
+            // sample coordinates as a feature tile (features 0..2 = x,y,z live on q == 0 lanes): dB^T operand
+            const float cx = __shfl(pc[tl], p), cy = __shfl(pc[tl], 16 + p), cz = __shfl(pc[tl], 32 + p);
+            ws_store_dep(ws[tl] + (14 + CT) * 256, q == 0 ? f32x4{cx, cy, cz, 0.f} : splat4(0.f), stage, lane, p, q);
         }
     }
     f32x4 h[NTL][2];
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(64, NTL == 1 ? 3 : 1) void render_fwd_kernel(int64_
         for (int tl = 0; tl < NTL; ++tl) {
             const Vox v = make_vox(pw[tl], sc.lo, sc.hi, sc.grid[1]);
             gather8(v, sc.grid[1], q, cm[tl][0], cm[tl][1]);
+            if (ws0[tl] != nullptr && q == 0) *reinterpret_cast<f32x4*>(ws0[tl] + ACT_VOX + p * 4) = vox_record(v, sc.grid[1]);
         }
         mlp_xyz_fwd<2, NTL>(sc.packed[1], pc, cm, occ, ws0, ws_stage, lane, p, q);
         if constexpr (STAGE >= 2) {
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(64, NTL == 1 ? 3 : 1) void render_fwd_kernel(int64_
             for (int tl = 0; tl < NTL; ++tl) {
                 const Vox v = make_vox(pw[tl], sc.lo, sc.hi, sc.grid[2]);
                 gather8(v, sc.grid[2], q, cf[tl][0], cf[tl][1]);
+                if (ws1[tl] != nullptr && q == 0) *reinterpret_cast<f32x4*>(ws1[tl] + ACT_VOX + p * 4) = vox_record(v, sc.grid[2]);
                 cf[tl][2] = cm[tl][0];                                    // decoder.py:184-187 concat
                 cf[tl][3] = cm[tl][1];
             }
@@ -264,6 +269,7 @@ __global__ __launch_bounds__(64, NTL == 1 ? 3 : 1) void render_fwd_kernel(int64_
             for (int tl = 0; tl < NTL; ++tl) {
                 const Vox v = make_vox(pw[tl], sc.lo, sc.hi, sc.grid[3]);
                 gather8(v, sc.grid[3], q, cc[tl][0], cc[tl][1]);
+                if (ws2[tl] != nullptr && q == 0) *reinterpret_cast<f32x4*>(ws2[tl] + ACT_VOX + p * 4) = vox_record(v, sc.grid[3]);
             }
             mlp_xyz_fwd<2, NTL>(sc.packed[3], pc, cc, col, ws2, ws_stage, lane, p, q);
         }
@@ -350,6 +356,8 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
         for (int t = 0; t < 6; ++t) ws_store_dep(ws + t * 256, emb[t], stage, lane, p, q);
 #pragma unroll
         for (int t = 0; t < CT; ++t) ws_store_dep(ws + (14 + t) * 256, c[t], stage, lane, p, q);
+        const float cx = __shfl(pc, p), cy = __shfl(pc, 16 + p), cz = __shfl(pc, 32 + p);
+        ws_store_dep(ws + (14 + CT) * 256, q == 0 ? f32x4{cx, cy, cz, 0.f} : splat4(0.f), stage, lane, p, q);
     }
     f32x4 h[5][2];
     unsigned mb0 = 0u, mb1 = 0u;
@@ -447,6 +455,7 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     {
         const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[1]);
         gather8(v, sc.grid[1], q, cm[0], cm[1]);
+        if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + ACT_VOX + p * 4) = vox_record(v, sc.grid[1]);
     }
     __syncthreads();                                                                   // chunk 0 landed
     mlp_xyz_ring<2, 0, RB, (STAGE >= 2 ? 64 : 0)>(sc.packed[1], STAGE >= 2 ? sc.packed[2] : nullptr, ring, pc, cm, occ, wsb,
@@ -456,6 +465,7 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
         {
             const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[2]);
             gather8(v, sc.grid[2], q, cf[0], cf[1]);
+            if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + ACT_STRIDE + ACT_VOX + p * 4) = vox_record(v, sc.grid[2]);
         }
         cf[2] = cm[0];
         cf[3] = cm[1];
@@ -470,6 +480,7 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
         {
             const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[3]);
             gather8(v, sc.grid[3], q, cc[0], cc[1]);
+            if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + 2 * ACT_STRIDE + ACT_VOX + p * 4) = vox_record(v, sc.grid[3]);
         }
         mlp_xyz_ring<2, 10, RB, 0>(sc.packed[3], nullptr, ring, pc, cc, col, wsb ? wsb + 2 * ACT_STRIDE : nullptr, stage,
                                    w32, w96, w128, w32, wq, wave, lane, p, q);

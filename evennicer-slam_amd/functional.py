@@ -5,6 +5,7 @@ path (sampling, gather, decoders, compositing and their backward) runs in libens
 There is no CPU implementation here: non-HIP tensors raise.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -363,7 +364,7 @@ class _RenderFn(torch.autograd.Function):
         act = None
         if any(ctx.needs_input_grad):
             n_act = lib.enslam_activation_floats(L.STAGE[plan.stage], N, S)
-            if 0 < n_act * 4 <= ACT_WORKSPACE_LIMIT_BYTES:
+            if 0 < n_act * 4 <= ACT_WORKSPACE_LIMIT_BYTES and max(d[0] * d[1] * d[2] for d in dims.values()) < (1 << 29):
                 act = torch.empty(n_act, dtype=torch.float32, device=dev)
         L.check(lib.enslam_render_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                       _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), st), "enslam_render_fwd")
@@ -447,8 +448,11 @@ class _RenderFn(torch.autograd.Function):
         if ev is not None:                      # bench.py: HIP events around the dominant kernel, on this stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        dgw = None
+        if act is not None and need_rays:
+            dgw = torch.empty(lib.enslam_grid_handoff_floats(L.STAGE[plan.stage], N, S), dtype=torch.float32, device=dev)
         L.check(lib.enslam_decoder_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                       _ptr(d_raw), _ptr(act), gg, gpk, p_ro, p_rd, st), "enslam_decoder_bwd")
+                                       _ptr(d_raw), _ptr(act), _ptr(dgw), gg, gpk, p_ro, p_rd, st), "enslam_decoder_bwd")
         if ev is not None:
             e1.record()
             ev.append((e0, e1))

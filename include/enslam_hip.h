@@ -156,6 +156,10 @@ int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
  * enslam_decoder_bwd / enslam_render_bwd given the same buffer read them instead of recomputing the decoder
  * forward.  NULL in both places selects recomputation (no extra memory, slower backward). */
 size_t enslam_activation_floats(int32_t stage, int32_t n_rays, int32_t n_samples);
+/* float32 count of the scratch buffer `dgrid_ws` the backward needs when it runs from `act_ws` AND ray gradients
+ * are requested (decoder kernel -> ray-gradient kernel hand-off: feature gradient and embedding position gradient per
+ * tile and decoder).  dgrid_ws may be NULL when g_rays_o is NULL.  act_ws needs every grid below 2^29 voxels. */
+size_t enslam_grid_handoff_floats(int32_t stage, int32_t n_rays, int32_t n_samples);
 
 /* Forward of Renderer.eval_points (Renderer.py:24-62) on explicit points p float64 [P,3].
  * apply_mask = 0 gives the bare decoder call NICE.forward (decoder.py:312-342, as Mesher.py:308 uses it). */
@@ -175,18 +179,20 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
                       const double *z_vals, const enslam_scene *scene, const float *raw, const double *depth,
                       const double *g_depth, const double *g_var, const float *g_rgb,
                       const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o, float *g_rays_d,
-                      float *d_raw, const float *act_ws, void *stream);
+                      float *d_raw, const float *act_ws, float *dgrid_ws, void *stream);
 
 /* The two halves of enslam_render_bwd, callable on their own.
  * enslam_composite_bwd: backward of raw2outputs_nerf_color (common.py:284-296): d(depth,var,rgb) -> d_raw [N*S,4].
- * enslam_decoder_bwd  : everything upstream of raw (decoders, gather, points), consuming d_raw. */
+ * enslam_decoder_bwd  : everything upstream of raw (decoders, gather, points), consuming d_raw.  With act_ws and
+ *   (from the size query above) it reads the saved activations and cell records, and ray gradients come from a
+ *   second small kernel fed through dgrid_ws; with act_ws NULL everything is recomputed in one kernel. */
 int enslam_composite_bwd(int32_t n_rays, int32_t n_samples, const float *raw, const double *z_vals,
                          const double *depth, const double *g_depth, const double *g_var, const float *g_rgb,
                          float *d_raw, void *stream);
 int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                        const double *z_vals, const enslam_scene *scene, const float *d_raw, const float *act_ws,
-                       const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o, float *g_rays_d,
-                       void *stream);
+                       float *dgrid_ws, const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o,
+                       float *g_rays_d, void *stream);
 
 /* raw2outputs_nerf_color (common.py:256-297, occupancy=True) on its own: raw float32 [N,S,4], z_vals float64 [N,S]
  * -> depth/var float64 [N], rgb float32 [N,3], weights float32 [N,S] (may be NULL).  1 <= S <= 64. */

@@ -22,7 +22,7 @@ assert handle.enslam_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 
 for i in range(5):
     buf.zero_()
     d, v, c = renderer.render_batch_ray(grids, model, rd, ro, dev, 'color', gt_depth=gd)
-    bench.mapper_loss(d, c, gd, gc, 'color').backward()
+    E.losses.rgbd_loss(d, c, gd, gc, 0.2).backward()
 torch.cuda.synchronize()
 st = buf.cpu().numpy().reshape(256, 4, NSEG).astype(np.float64)
 # role ranges as in ens_launch_decoder_bwd: 0.30 / 0.40 / 0.30 of 256 workgroups
