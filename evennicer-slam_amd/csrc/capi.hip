@@ -47,15 +47,15 @@ bool build_job(int kind, const enslam_mlp_params& P, bool with_transposed, PackJ
         if (with_transposed) {
             for (int i = 0; i < 5; ++i) {
                 if (i == 3) {
-                    add(j, P.W[3], L.oWT(3), 93, 32, 125, 32, 1);
-                    add(j, P.W[3] ? P.W[3] + 93 : nullptr, L.oWT(3) + 96 * 32, 32, 32, 125, 32, 1);
+                    add(j, P.W[3], L.oWT(3), 93, 32, 125, 32, 3);              // 3: transposed + swizzled (lds_util.hpp)
+                    add(j, P.W[3] ? P.W[3] + 93 : nullptr, L.oWT(3) + 96 * 32, 32, 32, 125, 32, 3);
                 } else {
-                    add(j, P.W[i], L.oWT(i), kin[i], 32, kin[i], 32, 1);
+                    add(j, P.W[i], L.oWT(i), kin[i], 32, kin[i], 32, 3);
                 }
-                add(j, P.Wc[i], L.oWcT(i), 32, 32, CD, 32, 1);                   // grid channels only
+                add(j, P.Wc[i], L.oWcT(i), 32, 32, CD, 32, 3);                   // grid channels only
             }
             add(j, P.Wo, L.oWoT(), 32, NO, 32, 4, 1);
-            add(j, P.B, L.oBp(), 3, 93, 93, 96, 0);
+            add(j, P.B, L.oBp(), 3, 93, 93, 96, 2);                              // swizzled, not transposed
         }
         const int need = with_transposed ? 24 + 13 : 24;
         return j.n - n0 == need;

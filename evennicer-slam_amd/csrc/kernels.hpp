@@ -10,7 +10,7 @@ struct PackSeg {
     int off;                                 // float offset in the packed buffer
     unsigned short rows, cols;               // extent in packed orientation
     unsigned short src_ld, dst_ld;
-    unsigned char transpose, dec;            // dec: index into PackJob::packed
+    unsigned char transpose, dec;            // transpose: bit 0 transposed copy, bit 1 XOR-swizzled chunks; dec: index into PackJob::packed
 };
 #define ENS_MAX_SEGS 120
 struct PackJob {

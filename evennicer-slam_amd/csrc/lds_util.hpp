@@ -37,6 +37,36 @@ ENS_DEV void lin_lds(f32x4 (&acc)[NR], unsigned base, const f32x4 (&x)[KT]) {
     }
 }
 
+// Bank-conflict-free images (the backward's transposed matrices, rows of 32 or 96 floats): the 16-byte chunk c of row r
+// sits at chunk  c ^ ((r & 15) >> 1)  of its row (packed that way by pack_kernel, copied verbatim by ring_load).  A
+// plain [row][32] image puts the 16 lanes of one ds_read_b128 group on 4 bank groups (4-way conflict); with the XOR
+// they cover all 64 banks.  Lane (p, q) reads chunk 4t+q of row 16rt+p:  (4t+q) ^ s = (q ^ (s&3)) + (4t ^ (s&4)),
+// so two lane bases (even / odd column tile) and immediates are enough.
+ENS_DEV unsigned swz_base_even(unsigned region, int LD, int p, int q) {
+    const int s = p >> 1;
+    return region + (unsigned)(p * LD * 4 + ((q ^ (s & 3)) + (s & 4)) * 16);
+}
+ENS_DEV unsigned swz_odd_delta(int p) { return (unsigned)(((p >> 1) & 4) * 32); }      // bytes: base_odd = base_even - delta
+template <int NR, int KT, int LD, int OFF>
+ENS_DEV void lin_lds_swz(f32x4 (&acc)[NR], unsigned base_even, unsigned odd_delta, const f32x4 (&x)[KT]) {
+    f32x4 a[KT][NR];
+    const unsigned base_odd = base_even - odd_delta;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt) a[t][rt] = lds4(((t & 1) ? base_odd : base_even) + OFF + (16 * rt * LD + 16 * t) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt) acc[rt] = MFMA16(a[t][rt][r], x[t][r], acc[rt]);
+        }
+    }
+}
+
 // cooperative async copy global -> LDS of n4 float4 (all 256 threads; 1 KB per wave instruction, no VGPR staging)
 ENS_DEV void ring_load(float* dst_lds, const float* __restrict__ src, int n4, int wave, int lane) {
     for (int j = 0; j * 256 < n4; ++j) {

@@ -195,6 +195,27 @@ ENS_DEV void linear_n(f32x4 (&acc)[NR], const float* __restrict__ M, int ld, con
     }
 }
 
+// the same on a swizzled image (lds_util.hpp) read straight from global memory
+template <int NR, int KT>
+ENS_DEV void linear_n_swz(f32x4 (&acc)[NR], const float* __restrict__ M, int ld, const f32x4 (&x)[KT], int p, int q) {
+    f32x4 a[KT][NR];
+    const int s = p >> 1;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt) a[t][rt] = ldw(M, (16 * rt + p) * ld + 4 * ((4 * t + q) ^ s));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt) acc[rt] = MFMA16(a[t][rt][r], x[t][r], acc[rt]);
+        }
+    }
+}
+
 ENS_DEV f32x4 mask4(const f32x4& v, unsigned bits, int sh) {
     return f32x4{(bits >> sh) & 1u ? v[0] : 0.f, (bits >> (sh + 1)) & 1u ? v[1] : 0.f,
                  (bits >> (sh + 2)) & 1u ? v[2] : 0.f, (bits >> (sh + 3)) & 1u ? v[3] : 0.f};
@@ -515,7 +536,9 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
         unsigned fb[4];
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
-        opaque(w32); opaque(w96); opaque(w128); opaque(wcd); opaque(wq); opaque(dep);
+        unsigned w32s = swz_base_even(lds0, 32, p, q);               // transposed (swizzled) images: lds_util.hpp
+        const unsigned swd = swz_odd_delta(p);
+        opaque(w32); opaque(w96); opaque(w128); opaque(wcd); opaque(wq); opaque(dep); opaque(w32s);
 
         // ---- recompute the forward chain (weights of layer i from ring buffer i&1, next chunk in flight)
         const float pc = q == 0 ? (float)G.pw[0] : (q == 1 ? (float)G.pw[1] : (q == 2 ? (float)G.pw[2] : 0.f));
@@ -633,16 +656,16 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
                 own_bias_a(aB[i], fb, (wave < 2 ? TP : TH) + (wave & 1));                        // db_i | dbc_i
                 STAMP(7)    // owned dW MFMAs
             }
-            if (want_c) lin_lds<2, 2, 32, OCT>(dc, w32, dh);                              // dC += Wc_i^T dh_i
+            if (want_c) lin_lds_swz<2, 2, 32, OCT>(dc, w32s, swd, dh);                    // dC += Wc_i^T dh_i
             if constexpr (i == 0) {
-                if (want_r || want_w) lin_lds<6, 2, 32, RO>(demb, w32, dpre);
+                if (want_r || want_w) lin_lds_swz<6, 2, 32, RO>(demb, w32s, swd, dpre);
             } else if constexpr (i == 3) {
-                if (want_r || want_w) lin_lds<6, 2, 32, RO>(demb, w32, dpre);       // rows 0..95 of W3^T: embedding part
+                if (want_r || want_w) lin_lds_swz<6, 2, 32, RO>(demb, w32s, swd, dpre);   // rows 0..95 of W3^T: embedding part
                 dh[0] = dh[1] = splat4(0.f);
-                lin_lds<2, 2, 32, RO + 96 * 32 * 4>(dh, w32, dpre);
+                lin_lds_swz<2, 2, 32, RO + 96 * 32 * 4>(dh, w32s, swd, dpre);
             } else {
                 dh[0] = dh[1] = splat4(0.f);
-                lin_lds<2, 2, 32, RO>(dh, w32, dpre);
+                lin_lds_swz<2, 2, 32, RO>(dh, w32s, swd, dpre);
             }
         };
         bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
@@ -672,7 +695,7 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
             }
             if (want_r) {
                 f32x4 dpe[1] = {splat4(0.f)};
-                linear_n<1, 6>(dpe, pk + L.oBp(), 96, demb, p, q);
+                linear_n_swz<1, 6>(dpe, pk + L.oBp(), 96, demb, p, q);
                 dpx = dpe[0][0]; dpy = dpe[0][1]; dpz = dpe[0][2];      // valid on q == 0 lanes
             }
         }
@@ -861,12 +884,11 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         }
         STAMP(0)        // d_raw load + vote barrier
 
-        unsigned w32 = lds0 + (p * 32 + 4 * q) * 4, w96 = lds0 + (p * 96 + 4 * q) * 4;
         unsigned dep = lds0 + RING_BYTES + (wave * SLOT + (p >> 2) * 64 + (p & 3) + 16 * q) * 4;
         unsigned fb[4];
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
-        opaque(w32); opaque(w96); opaque(dep);
+        opaque(dep);
 
         // ---- forward activations from the workspace: deposit tiles straight into this wave's LDS slot (async),
         //      h4 and the ReLU masks into registers
@@ -885,7 +907,9 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         f32x4 rec = splat4(0.f);
         if (want_g) rec = ld4(wsb + ACT_VOX + p * 4);
         unsigned mbits[5] = {mw.x & 255u, (mw.x >> 8) & 255u, (mw.x >> 16) & 255u, (mw.x >> 24) & 255u, mw.y & 255u};
-        unsigned wr[2] = {w32, w32 + RB * 4};                         // lane bases into ring buffers 0 / 1
+        unsigned wsw = swz_base_even(lds0, 32, p, q);                  // swizzled-image lane base, ring buffer 0
+        const unsigned swd = swz_odd_delta(p);
+        opaque(wsw);
         STAMP(3)
 
         // ---- output layer: dWo, dbo on the VALU (n_out <= 4 rows: not worth an MFMA tile); dh4 = Wo^T d_out
@@ -911,12 +935,12 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         f32x4 demb[6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) demb[t] = splat4(0.f);
-        unsigned wb0 = 0;                                           // lane base of the layer-0 ring buffer (tail)
+        unsigned ring0 = 0;                                         // byte address of the layer-0 ring buffer (tail)
         auto bwd_layer = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int kk = 4 - i;                                // chunk number inside the round
             const int buf = (kk + rp) & 1;
-            const unsigned wb = wr[buf];
+            const unsigned wb = wsw + (buf ? RB * 4 : 0);
             constexpr int OCT = 32 * L.K(i) * 4;                      // W_i^T [K][32] | Wc_i^T [32][32]
             constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
             constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);      // input h_{i-1} of layers 4, 2, 1
@@ -946,17 +970,17 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 own_bias_a(aB[i], fb, (wave < 2 ? TP : TH) + (wave & 1));                        // db_i | dbc_i
                 STAMP(7)    // owned dW MFMAs
             }
-            if (want_c) lin_lds<2, 2, 32, OCT>(dc, wb, dh);                               // dC += Wc_i^T dh_i
+            if (want_c) lin_lds_swz<2, 2, 32, OCT>(dc, wb, swd, dh);                      // dC += Wc_i^T dh_i
             if constexpr (i == 0) {
-                wb0 = wb;
-                if (want_r || want_w) lin_lds<6, 2, 32, 0>(demb, wb, dpre);
+                ring0 = lds0 + (buf ? RB * 4 : 0);
+                if (want_r || want_w) lin_lds_swz<6, 2, 32, 0>(demb, wb, swd, dpre);
             } else if constexpr (i == 3) {
-                if (want_r || want_w) lin_lds<6, 2, 32, 0>(demb, wb, dpre);         // rows 0..95 of W3^T: embedding part
+                if (want_r || want_w) lin_lds_swz<6, 2, 32, 0>(demb, wb, swd, dpre);  // rows 0..95 of W3^T: embedding part
                 dh[0] = dh[1] = splat4(0.f);
-                lin_lds<2, 2, 32, 96 * 32 * 4>(dh, wb, dpre);
+                lin_lds_swz<2, 2, 32, 96 * 32 * 4>(dh, wb, swd, dpre);
             } else {
                 dh[0] = dh[1] = splat4(0.f);
-                lin_lds<2, 2, 32, 0>(dh, wb, dpre);
+                lin_lds_swz<2, 2, 32, 0>(dh, wb, swd, dpre);
             }
         };
         bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
@@ -967,7 +991,6 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         f32x4 dpe[1] = {splat4(0.f)};
         if (want_r || want_w) {
             constexpr int OBP = (96 * 32 + 1024) * 4, OBT = OBP + 16 * 96 * 4;
-            const unsigned ring0 = wb0 - (p * 32 + 4 * q) * 4;       // byte address of the layer-0 buffer
             // coordinate q of sample p from the XYZ tile (feature i = q)
             const float pc = q < 3 ? *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(
                                          lds0 + RING_BYTES + (wave * SLOT + SL::Q * 256 + (p >> 2) * 64 + q * 4 + (p & 3)) * 4))
@@ -990,7 +1013,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 __syncthreads();
                 own_outer_a<2>(aBT, fb, SL::EMB, SL::Q, 1, 6, wave);                              // dB^T
             }
-            if (want_r) lin_lds<1, 6, 96, OBP>(dpe, ring0 + (p * 96 + 4 * q) * 4, demb);         // rows 0..2: dp (q == 0 lanes)
+            if (want_r) lin_lds_swz<1, 6, 96, OBP>(dpe, swz_base_even(ring0, 96, p, q), swd, demb);   // rows 0..2: dp (q == 0 lanes)
         }
         STAMP(9)        // embedding tail (cos recompute, dB^T, dp)
         if (want_r && tvalid) {         // hand-off to grid_bwd_kernel: dC (register layout) + embedding's position gradient

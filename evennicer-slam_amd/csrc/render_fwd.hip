@@ -58,7 +58,7 @@ ENS_DEV void xyz_layer(const float* __restrict__ pk, const f32x4 (&emb)[NTL][6],
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
         const unsigned bits = fwd_pos_bits(acc[tl][0]) | (fwd_pos_bits(acc[tl][1]) << 4);
-        if (I < 4) mb[tl][0] |= bits << (8 * I); else mb[tl][1] = bits;
+        if constexpr (I < 4) mb[tl][0] |= bits << (8 * I); else mb[tl][1] = bits;
     }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {

@@ -298,8 +298,9 @@ __global__ __launch_bounds__(256) void pack_kernel(PackJob job, float* __restric
     const int n = s.rows * s.cols;
     for (int e = blockIdx.y * 256 + threadIdx.x; e < n; e += 256 * gridDim.y) {
         const int r = e / s.cols, c = e - r * s.cols;
-        float* src = s.src + (s.transpose ? (int64_t)c * s.src_ld + r : (int64_t)r * s.src_ld + c);
-        float* dst = (job.packed[s.dec] ? job.packed[s.dec] : packed) + s.off + r * s.dst_ld + c;
+        float* src = s.src + ((s.transpose & 1) ? (int64_t)c * s.src_ld + r : (int64_t)r * s.src_ld + c);
+        const int cs = (s.transpose & 2) ? ((((c >> 2) ^ ((r & 15) >> 1)) << 2) | (c & 3)) : c;   // lds_util.hpp: swizzled image
+        float* dst = (job.packed[s.dec] ? job.packed[s.dec] : packed) + s.off + r * s.dst_ld + cs;
         if (unpack) *src = *dst; else *dst = *src;
     }
 }

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): kernel-time stats of the default bench run (hipGraph replay) and of an eager
+# run, then HBM traffic counters in separate --pmc passes.  Everything lands in gpurun_out/prof_round/; the summaries
+# worth keeping are copied into profiles/ by hand.
+set -e
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/graph -o g -- python3 $R/bench.py --steps 100 --warmup 10 > $O/graph.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/eager -o e -- python3 $R/bench.py --steps 50 --warmup 10 --eager > $O/eager.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+  tag=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o p -- python3 $R/bench.py --steps 10 --warmup 3 --eager > $O/pmc_$tag.log 2>&1
+done
+python3 - <<PY
+import csv, glob, json, collections
+O = "$O"
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(O + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+        acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, cs in acc.items():
+    if not any(s in k for s in ("decoder_bwd", "render_fwd", "grid_bwd", "convert_kernel", "composite", "sample_kernel")): continue
+    d = {c: sum(v) / len(v) for c, v in cs.items()}
+    d["dispatches"] = max(len(v) for v in cs.values())
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        d["bytes_per_launch"] = int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
+    out[k] = d
+json.dump(out, open(O + "/pmc_summary.json", "w"), indent=1)
+print(json.dumps({k: v.get("bytes_per_launch") for k, v in out.items()}, indent=1))
+PY
+tail -1 $O/graph.log | cut -c1-200
