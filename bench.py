@@ -179,6 +179,8 @@ def main():
         if dmax_static is not None:
             dmax_static.copy_(PAR.global_depth_max(gd))
 
+    seed_grad = {}
+
     def local_step():
         # a mapper iteration follows an optimiser step: grids and decoders have changed, so the voxel-major
         # copies and the packed decoders are rebuilt every step (no caching credit in the timed region)
@@ -192,7 +194,9 @@ def main():
             loss = mapper_loss(depth, color, gd, gc, stage)
         else:
             loss = E.losses.rgbd_loss(depth, color if stage == 'color' else None, gd, gc, 0.2)
-        loss.backward()
+        if 'one' not in seed_grad:              # d(loss)/d(loss) = 1, allocated once (backward() would fill one per step)
+            seed_grad['one'] = torch.ones_like(loss)
+        loss.backward(gradient=seed_grad['one'])
         return loss
 
     def post():         # one bucketed RCCL all-reduce of the leaf gradients

@@ -216,11 +216,17 @@ int enslam_grids_convert_sparse(int32_t n, const float* const* src, float* const
 }
 
 int enslam_zero_blocks(int32_t n, float* const* dst, const int64_t* n_voxels, const uint8_t* const* need,
-                       void* stream) {
-    if (n == 0) return ENSLAM_OK;
+                       float* flat, int64_t n_flat, void* stream) {
+    if (n_flat < 0 || (n_flat > 0 && !flat)) return ENSLAM_EINVAL;
+    if (n == 0 && n_flat == 0) return ENSLAM_OK;
     ConvJob job;
-    if (!make_conv_job(n, nullptr, dst, n_voxels, need, nullptr, false, job)) return ENSLAM_EINVAL;
-    return ens_launch_zero_blocks(job, (hipStream_t)stream);
+    if (n == 0) {
+        job.n = 0;
+        for (int i = 0; i < 5; ++i) job.block_begin[i] = 0;
+    } else if (!make_conv_job(n, nullptr, dst, n_voxels, need, nullptr, false, job)) {
+        return ENSLAM_EINVAL;
+    }
+    return ens_launch_zero_blocks(job, flat, n_flat, (hipStream_t)stream);
 }
 
 int enslam_mark_blocks(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,

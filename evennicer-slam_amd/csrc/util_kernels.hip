@@ -38,8 +38,21 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
                                                      double hi2, const float* __restrict__ t_lin,
                                                      const double* __restrict__ t_surf, int lindisp,
                                                      const float* __restrict__ t_rand,
-                                                     const float* __restrict__ dmax, double* __restrict__ zout) {
+                                                     const float* __restrict__ dmax, int dmax_inline,
+                                                     double* __restrict__ zout) {
     const int ray = blockIdx.x, lane = threadIdx.x;
+    float dmax0 = 0.f, dmax1 = 0.f;                     // max(gt_depth) over the batch and fl32(max * 1.2f)
+    if (gd != nullptr) {
+        if (dmax_inline) {                              // small batch: every wave reduces the (L2-resident) depths itself
+            float m = -INFINITY;
+            for (int i = lane; i < n_rays; i += 64) m = fmaxf(m, gd[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            dmax0 = m; dmax1 = m * 1.2f;
+        } else {
+            dmax0 = dmax[0]; dmax1 = dmax[1];
+        }
+    }
     const double lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
     double far_bb = INFINITY;
 #pragma unroll
@@ -56,7 +69,7 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
     double far = far_bb;
     if (guided) {
         near32 = g * 0.01f;
-        const double cap = (double)dmax[1];             // fl32(max(gd)*1.2f)
+        const double cap = (double)dmax1;               // fl32(max(gd)*1.2f)
         far = far_bb < 0.0 ? 0.0 : far_bb;              // clamp(min=0, max=cap)
         far = far > cap ? cap : far;
     }
@@ -82,7 +95,7 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
         if (lane >= n_lin && lane < S) {
             const float a32 = 0.95f * g, b32 = 1.05f * g;
             const double ts = t_surf[lane - n_lin];
-            z = g > 0.f ? (double)a32 * (1.0 - ts) + (double)b32 * ts : 0.001 * (1.0 - ts) + (double)dmax[0] * ts;
+            z = g > 0.f ? (double)a32 * (1.0 - ts) + (double)b32 * ts : 0.001 * (1.0 - ts) + (double)dmax0 * ts;
         }
 #pragma unroll
         for (int k = 2; k <= 64; k <<= 1) {              // bitonic sort, ascending over the 64 lanes
@@ -210,7 +223,12 @@ __global__ __launch_bounds__(256) void convert_kernel(ConvJob job, int to_vm) {
 }
 
 // zero the flagged 64-voxel blocks (8 KB each) of voxel-major buffers
-__global__ __launch_bounds__(256) void zero_blocks_kernel(ConvJob job) {
+__global__ __launch_bounds__(256) void zero_blocks_kernel(ConvJob job, float* __restrict__ flat, int64_t n_flat) {
+    if ((int)blockIdx.x >= job.block_begin[job.n]) {    // trailing blocks: a flat float range (2048 floats each)
+        const int64_t e0 = ((int64_t)blockIdx.x - job.block_begin[job.n]) * 2048;
+        for (int64_t e = e0 + threadIdx.x; e < e0 + 2048 && e < n_flat; e += 256) flat[e] = 0.f;
+        return;
+    }
     int g = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i) g = (i < job.n && (int)blockIdx.x >= job.block_begin[i]) ? i : g;
@@ -327,9 +345,10 @@ int ens_launch_convert(const ConvJob& job, bool to_vm, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int ens_launch_zero_blocks(const ConvJob& job, hipStream_t st) {
-    if (job.n <= 0 || job.block_begin[job.n] <= 0) return 0;
-    zero_blocks_kernel<<<dim3(job.block_begin[job.n]), dim3(256), 0, st>>>(job);
+int ens_launch_zero_blocks(const ConvJob& job, float* flat, int64_t n_flat, hipStream_t st) {
+    const int64_t nb = job.block_begin[job.n] + (flat != nullptr && n_flat > 0 ? (n_flat + 2047) / 2048 : 0);
+    if (nb <= 0) return 0;
+    zero_blocks_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(job, flat, flat ? n_flat : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -348,10 +367,11 @@ int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const 
                       float* scratch, int dmax_given, double* z, hipStream_t st) {
     if (n_rays <= 0) return 0;
     if (n_lin + n_surf > MAX_S || n_lin < 1) return -1;
-    if (gd != nullptr && !dmax_given) depth_max_kernel<<<1, 1024, 0, st>>>(n_rays, gd, scratch);
+    const int dmax_inline = (gd != nullptr && !dmax_given && n_rays <= 4096) ? 1 : 0;
+    if (gd != nullptr && !dmax_given && !dmax_inline) depth_max_kernel<<<1, 1024, 0, st>>>(n_rays, gd, scratch);
     sample_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(n_rays, n_lin, gd ? n_surf : 0, ro, rd, gd, b[0], b[1],
                                                                  b[2], b[3], b[4], b[5], t_lin, t_surf, lindisp,
-                                                                 t_rand, scratch, z);
+                                                                 t_rand, scratch, dmax_inline, z);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

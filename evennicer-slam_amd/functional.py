@@ -107,6 +107,23 @@ def _check_params(kind, ps):
         _require_hip(t, "decoder parameters")
 
 
+class _ZeroArena:
+    """One zero-filled allocation per render call, handed out in aligned typed slices (block flags, validity
+    bitmaps, packed-decoder buffers): one fill node in the step's graph instead of one per consumer."""
+
+    def __init__(self, device, nbytes):
+        self.buf = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        self.off = 0
+
+    def take(self, n, dtype):
+        nb = n * torch.empty((), dtype=dtype).element_size()
+        off = (self.off + 15) & ~15
+        if off + nb > self.buf.numel():
+            return torch.zeros(n, dtype=dtype, device=self.buf.device)
+        self.off = off + nb
+        return self.buf[off:off + nb].view(dtype)
+
+
 class _PackCache:
     """Packed form of a decoder, refreshed when any parameter's (data_ptr, _version) changes."""
 
@@ -130,7 +147,7 @@ class _PackCache:
 _pack_caches = weakref.WeakKeyDictionary()      # decoder module -> _PackCache
 
 
-def packed_decoders(items):
+def packed_decoders(items, arena=None):
     """Packed forms of several decoders [(module, kind, params)]; stale ones are rebuilt with ONE zero-fill and ONE
     launch (up to three decoders per launch)."""
     out, stale = [], []
@@ -147,7 +164,8 @@ def packed_decoders(items):
     if stale:
         lib = L.lib()
         sizes = [lib.enslam_packed_floats(items[i][1]) for i, _, _ in stale]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=items[stale[0][0]][2][0].device)
+        flat = (arena.take(sum(sizes), torch.float32) if arena is not None else
+                torch.zeros(sum(sizes), dtype=torch.float32, device=items[stale[0][0]][2][0].device))
         pieces = flat.split(sizes)
         for j, (i, cache, key) in enumerate(stale):
             _check_params(items[i][1], items[i][2])
@@ -237,7 +255,7 @@ class _GridCache:
         return out
 
 
-    def get_many_sparse(self, grids, need):
+    def get_many_sparse(self, grids, need, arena=None):
         """Voxel-major copies in which (at least) the 64-voxel blocks flagged in need[i] (uint8 tensors) are valid.
         Every entry carries a `valid` bitmap; one launch converts the blocks that are needed and not yet valid."""
         n = len(grids)
@@ -253,7 +271,8 @@ class _GridCache:
                 _require_hip(g, "feature grids")
                 V = g.shape[2] * g.shape[3] * g.shape[4]
                 vm = torch.empty((V, 32), dtype=torch.float32, device=g.device)
-                valid = torch.zeros((V + 63) // 64, dtype=torch.uint8, device=g.device)
+                valid = (arena.take((V + 63) // 64, torch.uint8) if arena is not None else
+                         torch.zeros((V + 63) // 64, dtype=torch.uint8, device=g.device))
                 key, items = id(g), self.items
                 items[key] = (weakref.ref(g, lambda _r, key=key, items=items: items.pop(key, None)), g._version, vm, valid)
             src = g.detach()
@@ -319,6 +338,7 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, rays_o, rays_d, gt_depth, t_rand, *tensors):
         lib = L.lib()
+        ctx.set_materialize_grads(False)          # unused outputs (the variance) arrive as None, not as a zero fill
         nk = len(plan.kinds)
         grids = tensors[:nk]
         N = rays_o.shape[0]
@@ -337,7 +357,8 @@ class _RenderFn(torch.autograd.Function):
         # blocks of 64 voxels this batch touches, per grid (one zeroed byte buffer for all grids)
         dims = {k: tuple(g.shape[2:]) for k, g in zip(plan.kinds, grids)}
         nblk = [(dims[k][0] * dims[k][1] * dims[k][2] + 63) // 64 for k in plan.kinds]
-        flag_buf = torch.zeros(sum(nblk), dtype=torch.uint8, device=dev)
+        arena = _ZeroArena(dev, 2 * sum(nblk) + 4 * sum(lib.enslam_packed_floats(k) for k in plan.kinds) + 256)
+        flag_buf = arena.take(sum(nblk), torch.uint8)
         flags = list(flag_buf.split(nblk))
         fptr = (ctypes.c_void_p * 4)()
         msc = L.Scene()
@@ -349,11 +370,11 @@ class _RenderFn(torch.autograd.Function):
                 "enslam_mark_blocks")
         grids_vm, packed = {}, {}
         po, items = nk, []
-        for k, g, vm in zip(plan.kinds, grids, _grid_cache.get_many_sparse(grids, flags)):
+        for k, g, vm in zip(plan.kinds, grids, _grid_cache.get_many_sparse(grids, flags, arena)):
             grids_vm[k] = vm
             items.append((plan.decoders[k], k, tensors[po:po + plan.n_params[k]]))
             po += plan.n_params[k]
-        for k, pk in zip(plan.kinds, packed_decoders(items)):
+        for k, pk in zip(plan.kinds, packed_decoders(items, arena)):
             packed[k] = pk
         sc = _scene_struct(plan.stage, plan.bound6, plan.coarse_bound6, grids_vm, dims, packed)
         depth = torch.empty(N, dtype=torch.float64, device=dev)
@@ -418,18 +439,18 @@ class _RenderFn(torch.autograd.Function):
         # decoder / ray accumulators are small and zero-filled whole
         n_grid = offs[nk]
         gbuf = torch.empty(max(n_grid, 1), dtype=torch.float32, device=dev)
-        zbuf = torch.zeros(max(offs[-1] - n_grid, 1), dtype=torch.float32, device=dev)
+        n_flat = offs[-1] - n_grid
+        zbuf = torch.empty(max(n_flat, 1), dtype=torch.float32, device=dev)      # zeroed by the launch below
         gbase, zbase = gbuf.data_ptr(), zbuf.data_ptr() - 4 * n_grid
         g_grids_vm, g_packed = {}, {}
         zl = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k]]
-        if zl:
-            n = len(zl)
-            dsts, vs, need_ptrs = (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), (ctypes.c_void_p * n)()
-            for j, (i, k) in enumerate(zl):
-                g_grids_vm[k] = gbase + 4 * offs[i]
-                gg[k].data = g_grids_vm[k]
-                dsts[j], vs[j], need_ptrs[j] = g_grids_vm[k], sizes[i] // 32, flags[i].data_ptr()
-            L.check(lib.enslam_zero_blocks(n, dsts, vs, need_ptrs, st), "enslam_zero_blocks")
+        n = len(zl)
+        dsts, vs, need_ptrs = (ctypes.c_void_p * max(n, 1))(), (ctypes.c_int64 * max(n, 1))(), (ctypes.c_void_p * max(n, 1))()
+        for j, (i, k) in enumerate(zl):
+            g_grids_vm[k] = gbase + 4 * offs[i]
+            gg[k].data = g_grids_vm[k]
+            dsts[j], vs[j], need_ptrs[j] = g_grids_vm[k], sizes[i] // 32, flags[i].data_ptr()
+        L.check(lib.enslam_zero_blocks(n, dsts, vs, need_ptrs, _ptr(zbuf), n_flat, st), "enslam_zero_blocks")
         for i, k in enumerate(plan.kinds):
             if need_par[k]:
                 g_packed[k] = zbase + 4 * offs[nk + i]

@@ -116,14 +116,15 @@ int enslam_grids_convert(int32_t n, const float *const *src, float *const *dst, 
  * enslam_grids_convert_sparse, to_voxel_major != 0: converts blocks with need && !valid and sets valid (valid: uint8
  *   bitmap that lives with the voxel-major copy; zero it when the source grid changes).
  *   to_voxel_major == 0 (gradients back to [32,V]): blocks with need are transposed, all others written as zeros.
- * enslam_zero_blocks: zero-fills the flagged blocks of voxel-major buffers (gradient accumulators). */
+ * enslam_zero_blocks: zero-fills the flagged blocks of voxel-major buffers (gradient accumulators) and, in the same
+ *   launch, the flat float range [flat, flat + n_flat) (the small decoder / ray accumulators; may be NULL / 0). */
 int enslam_mark_blocks(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                        const double *z_vals, const enslam_scene *scene, uint8_t *const *flags, void *stream);
 int enslam_grids_convert_sparse(int32_t n, const float *const *src, float *const *dst, const int64_t *n_voxels,
                                 const uint8_t *const *need, uint8_t *const *valid, int32_t to_voxel_major,
                                 void *stream);
 int enslam_zero_blocks(int32_t n, float *const *dst, const int64_t *n_voxels, const uint8_t *const *need,
-                       void *stream);
+                       float *flat, int64_t n_flat, void *stream);
 
 /* Sample distances along rays.  Replaces Renderer.render_batch_ray lines 83-171
  * (src/utils/Renderer.py): near/far from gt_depth and the AABB exit, n_lin linear samples,
