@@ -336,6 +336,20 @@ int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const f
                                   grad_packed, g_rays_o, g_rays_d, (hipStream_t)stream);
 }
 
+int enslam_ray_grad_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                        const double* z_vals, const enslam_scene* scene, float* dgrid_ws, float* g_rays_o,
+                        float* g_rays_d, void* stream) {
+    if (n_rays < 0) return ENSLAM_EINVAL;
+    if (n_rays == 0 || stage == ENSLAM_STAGE_COARSE) return ENSLAM_OK;
+    if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
+    DevScene d;
+    if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
+    if (!rays_o || !rays_d || !z_vals || !dgrid_ws || !g_rays_o || !g_rays_d) return ENSLAM_EINVAL;
+    const int rc = ens_launch_ray_grad_bwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, dgrid_ws, g_rays_o,
+                                           g_rays_d, (hipStream_t)stream);
+    return rc == 0 ? ENSLAM_OK : (rc == -1 ? ENSLAM_EINVAL : ENSLAM_ELAUNCH);
+}
+
 int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                       const double* z_vals, const enslam_scene* scene, const float* raw, const double* depth,
                       const double* g_depth, const double* g_var, const float* g_rgb, const enslam_grid* grad_grids,
@@ -344,8 +358,11 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
     if (!g_depth && !g_var && !g_rgb) return ENSLAM_EINVAL;
     const int rc = enslam_composite_bwd(n_rays, n_samples, raw, z_vals, depth, g_depth, g_var, g_rgb, d_raw, stream);
     if (rc != ENSLAM_OK) return rc;
-    return enslam_decoder_bwd(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, d_raw, act_ws, dgrid_ws,
-                              grad_grids, grad_packed, g_rays_o, g_rays_d, stream);
+    const int rd = enslam_decoder_bwd(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, d_raw, act_ws, dgrid_ws,
+                                      grad_grids, grad_packed, g_rays_o, g_rays_d, stream);
+    if (rd != ENSLAM_OK || !act_ws || !g_rays_o || !g_rays_d || stage == ENSLAM_STAGE_COARSE) return rd;
+    return enslam_ray_grad_bwd(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, dgrid_ws, g_rays_o, g_rays_d,
+                               stream);
 }
 
 int enslam_rgbd_loss_fwd(int32_t n, const double* depth, const float* color, const float* gt_depth,

@@ -31,6 +31,8 @@ struct ConvJob {                 // up to 4 grids converted in one launch
 int ens_launch_pack(const PackJob& job, float* packed, bool unpack, hipStream_t st);
 int ens_launch_transpose(const float* src, float* dst, int64_t n_vox, bool to_voxel_major, hipStream_t st);
 int ens_launch_convert(const ConvJob& job, bool to_voxel_major, hipStream_t st);
+int ens_launch_ray_grad_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
+                            const DevScene& sc, float* dgrid_ws, float* g_ro, float* g_rd, hipStream_t st);
 int ens_launch_zero_blocks(const ConvJob& job, float* flat, int64_t n_flat, hipStream_t st);
 int ens_launch_mark_blocks(int stage, int n_rays, int S, const float* ro, const float* rd, const double* z,
                            const DevScene& sc, uint8_t* const* flags, hipStream_t st);

@@ -1381,11 +1381,28 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         attr_set = true;
     }
     if (A.act_ws != nullptr) {
-        decoder_bwd_kernel<true><<<dim3(total), dim3(256), lds_saved, st>>>(A);
-        if (A.g_ro != nullptr && hipGetLastError() == hipSuccess)
-            grid_bwd_kernel<<<dim3((unsigned)(n_tiles * n2)), dim3(64), 0, st>>>(A, n2);
+        decoder_bwd_kernel<true><<<dim3(total), dim3(256), lds_saved, st>>>(A);      // ray gradients: ens_launch_ray_grad_bwd
     } else {
         decoder_bwd_kernel<false><<<dim3(total), dim3(256), lds, st>>>(A);
     }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Second kernel of the saved-activation backward: ray gradients from the decoder kernel's hand-off buffer.
+int ens_launch_ray_grad_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
+                            const DevScene& sc, float* dgrid_ws, float* g_ro, float* g_rd, hipStream_t st) {
+    if (n_rays <= 0 || stage == 0) return 0;
+    if (!dgrid_ws || !g_ro || !g_rd) return -1;
+    BwdArgs A;
+    A.act_ws = nullptr;
+    A.dgrid_ws = dgrid_ws;
+    A.n_rays = n_rays; A.ntl = ntl; A.ro = ro; A.rd = rd; A.z = z; A.d_raw = nullptr; A.sc = sc;
+    A.g_ro = g_ro; A.g_rd = g_rd;
+    for (int k = 0; k < 4; ++k) { A.ggrid[k] = DevGrid{nullptr, 0, 0, 0}; A.gpacked[k] = nullptr; A.role_kind[k] = -1; }
+    const int n2 = stage;                                   // middle | middle+fine | middle+fine+color
+    for (int i = 0; i < n2; ++i) A.role_kind[i] = i + 1;
+    A.n_roles = n2;
+    const int64_t n_tiles = (int64_t)n_rays * ntl;
+    grid_bwd_kernel<<<dim3((unsigned)(n_tiles * n2)), dim3(64), 0, st>>>(A, n2);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -465,18 +465,21 @@ class _RenderFn(torch.autograd.Function):
         d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
         L.check(lib.enslam_composite_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
                                          _ptr(d_raw), st), "enslam_composite_bwd")
+        dgw = None
+        if act is not None and need_rays:
+            dgw = torch.empty(lib.enslam_grid_handoff_floats(L.STAGE[plan.stage], N, S), dtype=torch.float32, device=dev)
         ev = PROFILE.get('decoder_bwd')
         if ev is not None:                      # bench.py: HIP events around the dominant kernel, on this stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        dgw = None
-        if act is not None and need_rays:
-            dgw = torch.empty(lib.enslam_grid_handoff_floats(L.STAGE[plan.stage], N, S), dtype=torch.float32, device=dev)
         L.check(lib.enslam_decoder_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                        _ptr(d_raw), _ptr(act), _ptr(dgw), gg, gpk, p_ro, p_rd, st), "enslam_decoder_bwd")
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
+        if dgw is not None and plan.stage != 'coarse':      # saved-activation path: ray gradients in their own kernel
+            L.check(lib.enslam_ray_grad_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
+                                            _ptr(dgw), p_ro, p_rd, st), "enslam_ray_grad_bwd")
         out = [None, g_ro if needs[1] else None, g_rd if needs[2] else None, None, None]
         # grid gradients back to the callers' [1,32,D,H,W] layout: one launch for all grids
         conv = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k]]

@@ -185,8 +185,11 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
 /* The two halves of enslam_render_bwd, callable on their own.
  * enslam_composite_bwd: backward of raw2outputs_nerf_color (common.py:284-296): d(depth,var,rgb) -> d_raw [N*S,4].
  * enslam_decoder_bwd  : everything upstream of raw (decoders, gather, points), consuming d_raw.  With act_ws and
- *   (from the size query above) it reads the saved activations and cell records, and ray gradients come from a
- *   second small kernel fed through dgrid_ws; with act_ws NULL everything is recomputed in one kernel. */
+ *   (from the size query above) it reads the saved activations and cell records and leaves what the ray gradients
+ *   need in dgrid_ws: follow it with enslam_ray_grad_bwd (enslam_render_bwd does).  With act_ws NULL everything,
+ *   ray gradients included, is recomputed in the one kernel and enslam_ray_grad_bwd must not be called.
+ * enslam_ray_grad_bwd : ray gradients of the saved-activation path (fp64 sample geometry, corner re-gather,
+ *   coordinate gradient, per-ray reduction) from dgrid_ws, added into g_rays_o / g_rays_d. */
 int enslam_composite_bwd(int32_t n_rays, int32_t n_samples, const float *raw, const double *z_vals,
                          const double *depth, const double *g_depth, const double *g_var, const float *g_rgb,
                          float *d_raw, void *stream);
@@ -194,6 +197,9 @@ int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const f
                        const double *z_vals, const enslam_scene *scene, const float *d_raw, const float *act_ws,
                        float *dgrid_ws, const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o,
                        float *g_rays_d, void *stream);
+int enslam_ray_grad_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                        const double *z_vals, const enslam_scene *scene, float *dgrid_ws, float *g_rays_o,
+                        float *g_rays_d, void *stream);
 
 /* raw2outputs_nerf_color (common.py:256-297, occupancy=True) on its own: raw float32 [N,S,4], z_vals float64 [N,S]
  * -> depth/var float64 [N], rgb float32 [N,3], weights float32 [N,S] (may be NULL).  1 <= S <= 64. */
