@@ -144,12 +144,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU implementation")
+    # rehearsal on a one-GPU box: ENSLAM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and ENSLAM_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device); the measured runs use neither
+    if os.environ.get('ENSLAM_BENCH_SHARE_GPU') == '1':
+        local_rank = 0
+    backend = os.environ.get('ENSLAM_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import evennicer_slam_amd as E
     import evennicer_slam_amd.functional as EF
@@ -179,7 +187,7 @@ def main():
         if dmax_static is not None:
             dmax_static.copy_(PAR.global_depth_max(gd))
 
-    seed_grad = {}
+    seed_grad, comm = {}, {'bytes': 0}
 
     def local_step():
         # a mapper iteration follows an optimiser step: grids and decoders have changed, so the voxel-major
@@ -201,7 +209,7 @@ def main():
 
     def post():         # one bucketed RCCL all-reduce of the leaf gradients
         if world > 1:
-            PAR.allreduce_gradients(leaves)
+            comm['bytes'] = PAR.allreduce_gradients(leaves, block_flags=EF.last_block_flags())
 
     def step():
         pre()
@@ -281,7 +289,8 @@ def main():
         "config": {"workload": f"Replica {args.scene} full 4-level grid, stage {stage}, {args.rays} rays x {S} samples "
                                f"per GPU, render_batch_ray + mapper loss + backward (grads: grids, all decoder params, rays)",
                    "rays_per_gpu": args.rays, "samples_per_ray": S,
-                   "parallelism": "1 GPU" if world == 1 else f"ray-sharded dp{world}, one bucketed RCCL all-reduce of leaf grads"},
+                   "parallelism": "1 GPU" if world == 1 else f"ray-sharded dp{world}, one bucketed RCCL all-reduce of leaf grads "
+                                                            f"(touched 64-voxel blocks only: {comm['bytes'] / 1e6:.1f} MB per step)"},
         "loss": float(loss.item()), "mode": mode, "loss_impl": "torch" if args.torch_loss else "fused HIP (losses.rgbd_loss)",
         "eager_rays_per_s": world * args.rays * eager_steps / eager_elapsed,
     }

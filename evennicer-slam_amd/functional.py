@@ -315,6 +315,15 @@ def stage_kinds(stage):
 # ------------------------------------------------------------------------------------------------
 # the differentiable render call
 # ------------------------------------------------------------------------------------------------
+_last_flags = {}        # id(grid tensor) -> uint8 flags of the 64-voxel blocks the latest render call touched
+
+
+def last_block_flags():
+    """{id(grid tensor): flags} of the most recent render call (parallel.allreduce_gradients uses them to send only
+    the touched blocks).  Under hipGraph replay the flag buffers are rewritten in place by every replay."""
+    return dict(_last_flags)
+
+
 class RenderPlan:
     """Static description of one render_batch_ray call (everything that is not a differentiable tensor)."""
 
@@ -368,6 +377,9 @@ class _RenderFn(torch.autograd.Function):
             msc.grids[k].D, msc.grids[k].H, msc.grids[k].W = dims[k]
         L.check(lib.enslam_mark_blocks(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(msc), fptr, st),
                 "enslam_mark_blocks")
+        _last_flags.clear()
+        for g, fl in zip(grids, flags):
+            _last_flags[id(g)] = fl
         grids_vm, packed = {}, {}
         po, items = nk, []
         for k, g, vm in zip(plan.kinds, grids, _grid_cache.get_many_sparse(grids, flags, arena)):

@@ -25,31 +25,41 @@ def global_depth_max(gt_depth_local, group=None):
     return torch.cat([m, m * 1.2]).contiguous()
 
 
-def _touched_ranges(grads, group):
-    """For feature-grid gradients [1,C,D,H,W] (nonzero only where this step's rays passed): the union over ranks
-    of the touched range [lo, hi) of the flattened voxel index (z-major).  One small MAX all-reduce + one host
-    read; lets the bucket carry only that slab of every channel row instead of the whole grid."""
-    if not grads:
-        return []
-    dev = grads[0].device
-    stats = []
+def block_flags_of(grads):
+    """uint8 flags of the 64-voxel blocks (flattened z-major voxel index) in which a feature-grid gradient
+    [1,C,D,H,W] is nonzero -- the fallback when the renderer's own flags (functional.last_block_flags) are not at
+    hand (e.g. CPU tests)."""
+    out = []
     for g in grads:
-        V = g.shape[2] * g.shape[3] * g.shape[4]
-        prof = g.reshape(g.shape[1], V).abs().amax(dim=0) > 0                 # [V] touched by this rank
-        idx = torch.arange(V, device=dev)
-        lo = torch.where(prof, idx, torch.full_like(idx, V)).min()
-        hi = torch.where(prof, idx + 1, torch.zeros_like(idx)).max()
-        stats += [-lo, hi]                                                      # MAX-reduce both
-    st = torch.stack(stats).to(torch.int64)
-    dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)
-    vals = st.tolist()
-    return [(max(0, -vals[2 * i]), vals[2 * i + 1]) for i in range(len(grads))]
+        C, V = g.shape[1], g.shape[2] * g.shape[3] * g.shape[4]
+        touched = (g.reshape(C, V) != 0).any(dim=0)
+        pad = (-V) % 64
+        if pad:
+            touched = torch.cat([touched, touched.new_zeros(pad)])
+        out.append(touched.view(-1, 64).any(dim=1).to(torch.uint8))
+    return out
 
 
-def allreduce_gradients(tensors, group=None, compact_grids=True):
-    """Sum `.grad` of the given leaf tensors over ranks through one flat bucket (one collective per step).
+def _gather_blocks(g, idx):
+    """g: gradient [1,C,D,H,W]; idx: int64 indices of 64-voxel blocks -> (main [C,n,64] copy, tail view or None)."""
+    C, V = g.shape[1], g.shape[2] * g.shape[3] * g.shape[4]
+    g2 = g.reshape(C, V)
+    nfull = V // 64
+    full = idx[idx < nfull]
+    main = g2[:, :nfull * 64].view(C, nfull, 64)
+    tail = g2[:, nfull * 64:] if (V > nfull * 64 and bool((idx == nfull).any())) else None
+    return main, full, tail
+
+
+def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=None):
+    """Sum `.grad` of the given leaf tensors over ranks through one flat bucket (one SUM collective per step).
     Leaves whose grad is None on this rank contribute zeros, so every rank issues the same collectives.
-    compact_grids: 5-D feature-grid gradients contribute only the slab of voxels touched on any rank."""
+
+    Feature-grid gradients ([1,C,D,H,W]) are nonzero only in the 64-voxel blocks this step's rays touched.  With
+    compact_grids the bucket carries, per grid, only the union over ranks of those blocks: one small MAX
+    all-reduce of the block flags (block_flags: {id(tensor): uint8 flags}, normally functional.last_block_flags();
+    derived from the gradients when absent), a gather of the flagged blocks, the SUM all-reduce, a scatter back.
+    Returns the bucket size in bytes."""
     tensors = [t for t in tensors if t is not None and t.requires_grad]
     if not tensors or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 0
@@ -58,26 +68,43 @@ def allreduce_gradients(tensors, group=None, compact_grids=True):
         if t.grad is None:
             t.grad = torch.zeros_like(t)
     grid_ids = [i for i, t in enumerate(tensors) if compact_grids and t.dim() == 5 and t.shape[0] == 1]
-    ranges = dict(zip(grid_ids, _touched_ranges([tensors[i].grad for i in grid_ids], group)))
-    views = []
+    plans = {}
+    if grid_ids:
+        flags = []
+        for i in grid_ids:
+            f = block_flags.get(id(tensors[i])) if block_flags else None
+            flags.append(f if f is not None else block_flags_of([tensors[i].grad])[0])
+        sizes_f = [f.numel() for f in flags]
+        allf = torch.cat([f.reshape(-1).to(torch.uint8) for f in flags])
+        dist.all_reduce(allf, op=dist.ReduceOp.MAX, group=group)          # union of the touched blocks
+        for i, f in zip(grid_ids, allf.split(sizes_f)):
+            idx = torch.nonzero(f, as_tuple=False).reshape(-1)             # (host sync: the bucket size is needed)
+            plans[i] = _gather_blocks(tensors[i].grad, idx)
+    parts = []
     for i, t in enumerate(tensors):
-        if i in ranges:
-            lo, hi = ranges[i]
-            V = t.shape[2] * t.shape[3] * t.shape[4]
-            views.append(t.grad.reshape(t.shape[1], V)[:, lo:max(hi, lo)])       # strided slab of every channel row
+        if i in plans:
+            main, full, tail = plans[i]
+            parts.append(main.index_select(1, full).reshape(-1))
+            if tail is not None:
+                parts.append(tail.reshape(-1))
         else:
-            views.append(t.grad.reshape(-1))
-    sizes = [v.numel() for v in views]
-    bucket = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-    o = 0
-    for v, n in zip(views, sizes):
-        bucket[o:o + n].view(v.shape).copy_(v)
-        o += n
+            parts.append(t.grad.reshape(-1))
+    bucket = torch.cat(parts) if len(parts) > 1 else parts[0].clone()
     dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     o = 0
-    for v, n in zip(views, sizes):
-        v.copy_(bucket[o:o + n].view(v.shape))
-        o += n
+    for i, t in enumerate(tensors):
+        if i in plans:
+            main, full, tail = plans[i]
+            n = main.shape[0] * full.numel() * 64
+            main.index_copy_(1, full, bucket[o:o + n].view(main.shape[0], full.numel(), 64))
+            o += n
+            if tail is not None:
+                tail.copy_(bucket[o:o + tail.numel()].view(tail.shape))
+                o += tail.numel()
+        else:
+            n = t.grad.numel()
+            t.grad.copy_(bucket[o:o + n].view(t.grad.shape))
+            o += n
     return bucket.numel() * 4
 
 
