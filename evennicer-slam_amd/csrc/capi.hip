@@ -229,6 +229,31 @@ int enslam_zero_blocks(int32_t n, float* const* dst, const int64_t* n_voxels, co
     return ens_launch_zero_blocks(job, flat, n_flat, (hipStream_t)stream);
 }
 
+int enslam_adam_masked(int32_t n, float* const* param, float* const* grad, float* const* exp_avg,
+                       float* const* exp_avg_sq, const uint8_t* const* mask, const int64_t* n_voxels,
+                       const double* const* lr, const int32_t* const* step, double beta1, double beta2, double eps,
+                       void* stream) {
+    if (n == 0) return ENSLAM_OK;
+    if (n < 0 || n > 4 || !param || !grad || !exp_avg || !exp_avg_sq || !n_voxels || !lr || !step) return ENSLAM_EINVAL;
+    AdamJob job;
+    job.n = n;
+    job.beta1 = beta1; job.beta2 = beta2; job.eps = eps;
+    int64_t blocks = 0;
+    for (int i = 0; i < 4; ++i) {
+        job.block_begin[i] = (int)blocks;
+        if (i >= n) { job.p[i] = job.g[i] = job.m[i] = job.v[i] = nullptr; job.mask[i] = nullptr; job.V[i] = 0; job.lr[i] = nullptr; job.step[i] = nullptr; continue; }
+        if (!param[i] || !grad[i] || !exp_avg[i] || !exp_avg_sq[i] || !lr[i] || !step[i] || n_voxels[i] < 0) return ENSLAM_EINVAL;
+        job.p[i] = param[i]; job.g[i] = grad[i]; job.m[i] = exp_avg[i]; job.v[i] = exp_avg_sq[i];
+        job.mask[i] = mask ? mask[i] : nullptr;
+        job.V[i] = n_voxels[i]; job.lr[i] = lr[i]; job.step[i] = step[i];
+        blocks += (n_voxels[i] + 63) / 64;
+        if (blocks > 0x7fffffff) return ENSLAM_EUNSUPPORTED;
+    }
+    job.block_begin[4] = (int)blocks;
+    for (int i = n; i < 4; ++i) job.block_begin[i] = (int)blocks;
+    return ens_launch_adam(job, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+
 int enslam_mark_blocks(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                        const double* z_vals, const enslam_scene* scene, uint8_t* const* flags, void* stream) {
     if (n_rays < 0 || n_samples < 1 || stage < 0 || stage > 3) return ENSLAM_EINVAL;

@@ -18,6 +18,19 @@ struct PackJob {
     float* packed[4];                        // packed buffers of the decoders of this job
     int n;
 };
+struct AdamJob {                 // masked Adam over up to 4 voxel-major grids in one launch (Mapper.py:328-361,573-602)
+    float* p[4];                 // parameters   [V,32]
+    float* g[4];                 // gradients    [V,32]  (consumed and cleared)
+    float* m[4];                 // exp_avg      [V,32]
+    float* v[4];                 // exp_avg_sq   [V,32]
+    const uint8_t* mask[4];      // [V] 1 = optimisable voxel (null: every voxel)
+    int64_t V[4];
+    const double* lr[4];         // device scalars: learning rate of each grid (float64 like the Python float)
+    const int* step[4];          // device scalars: Adam step count of each grid (already incremented; <= 0: clear only)
+    int block_begin[5];
+    int n;
+    double beta1, beta2, eps;    // Python floats of the optimiser
+};
 struct ConvJob {                 // up to 4 grids converted in one launch
     const float* src[4];
     float* dst[4];
@@ -33,6 +46,7 @@ int ens_launch_transpose(const float* src, float* dst, int64_t n_vox, bool to_vo
 int ens_launch_convert(const ConvJob& job, bool to_voxel_major, hipStream_t st);
 int ens_launch_ray_grad_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
                             const DevScene& sc, float* dgrid_ws, float* g_ro, float* g_rd, hipStream_t st);
+int ens_launch_adam(const AdamJob& job, hipStream_t st);
 int ens_launch_zero_blocks(const ConvJob& job, float* flat, int64_t n_flat, hipStream_t st);
 int ens_launch_mark_blocks(int stage, int n_rays, int S, const float* ro, const float* rd, const double* z,
                            const DevScene& sc, uint8_t* const* flags, hipStream_t st);

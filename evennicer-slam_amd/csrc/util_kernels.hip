@@ -240,6 +240,57 @@ __global__ __launch_bounds__(256) void zero_blocks_kernel(ConvJob job, float* __
     for (int e = threadIdx.x; e < n4; e += 256) dst[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// ------------------------------------------------------------------ masked Adam on voxel-major grids
+// torch.optim.Adam (defaults: no weight decay, no amsgrad) restricted to the voxels of the frustum mask, the way
+// Mapper.optimize_map holds val_grad = val[mask] (Mapper.py:328-361) and steps it (:573-575):
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// One workgroup per 64-voxel block (8 KB per array); a lane owns 4 channels of 8 voxels.  Gradients are cleared on
+// the way (also where the mask is 0: the reference drops those), so the accumulators are all-zero again afterwards.
+__global__ __launch_bounds__(256) void adam_masked_kernel(AdamJob job) {
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) gi = (i < job.n && (int)blockIdx.x >= job.block_begin[i]) ? i : gi;
+    const int64_t blk = blockIdx.x - job.block_begin[gi];
+    const int64_t V = job.V[gi], v0 = blk * 64;
+    const int step = job.step[gi][0];
+    const double lr = job.lr[gi][0];
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (step > 0) {                                      // the scalars torch.optim.Adam forms in Python float64
+        const double bc1 = 1.0 - pow(job.beta1, (double)step);
+        const double bc2 = 1.0 - pow(job.beta2, (double)step);
+        step_size = (float)(lr / bc1);
+        bc2_sqrt = (float)sqrt(bc2);
+    }
+    const float b1 = (float)job.beta1, b2 = (float)job.beta2, eps = (float)job.eps;
+    const float omb1 = (float)(1.0 - job.beta1), omb2 = (float)(1.0 - job.beta2);
+    f32x4* __restrict__ P = reinterpret_cast<f32x4*>(job.p[gi]);
+    f32x4* __restrict__ G = reinterpret_cast<f32x4*>(job.g[gi]);
+    f32x4* __restrict__ M = reinterpret_cast<f32x4*>(job.m[gi]);
+    f32x4* __restrict__ W = reinterpret_cast<f32x4*>(job.v[gi]);
+    const uint8_t* mask = job.mask[gi];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = threadIdx.x + 256 * j;                  // float4 index inside the block: voxel e>>3, channels 4*(e&7)..
+        const int64_t vox = v0 + (e >> 3);
+        if (vox >= V) continue;
+        const int64_t o = vox * 8 + (e & 7);
+        const bool on = step > 0 && (mask == nullptr || mask[vox] != 0);
+        if (on) {
+            const f32x4 g = G[o];
+            f32x4 m = M[o], w = W[o], p = P[o];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                m[r] = m[r] * b1 + omb1 * g[r];
+                w[r] = w[r] * b2 + omb2 * (g[r] * g[r]);
+                const float denom = sqrtf(w[r]) / bc2_sqrt + eps;
+                p[r] = p[r] - step_size * (m[r] / denom);
+            }
+            M[o] = m; W[o] = w; P[o] = p;
+        }
+        G[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // flag the blocks holding the 8 (clamped) corners of every sample in every grid the stage reads
 __global__ __launch_bounds__(256) void mark_blocks_kernel(int64_t n_samples_total, int S, const float* __restrict__ ro,
                                                           const float* __restrict__ rd, const double* __restrict__ z,
@@ -349,6 +400,12 @@ int ens_launch_zero_blocks(const ConvJob& job, float* flat, int64_t n_flat, hipS
     const int64_t nb = job.block_begin[job.n] + (flat != nullptr && n_flat > 0 ? (n_flat + 2047) / 2048 : 0);
     if (nb <= 0) return 0;
     zero_blocks_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(job, flat, flat ? n_flat : 0);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_adam(const AdamJob& job, hipStream_t st) {
+    if (job.n <= 0 || job.block_begin[job.n] <= 0) return 0;
+    adam_masked_kernel<<<dim3(job.block_begin[job.n]), dim3(256), 0, st>>>(job);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

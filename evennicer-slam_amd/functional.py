@@ -324,6 +324,37 @@ def last_block_flags():
     return dict(_last_flags)
 
 
+class VoxelMajorGrid:
+    """A feature grid kept in the kernels' own layout across iterations (see mapper.MaskedGridOptimizer):
+    `vm` float32 [V,32] values, `grad_vm` float32 [V,32] gradient accumulator that render backwards ADD into and
+    the optimiser consumes and clears.  Passing one of these in the `c` dict of Renderer.render_batch_ray skips the
+    per-call layout conversion, block marking, accumulator clearing and transposed-back gradient.  `anchor` is the
+    tensor that ties the object into autograd (its own gradient is always None)."""
+
+    def __init__(self, dims, vm, grad_vm):
+        self.dims = tuple(int(d) for d in dims)
+        V = self.dims[0] * self.dims[1] * self.dims[2]
+        for t, name in ((vm, "vm"), (grad_vm, "grad_vm")):
+            _require_hip(t, name)
+            if tuple(t.shape) != (V, 32) or t.dtype != torch.float32 or not t.is_contiguous():
+                raise L.EnslamError(f"VoxelMajorGrid.{name}: expected contiguous float32 [{V},32], got {tuple(t.shape)} {t.dtype}")
+        self.vm, self.grad_vm = vm, grad_vm
+        self.anchor = torch.zeros(1, dtype=torch.float32, device=vm.device, requires_grad=True)
+        self.has_grad = False           # set by a backward that added into grad_vm
+
+    @property
+    def shape(self):
+        return (1, 32) + self.dims
+
+    @property
+    def device(self):
+        return self.vm.device
+
+    @property
+    def requires_grad(self):
+        return self.anchor.requires_grad
+
+
 class RenderPlan:
     """Static description of one render_batch_ray call (everything that is not a differentiable tensor)."""
 
@@ -338,6 +369,7 @@ class RenderPlan:
         self.kinds = kinds                      # decoder / grid kinds used, ascending
         self.decoders = decoders                # dict kind -> module
         self.n_params = {k: (12 if k == L.MLP_COARSE else 23) for k in kinds}
+        self.vm = {}                            # kind -> VoxelMajorGrid for grids passed in the device layout
 
 
 class _RenderFn(torch.autograd.Function):
@@ -363,27 +395,33 @@ class _RenderFn(torch.autograd.Function):
                                        _ptr(plan.t_lin), _ptr(plan.t_surf), plan.lindisp, _ptr(t_rand),
                                        _ptr(scratch), int(plan.depth_max is not None), _ptr(z), st),
                 "enslam_sample_rays")
-        # blocks of 64 voxels this batch touches, per grid (one zeroed byte buffer for all grids)
-        dims = {k: tuple(g.shape[2:]) for k, g in zip(plan.kinds, grids)}
-        nblk = [(dims[k][0] * dims[k][1] * dims[k][2] + 63) // 64 for k in plan.kinds]
+        # blocks of 64 voxels this batch touches, per grid (one zeroed byte buffer for all grids).  Grids that
+        # arrive in the device layout (plan.vm) need none of this.
+        vmg = plan.vm
+        dims = {k: (vmg[k].dims if k in vmg else tuple(g.shape[2:])) for k, g in zip(plan.kinds, grids)}
+        dense = [(i, k) for i, k in enumerate(plan.kinds) if k not in vmg]
+        nblk = [(dims[k][0] * dims[k][1] * dims[k][2] + 63) // 64 for _, k in dense]
         arena = _ZeroArena(dev, 2 * sum(nblk) + 4 * sum(lib.enslam_packed_floats(k) for k in plan.kinds) + 256)
-        flag_buf = arena.take(sum(nblk), torch.uint8)
-        flags = list(flag_buf.split(nblk))
-        fptr = (ctypes.c_void_p * 4)()
-        msc = L.Scene()
-        msc.bound, msc.coarse_bound = plan.bound6, plan.coarse_bound6
-        for k, fl in zip(plan.kinds, flags):
-            fptr[k] = fl.data_ptr()
-            msc.grids[k].D, msc.grids[k].H, msc.grids[k].W = dims[k]
-        L.check(lib.enslam_mark_blocks(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(msc), fptr, st),
-                "enslam_mark_blocks")
+        flags = [None] * nk
+        grids_vm, packed = {k: vmg[k].vm for k in vmg}, {}
         _last_flags.clear()
-        for g, fl in zip(grids, flags):
-            _last_flags[id(g)] = fl
-        grids_vm, packed = {}, {}
+        if dense:
+            flag_buf = arena.take(sum(nblk), torch.uint8)
+            fptr = (ctypes.c_void_p * 4)()
+            msc = L.Scene()
+            msc.bound, msc.coarse_bound = plan.bound6, plan.coarse_bound6
+            for (i, k), fl in zip(dense, flag_buf.split(nblk)):
+                flags[i] = fl
+                fptr[k] = fl.data_ptr()
+                msc.grids[k].D, msc.grids[k].H, msc.grids[k].W = dims[k]
+                _last_flags[id(grids[i])] = fl
+            L.check(lib.enslam_mark_blocks(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(msc), fptr, st),
+                    "enslam_mark_blocks")
+            dense_grids = [grids[i] for i, _ in dense]
+            for (i, k), vm in zip(dense, _grid_cache.get_many_sparse(dense_grids, [flags[i] for i, _ in dense], arena)):
+                grids_vm[k] = vm
         po, items = nk, []
-        for k, g, vm in zip(plan.kinds, grids, _grid_cache.get_many_sparse(grids, flags, arena)):
-            grids_vm[k] = vm
+        for k in plan.kinds:
             items.append((plan.decoders[k], k, tensors[po:po + plan.n_params[k]]))
             po += plan.n_params[k]
         for k, pk in zip(plan.kinds, packed_decoders(items, arena)):
@@ -436,11 +474,15 @@ class _RenderFn(torch.autograd.Function):
         gg = (L.Grid * 4)()
         gpk = (ctypes.c_void_p * 4)()
         # ONE zero-filled buffer holds every accumulator the kernels add into
+        vmg = plan.vm               # grids in the device layout accumulate into their own grad_vm (kept clear by the optimiser)
         sizes = []
         for k in plan.kinds:
             D, H, W = ctx.dims[k]
             gg[k].D, gg[k].H, gg[k].W = D, H, W
-            sizes.append(D * H * W * 32 if need_grid[k] else 0)
+            sizes.append(D * H * W * 32 if (need_grid[k] and k not in vmg) else 0)
+            if need_grid[k] and k in vmg:
+                gg[k].data = vmg[k].grad_vm.data_ptr()
+                vmg[k].has_grad = True
         for k in plan.kinds:
             sizes.append(lib.enslam_packed_grad_floats(k) if need_par[k] else 0)
         sizes.append(6 * N if need_rays else 0)
@@ -455,7 +497,7 @@ class _RenderFn(torch.autograd.Function):
         zbuf = torch.empty(max(n_flat, 1), dtype=torch.float32, device=dev)      # zeroed by the launch below
         gbase, zbase = gbuf.data_ptr(), zbuf.data_ptr() - 4 * n_grid
         g_grids_vm, g_packed = {}, {}
-        zl = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k]]
+        zl = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k] and k not in vmg]
         n = len(zl)
         dsts, vs, need_ptrs = (ctypes.c_void_p * max(n, 1))(), (ctypes.c_int64 * max(n, 1))(), (ctypes.c_void_p * max(n, 1))()
         for j, (i, k) in enumerate(zl):
@@ -494,7 +536,7 @@ class _RenderFn(torch.autograd.Function):
                                             _ptr(dgw), p_ro, p_rd, st), "enslam_ray_grad_bwd")
         out = [None, g_ro if needs[1] else None, g_rd if needs[2] else None, None, None]
         # grid gradients back to the callers' [1,32,D,H,W] layout: one launch for all grids
-        conv = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k]]
+        conv = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k] and k not in vmg]
         grid_out = {}
         if conv:
             n = len(conv)
@@ -560,7 +602,7 @@ def eval_points(p, decoders, c, stage, bound, apply_mask=True, coarse_bound=None
     grids_vm, dims, packed = {}, {}, {}
     for k in kinds:
         g = c[L.GRID_NAMES[k]]
-        grids_vm[k] = _grid_cache.get(g)
+        grids_vm[k] = g.vm if isinstance(g, VoxelMajorGrid) else _grid_cache.get(g)
         dims[k] = tuple(g.shape[2:])
         packed[k] = packed_decoder(getattr(decoders, L.MLP_NAMES[k]), k)
     if coarse_bound is None:

@@ -78,7 +78,13 @@ class Renderer(object):
         decs = {k: getattr(decoders, L.MLP_NAMES[k]) for k in kinds}
         plan = EF.RenderPlan(stage, self.bound, self._coarse_bound(decoders), n_lin, n_surf, self.lindisp, t_lin,
                              t_surf, kinds, decs, depth_max=self.depth_max_override if gt_depth is not None else None)
-        grids = [c[L.GRID_NAMES[k]] for k in kinds]
+        grids = []
+        for k in kinds:
+            g = c[L.GRID_NAMES[k]]
+            if isinstance(g, EF.VoxelMajorGrid):            # grid held in the device layout (mapper.MaskedGridOptimizer)
+                plan.vm[k] = g
+                g = g.anchor
+            grids.append(g)
         params = []
         for k in kinds:
             params += EF.decoder_params(decs[k], k)

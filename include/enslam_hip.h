@@ -126,6 +126,17 @@ int enslam_grids_convert_sparse(int32_t n, const float *const *src, float *const
 int enslam_zero_blocks(int32_t n, float *const *dst, const int64_t *n_voxels, const uint8_t *const *need,
                        float *flat, int64_t n_flat, void *stream);
 
+/* Mapper glue.  torch.optim.Adam (defaults) on voxel-major grids [V,32], restricted to the voxels whose
+ * mask byte is 1 -- how Mapper.optimize_map optimises val_grad = val[mask] (Mapper.py:328-361, 573-575) without the
+ * val[mask] = val_grad re-materialisation (:448-458, :596-602).  Per grid i: param / grad / exp_avg / exp_avg_sq are
+ * float32 [n_voxels[i]*32]; mask uint8 [n_voxels[i]] or NULL (all voxels); lr[i] (float64) and step[i] (int32) are
+ * DEVICE scalars (learning rate; Adam step count t >= 1 of this update, t <= 0: only clear the gradients) so that a captured
+ * launch follows stage changes.  The gradients are cleared (everywhere, masked or not) by the same launch. */
+int enslam_adam_masked(int32_t n, float *const *param, float *const *grad, float *const *exp_avg,
+                       float *const *exp_avg_sq, const uint8_t *const *mask, const int64_t *n_voxels,
+                       const double *const *lr, const int32_t *const *step, double beta1, double beta2, double eps,
+                       void *stream);
+
 /* Sample distances along rays.  Replaces Renderer.render_batch_ray lines 83-171
  * (src/utils/Renderer.py): near/far from gt_depth and the AABB exit, n_lin linear samples,
  * n_surf near-surface samples (gt_depth>0: [0.95d,1.05d]; else [0.001,max d]), ascending merge.

@@ -1,0 +1,92 @@
+"""-m gpu: the mapper glue on the device layout (mapper.MaskedGridOptimizer + functional.VoxelMajorGrid) against
+the fixture produced by the reference's own optimize_map statements (tests/golden/tiny_mapper_iters.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ('grid_middle', 'grid_fine', 'grid_color')
+STAGE_LR = {'middle': (0.0, 0.1, 0.0, 0.0), 'fine': (0.0, 0.005, 0.005, 0.0), 'color': (0.005, 0.005, 0.005, 0.005)}
+
+
+def _run(graph_free=True):
+    import evennicer_slam_amd as E
+    from evennicer_slam_amd.mapper import MaskedGridOptimizer
+    from tests.hip_util import DEV, tiny_on_gpu
+    g = load("tiny_mapper_iters")
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    masks = {k: torch.from_numpy(g['mask_' + k]).to(DEV) for k in KEYS}
+    before = {k: grids[k].clone() for k in KEYS}
+    opt = MaskedGridOptimizer(grids, masks, keys=KEYS)
+    dec_params = list(model.color_decoder.parameters())
+    dec_opt = torch.optim.Adam([{'params': dec_params, 'lr': 0.0}])
+    lrf = float(g['lr_factor'])
+    losses = []
+    for it, stage in enumerate(g['stages']):
+        stage = str(stage)
+        lr = STAGE_LR[stage]
+        dec_opt.param_groups[0]['lr'] = lr[0] * lrf
+        dec_opt.zero_grad()
+        depth, var, color = renderer.render_batch_ray(opt.render_grids(), model, rays['rays_d'], rays['rays_o'], DEV,
+                                                      stage, gt_depth=rays['gt_depth'])
+        loss = E.losses.rgbd_loss(depth, color if stage == 'color' else None, rays['gt_depth'], rays['gt_color'],
+                                  float(g['w_color_loss']))
+        loss.backward()
+        dec_opt.step()
+        opt.step({'grid_middle': lr[1] * lrf, 'grid_fine': lr[2] * lrf, 'grid_color': lr[3] * lrf})
+        losses.append(float(loss.item()))
+        if it in (0, 4, 6):
+            ref = g[f'grid_middle_after_{it}']
+            got = opt.grid('grid_middle').cpu().numpy()
+            assert np.abs(got - ref).max() <= 5e-5, it
+    opt.write_back()
+    return g, s, grids, before, model, losses, opt
+
+
+def test_mapper_iterations_match_reference_fixture():
+    g, s, grids, before, model, losses, opt = _run()
+    assert np.abs(np.array(losses) - g['losses']).max() <= 1e-4 * np.abs(g['losses']).max()
+    for k in KEYS:
+        ref = g['final_' + k]
+        got = grids[k].cpu().numpy()
+        # an Adam update is at most lr per step whatever the gradient; 10 steps at lr <= 0.1
+        assert np.abs(got - ref).max() <= 5e-5, k
+        unmasked = ~g['mask_' + k]
+        assert np.array_equal(got[0, :, unmasked], before[k].cpu().numpy()[0, :, unmasked]), k     # bit-identical
+        moved = np.abs(ref - s[k]).max()
+        assert moved > 1e-2, k                                                        # the test is not vacuous
+    for name, ref in g.items():
+        if name.startswith('final_cd_'):
+            got = dict(model.color_decoder.named_parameters())[name[len('final_cd_'):]].detach().cpu().numpy()
+            assert np.abs(got - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), name
+    # the accumulators are clear again, the step counters follow torch.optim.Adam's (grids join with their stage)
+    for k in KEYS:
+        assert float(opt.grids[k].grad_vm.abs().max()) == 0.0
+    assert opt.steps == [10, 5, 3]
+    assert opt.step_t.tolist() == [10, 5, 3]
+
+
+def test_voxel_major_grid_gradients_equal_dense_path():
+    """Same render call through a dense [1,32,D,H,W] leaf and through VoxelMajorGrid: identical gradients."""
+    import evennicer_slam_amd as E
+    from evennicer_slam_amd.mapper import MaskedGridOptimizer
+    from tests.hip_util import DEV, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    dense = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+    d, v, c = renderer.render_batch_ray(dense, model, rays['rays_d'], rays['rays_o'], DEV, 'color', gt_depth=rays['gt_depth'])
+    (d.sum() + c.sum()).backward()
+    opt = MaskedGridOptimizer(grids, None, keys=KEYS)
+    d2, v2, c2 = renderer.render_batch_ray(opt.render_grids(), model, rays['rays_d'], rays['rays_o'], DEV, 'color',
+                                           gt_depth=rays['gt_depth'])
+    assert torch.equal(d, d2) and torch.equal(c, c2)
+    (d2.sum() + c2.sum()).backward()
+    for k in KEYS:
+        G = opt.grids[k]
+        D, H, W = G.dims
+        got = G.grad_vm.reshape(D, H, W, 32).permute(3, 0, 1, 2)[None]
+        ref = dense[k].grad
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), k
+        assert G.has_grad
