@@ -53,6 +53,9 @@ _SIGS = {
     "enslam_adam_masked": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                           POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), POINTER(c_void_p),
                                           ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p]),
+    "enslam_adam_tensors": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                           POINTER(c_int64), c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_double, c_void_p]),
     "enslam_ray_grad_bwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene), c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
     "enslam_zero_blocks": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), c_void_p,

@@ -254,6 +254,27 @@ int enslam_adam_masked(int32_t n, float* const* param, float* const* grad, float
     return ens_launch_adam(job, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
 
+int enslam_adam_tensors(int32_t n, float* const* param, const float* const* grad, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int32_t* step,
+                        double beta1, double beta2, double eps, void* stream) {
+    if (n == 0) return ENSLAM_OK;
+    if (n < 0 || n > ENS_ADAM_MAX_TENSORS) return ENSLAM_EUNSUPPORTED;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !numel || !lr || !step) return ENSLAM_EINVAL;
+    AdamTensorsJob job;
+    job.n = n; job.beta1 = beta1; job.beta2 = beta2; job.eps = eps; job.lr = lr; job.step = step;
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!param[i] || !grad[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 0 || numel[i] > 0x7fffffff) return ENSLAM_EINVAL;
+        job.p[i] = param[i]; job.g[i] = grad[i]; job.m[i] = exp_avg[i]; job.v[i] = exp_avg_sq[i];
+        job.numel[i] = (int)numel[i];
+        job.block_begin[i] = (int)blocks;
+        blocks += (numel[i] + 1023) / 1024;
+        if (blocks > 0x7fffffff) return ENSLAM_EUNSUPPORTED;
+    }
+    job.block_begin[n] = (int)blocks;
+    return ens_launch_adam_tensors(job, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+
 int enslam_mark_blocks(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                        const double* z_vals, const enslam_scene* scene, uint8_t* const* flags, void* stream) {
     if (n_rays < 0 || n_samples < 1 || stage < 0 || stage > 3) return ENSLAM_EINVAL;

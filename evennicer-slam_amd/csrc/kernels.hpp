@@ -31,6 +31,19 @@ struct AdamJob {                 // masked Adam over up to 4 voxel-major grids i
     int n;
     double beta1, beta2, eps;    // Python floats of the optimiser
 };
+#define ENS_ADAM_MAX_TENSORS 72
+struct AdamTensorsJob {          // torch.optim.Adam over a list of small dense tensors (decoder parameters) in one launch
+    float* p[ENS_ADAM_MAX_TENSORS];
+    const float* g[ENS_ADAM_MAX_TENSORS];
+    float* m[ENS_ADAM_MAX_TENSORS];
+    float* v[ENS_ADAM_MAX_TENSORS];
+    int numel[ENS_ADAM_MAX_TENSORS];
+    int block_begin[ENS_ADAM_MAX_TENSORS + 1];      // 1024 elements per workgroup
+    int n;
+    double beta1, beta2, eps;
+    const double* lr;            // device scalar
+    const int* step;             // device scalar (already incremented)
+};
 struct ConvJob {                 // up to 4 grids converted in one launch
     const float* src[4];
     float* dst[4];
@@ -47,6 +60,7 @@ int ens_launch_convert(const ConvJob& job, bool to_voxel_major, hipStream_t st);
 int ens_launch_ray_grad_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
                             const DevScene& sc, float* dgrid_ws, float* g_ro, float* g_rd, hipStream_t st);
 int ens_launch_adam(const AdamJob& job, hipStream_t st);
+int ens_launch_adam_tensors(const AdamTensorsJob& job, hipStream_t st);
 int ens_launch_zero_blocks(const ConvJob& job, float* flat, int64_t n_flat, hipStream_t st);
 int ens_launch_mark_blocks(int stage, int n_rays, int S, const float* ro, const float* rd, const double* z,
                            const DevScene& sc, uint8_t* const* flags, hipStream_t st);

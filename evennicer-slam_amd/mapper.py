@@ -133,3 +133,60 @@ class MaskedGridOptimizer:
                 else:
                     self.c[k].copy_(torch.where(self.mask5[k][None, None], new, self.c[k]))
         return self.c
+
+
+class FusedAdam:
+    """torch.optim.Adam (defaults) for a list of small dense parameters -- the decoders the mapper optimises
+    (Mapper.py:363-369, group 0 of :409) -- as ONE launch per step; learning rate and step count live on the
+    device, so a captured step follows `set_lr` without re-capture.  Parameters whose `.grad` is None are skipped
+    only if that holds for all of them (the reference's decoder group always receives gradients together)."""
+
+    def __init__(self, params, lr=0.0, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("FusedAdam: empty parameter list")
+        if len(self.params) > 72:
+            raise L.EnslamError("FusedAdam: at most 72 tensors per optimiser")
+        dev = self.params[0].device
+        for p in self.params:
+            _require_hip(p, "parameter")
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise L.EnslamError("FusedAdam: parameters must be contiguous float32")
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        sizes = [p.numel() for p in self.params]
+        self._m = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self._v = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.exp_avg, self.exp_avg_sq = list(self._m.split(sizes)), list(self._v.split(sizes))
+        self.lr_t = torch.full((1,), float(lr), dtype=torch.float64, device=dev)
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._lr_host = float(lr)
+
+    def set_lr(self, lr):
+        if float(lr) != self._lr_host:
+            self.lr_t.fill_(float(lr))
+            self._lr_host = float(lr)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self, lr=None):
+        if lr is not None:
+            self.set_lr(lr)
+        grads = [p.grad for p in self.params]
+        if all(g is None for g in grads):
+            return
+        n = len(self.params)
+        P, G, M, V = ((ctypes.c_void_p * n)() for _ in range(4))
+        numel = (ctypes.c_int64 * n)()
+        for i, (p, g) in enumerate(zip(self.params, grads)):
+            if g is None:
+                raise L.EnslamError("FusedAdam.step: some parameters of the group have no gradient")
+            g = g if g.is_contiguous() else g.contiguous()
+            P[i], G[i], M[i], V[i] = p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
+            numel[i] = p.numel()
+        self.step_t += 1
+        for p in self.params:                 # raw kernel writes: tell torch (and the packed-decoder cache) they changed
+            torch._C._increment_version(p)
+        L.check(L.lib().enslam_adam_tensors(n, P, G, M, V, numel, _ptr(self.lr_t), _ptr(self.step_t), self.betas[0],
+                                            self.betas[1], self.eps, _stream()), "enslam_adam_tensors")

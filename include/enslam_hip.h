@@ -137,6 +137,12 @@ int enslam_adam_masked(int32_t n, float *const *param, float *const *grad, float
                        const double *const *lr, const int32_t *const *step, double beta1, double beta2, double eps,
                        void *stream);
 
+/* The same Adam update for up to 72 small dense tensors (the decoder parameters the mapper optimises,
+ * Mapper.py:363-369) in one launch; lr (float64) and step (int32, count of this update) are device scalars. */
+int enslam_adam_tensors(int32_t n, float *const *param, const float *const *grad, float *const *exp_avg,
+                        float *const *exp_avg_sq, const int64_t *numel, const double *lr, const int32_t *step,
+                        double beta1, double beta2, double eps, void *stream);
+
 /* Sample distances along rays.  Replaces Renderer.render_batch_ray lines 83-171
  * (src/utils/Renderer.py): near/far from gt_depth and the AABB exit, n_lin linear samples,
  * n_surf near-surface samples (gt_depth>0: [0.95d,1.05d]; else [0.001,max d]), ascending merge.

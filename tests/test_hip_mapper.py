@@ -21,14 +21,15 @@ def _run(graph_free=True):
     masks = {k: torch.from_numpy(g['mask_' + k]).to(DEV) for k in KEYS}
     before = {k: grids[k].clone() for k in KEYS}
     opt = MaskedGridOptimizer(grids, masks, keys=KEYS)
+    from evennicer_slam_amd.mapper import FusedAdam
     dec_params = list(model.color_decoder.parameters())
-    dec_opt = torch.optim.Adam([{'params': dec_params, 'lr': 0.0}])
+    dec_opt = FusedAdam(dec_params, lr=0.0)
     lrf = float(g['lr_factor'])
     losses = []
     for it, stage in enumerate(g['stages']):
         stage = str(stage)
         lr = STAGE_LR[stage]
-        dec_opt.param_groups[0]['lr'] = lr[0] * lrf
+        dec_opt.set_lr(lr[0] * lrf)
         dec_opt.zero_grad()
         depth, var, color = renderer.render_batch_ray(opt.render_grids(), model, rays['rays_d'], rays['rays_o'], DEV,
                                                       stage, gt_depth=rays['gt_depth'])
@@ -90,3 +91,25 @@ def test_voxel_major_grid_gradients_equal_dense_path():
         ref = dense[k].grad
         assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), k
         assert G.has_grad
+
+
+def test_fused_adam_matches_torch_adam():
+    from evennicer_slam_amd.mapper import FusedAdam
+    from tests.hip_util import DEV
+    g = torch.Generator().manual_seed(0)
+    shapes = [(32, 93), (32,), (4, 32), (1,), (32, 125), (3, 93)]
+    a = [torch.randn(s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    ref = torch.optim.Adam([{'params': b, 'lr': 0.0}])
+    opt = FusedAdam(a, lr=0.0)
+    for it, lr in enumerate([0.0, 0.005, 0.005, 0.1, 0.1, 0.005, 0.0, 0.005]):
+        grads = [torch.randn(s, generator=g).to(DEV) * (10.0 ** ((it % 4) - 2)) for s in shapes]
+        grads[1][:4] = 0.0                                   # exact zeros: update must be exactly 0 at step 1
+        for t, u, gr in zip(a, b, grads):
+            t.grad, u.grad = gr.clone(), gr.clone()
+        ref.param_groups[0]['lr'] = lr
+        ref.step()
+        opt.step(lr)
+    assert opt.step_t.item() == 8
+    for t, u in zip(a, b):
+        assert float((t - u).abs().max()) <= 2e-6 * max(1.0, float(u.abs().max()))
