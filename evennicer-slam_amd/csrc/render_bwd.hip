@@ -1360,14 +1360,47 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
     if (total > max_useful) total = (int)max_useful;
     if (total < n2) total = n2;
     A.n_roles = n2;
+    // Workgroups per role.  A workgroup takes 4 tiles per round, so a role with n workgroups needs
+    // ceil(groups / n) rounds of relative cost cc: pick the split whose slowest role finishes first (the proportional
+    // split wastes up to one round of the slowest role: 4-11 % at 1000 rays).  Searched once per (shape, roles).
+    int split[3] = {0, 0, 0};
+    {
+        static thread_local int c_key[4] = {-1, -1, -1, -1}, c_split[3];
+        const int groups = (int)((n_tiles + 3) / 4);
+        int mask = 0;
+        for (int i = 0; i < n2; ++i) mask |= 1 << kk[i];
+        if (c_key[0] == groups && c_key[1] == total && c_key[2] == mask && c_key[3] == stage) {
+            for (int i = 0; i < 3; ++i) split[i] = c_split[i];
+        } else {
+            auto rounds = [&](int n) { return (groups + n - 1) / n; };
+            if (n2 == 1) {
+                split[0] = total;
+            } else if (n2 == 2) {
+                float best = 1e30f;
+                for (int a = 1; a < total; ++a) {
+                    const float t = fmaxf(rounds(a) * cc[0], rounds(total - a) * cc[1]);
+                    if (t < best) { best = t; split[0] = a; split[1] = total - a; }
+                }
+            } else {
+                float best = 1e30f;
+                for (int a = 1; a < total - 1; ++a) {
+                    const float ta = rounds(a) * cc[0];
+                    if (ta >= best) continue;
+                    for (int b = 1; b < total - a; ++b) {
+                        const float t = fmaxf(ta, fmaxf(rounds(b) * cc[1], rounds(total - a - b) * cc[2]));
+                        if (t < best) { best = t; split[0] = a; split[1] = b; split[2] = total - a - b; }
+                    }
+                }
+            }
+            c_key[0] = groups; c_key[1] = total; c_key[2] = mask; c_key[3] = stage;
+            for (int i = 0; i < 3; ++i) c_split[i] = split[i];
+        }
+    }
     int begin = 0;
     for (int i = 0; i < n2; ++i) {
         A.role_kind[i] = kk[i];
         A.role_begin[i] = begin;
-        int n = (i == n2 - 1) ? total - begin : (int)(total * cc[i] / csum + 0.5f);
-        if (n < 1) n = 1;
-        if (begin + n > total - (n2 - 1 - i)) n = total - (n2 - 1 - i) - begin;
-        begin += n;
+        begin += split[i];
     }
     A.role_begin[n2] = total;
     for (int i = n2; i < 4; ++i) A.role_kind[i] = -1;
