@@ -1334,6 +1334,13 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         case 1: kinds[nk] = 1; cost[nk++] = 1.f; break;
         case 2: kinds[nk] = 1; cost[nk++] = 0.44f; kinds[nk] = 2; cost[nk++] = 0.56f; break;
         case 3: kinds[nk] = 1; cost[nk++] = 0.315f; kinds[nk] = 2; cost[nk++] = 0.365f; kinds[nk] = 3; cost[nk++] = 0.32f; break;
+    }
+    if (const char* e = getenv("ENS_ROLE_COST")) {          // tuning aid: "a,b,c" relative cost of middle, fine, color
+        float x[3];
+        if (stage == 3 && sscanf(e, "%f,%f,%f", &x[0], &x[1], &x[2]) == 3) { cost[0] = x[0]; cost[1] = x[1]; cost[2] = x[2]; }
+    }
+    switch (stage) {
+        case 0: case 1: case 2: case 3: break;
         default: return -1;
     }
     for (int k = 0; k < 4; ++k) { A.ggrid[k] = DevGrid{nullptr, 0, 0, 0}; A.gpacked[k] = nullptr; }

@@ -40,15 +40,16 @@ def block_flags_of(grads):
     return out
 
 
-def _gather_blocks(g, idx):
-    """g: gradient [1,C,D,H,W]; idx: int64 indices of 64-voxel blocks -> (main [C,n,64] copy, tail view or None)."""
+def _block_views(g):
+    """g: gradient [1,C,D,H,W] -> (view of the whole 64-voxel blocks [C,nfull,64], view of the partial last block or
+    None).  The partial block (voxel count not a multiple of 64) always travels: a few hundred floats, no
+    data-dependent branch."""
     C, V = g.shape[1], g.shape[2] * g.shape[3] * g.shape[4]
     g2 = g.reshape(C, V)
     nfull = V // 64
-    full = idx[idx < nfull]
     main = g2[:, :nfull * 64].view(C, nfull, 64)
-    tail = g2[:, nfull * 64:] if (V > nfull * 64 and bool((idx == nfull).any())) else None
-    return main, full, tail
+    tail = g2[:, nfull * 64:] if V > nfull * 64 else None
+    return main, tail
 
 
 def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=None):
@@ -77,9 +78,12 @@ def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=Non
         sizes_f = [f.numel() for f in flags]
         allf = torch.cat([f.reshape(-1).to(torch.uint8) for f in flags])
         dist.all_reduce(allf, op=dist.ReduceOp.MAX, group=group)          # union of the touched blocks
-        for i, f in zip(grid_ids, allf.split(sizes_f)):
-            idx = torch.nonzero(f, as_tuple=False).reshape(-1)             # (host sync: the bucket size is needed)
-            plans[i] = _gather_blocks(tensors[i].grad, idx)
+        views = [_block_views(tensors[i].grad) for i in grid_ids]
+        whole = [f[:mv[0].shape[1]] for f, mv in zip(allf.split(sizes_f), views)]       # flags of the whole blocks
+        counts = torch.stack([f.sum(dtype=torch.int64) for f in whole]).tolist()         # the one host sync: bucket sizes
+        for i, f, n, (main, tail) in zip(grid_ids, whole, counts, views):
+            idx = torch.nonzero_static(f, size=int(n)).reshape(-1)                       # known size: no further sync
+            plans[i] = (main, idx, tail)
     parts = []
     for i, t in enumerate(tensors):
         if i in plans:

@@ -83,9 +83,50 @@ def test_two_rank_sharded_step_matches_unsharded():
     for o in outs:
         assert o['nbytes'] > 0 and o['g_coarse_is_none_or_zero']
         dense_bytes = 4 * (sum(grids[k].numel() for k in GRID_KEYS) + sum(v.numel() for v in params.values()))
-        assert o['nbytes'] < dense_bytes          # only the touched voxel slab of each grid travels
+        assert o['nbytes'] <= dense_bytes         # (tiny grids: every 64-voxel block is touched)
         ref = grids['grid_fine'].grad.numpy()
         assert np.abs(o['g_fine'] - ref).max() <= 1e-5 * np.abs(ref).max()
         ref = params['color_decoder.pts_linears.0.weight'].grad.numpy()
         assert np.abs(o['g_w'] - ref).max() <= 1e-5 * np.abs(ref).max()
     assert np.array_equal(outs[0]['g_fine'], outs[1]['g_fine'])  # replicas hold identical summed gradients
+
+
+def _sparse_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from evennicer_slam_amd.parallel import allreduce_gradients
+        g = torch.Generator().manual_seed(5)
+        grid = torch.zeros(1, 4, 5, 7, 11).requires_grad_(True)        # 385 voxels: 6 whole blocks + a partial one
+        other = torch.zeros(3, 2).requires_grad_(True)
+        V = 385
+        grad = torch.zeros(4, V)
+        for b in ([1, 4] if rank == 0 else [4, 6]):                      # rank 1 touches the partial block (6)
+            lo, hi = b * 64, min(V, b * 64 + 64)
+            grad[:, lo:hi] = torch.randn(4, hi - lo, generator=g) + rank
+        grid.grad = grad.view(1, 4, 5, 7, 11).clone()
+        other.grad = torch.full((3, 2), float(rank + 1))
+        nbytes = allreduce_gradients([grid, other])
+        q.put({'rank': rank, 'nbytes': nbytes, 'grid': grid.grad.numpy().copy(), 'own': grad.numpy(), 'other': other.grad.numpy().copy()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_block_sparse_bucket_sums_only_touched_blocks():
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = (outs[0]['own'] + outs[1]['own']).reshape(1, 4, 5, 7, 11)
+    for o in outs:
+        assert np.array_equal(o['grid'], want)
+        assert np.array_equal(o['other'], np.full((3, 2), 3.0, dtype=np.float32))
+        # blocks 1 and 4 (whole) + the partial block of 1 voxel + the 6 floats of `other`
+        assert o['nbytes'] == 4 * (4 * 2 * 64 + 4 * 1 + 6)
