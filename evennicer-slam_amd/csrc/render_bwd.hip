@@ -854,11 +854,30 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             pend = false;
         }
     };
+    // d_raw and the ReLU mask words of a tile are fetched one round ahead: their latency (the vote and the first
+    // layer wait on them) hides under the previous round
+    auto tile_of = [&](int64_t b) {
+        const int64_t tr = b + wave;
+        return __builtin_amdgcn_readfirstlane((int)(tr < n_tiles ? tr : n_tiles - 1));
+    };
+    f32x4 draw_n = splat4(0.f);
+    uint2 mw_n = make_uint2(0u, 0u);
+    if ((int64_t)wg * 4 < n_tiles) {
+        const int t0 = tile_of((int64_t)wg * 4);
+        draw_n = *reinterpret_cast<const f32x4*>(A.d_raw + ((int64_t)t0 * 16 + p) * 4);
+        mw_n = *reinterpret_cast<const uint2*>(A.act_ws + ((int64_t)t0 * ACT_SLOTS + slot_idx) * ACT_STRIDE + ACT_MASK + lane * 2);
+    }
     for (int64_t base = (int64_t)wg * 4; base < n_tiles; base += stride) {
         const int64_t tile_raw = base + wave;
         const bool tvalid = tile_raw < n_tiles;
-        const int tile = __builtin_amdgcn_readfirstlane((int)(tvalid ? tile_raw : n_tiles - 1));
-        f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + ((int64_t)tile * 16 + p) * 4);
+        const int tile = tile_of(base);
+        f32x4 draw = draw_n;
+        const uint2 mw = mw_n;
+        if (base + stride < n_tiles) {
+            const int t1 = tile_of(base + stride);
+            draw_n = *reinterpret_cast<const f32x4*>(A.d_raw + ((int64_t)t1 * 16 + p) * 4);
+            mw_n = *reinterpret_cast<const uint2*>(A.act_ws + ((int64_t)t1 * ACT_SLOTS + slot_idx) * ACT_STRIDE + ACT_MASK + lane * 2);
+        }
         if (!tvalid) draw = splat4(0.f);
         float dj[NE];                                               // d(loss)/d(output j) of this lane's sample
         if constexpr (NOUT == 4) { dj[0] = draw[0]; dj[1] = draw[1]; dj[2] = draw[2]; } else { dj[0] = draw[3]; }
@@ -903,7 +922,6 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         f32x4 h4[2];
         h4[0] = ld4(wsb + ACT_H4 + lane * 4);
         h4[1] = ld4(wsb + ACT_H4 + 256 + lane * 4);
-        const uint2 mw = *reinterpret_cast<const uint2*>(wsb + ACT_MASK + lane * 2);
         f32x4 rec = splat4(0.f);
         if (want_g) rec = ld4(wsb + ACT_VOX + p * 4);
         unsigned mbits[5] = {mw.x & 255u, (mw.x >> 8) & 255u, (mw.x >> 16) & 255u, (mw.x >> 24) & 255u, mw.y & 255u};
@@ -912,18 +930,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         opaque(wsw);
         STAMP(3)
 
-        // ---- output layer: dWo, dbo on the VALU (n_out <= 4 rows: not worth an MFMA tile); dh4 = Wo^T d_out
-        if (want_w) {
-#pragma unroll
-            for (int j = 0; j < NE; ++j) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) aWo[j][4 * t + r] = fmaf(dj[j], h4[t][r], aWo[j][4 * t + r]);
-                }
-                if (q == 0) aBo[j] += dj[j];
-            }
-        }
+        // ---- output layer: dh4 = Wo^T d_out (dWo, dbo follow after the first barrier, when h4 has arrived)
         f32x4 dh[2] = {splat4(0.f), splat4(0.f)};
         {   // K = 4: one MFMA step per row tile; k-slot q carries output q
             const float dq = NOUT == 4 ? (q == 0 ? draw[0] : (q == 1 ? draw[1] : (q == 2 ? draw[2] : 0.f)))
@@ -954,6 +961,20 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             STAMP(5)    // barrier wait
             if constexpr (i > 0) prefetch(IC(i - 1), buf ^ 1); else prefetch(IC(4), buf ^ 1);
             if constexpr (i == 4) scatter_pending();                 // previous tile's atomics, behind this round's loads
+            if constexpr (i == 4) { STAMP(1) }      // deferred scatter
+            if constexpr (i == 4) {
+                if (want_w) {                       // dWo, dbo on the VALU (n_out <= 4 rows: not worth an MFMA tile)
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) aWo[j][4 * t + r] = fmaf(dj[j], h4[t][r], aWo[j][4 * t + r]);
+                        }
+                        if (q == 0) aBo[j] += dj[j];
+                    }
+                }
+            }
             if (want_w) {
                 own_outer_a<CT / 2>(aWc[i], fb, TH, SL::C, CT, 2 * CT, wave);                     // dWc_i
                 if constexpr (i == 0) {

@@ -5,7 +5,7 @@ import numpy as np, torch, bench
 import evennicer_slam_amd as E
 import evennicer_slam_amd.functional as EF
 NSEG = 12
-names = ["geom+d_raw+vote", "vox+gather", "embedding", "fwd chain", "deposits(fwd)", "barrier waits", "layer deposits(+prev dX)",
+names = ["d_raw+vote", "deferred scatter", "embedding", "fill issue + h4/mask loads", "deposits(fwd)", "barrier waits", "layer deposits(+prev dX)",
          "owned dW MFMAs", "tail dX", "emb tail", "coord+scatter+rays", "-"]
 dev = torch.device('cuda', 0)
 lib = E._lib.lib()
@@ -26,7 +26,7 @@ for i in range(5):
 torch.cuda.synchronize()
 st = buf.cpu().numpy().reshape(256, 4, NSEG).astype(np.float64)
 # role ranges as in ens_launch_decoder_bwd: 0.30 / 0.40 / 0.30 of 256 workgroups
-r0 = int(256 * 0.315 + 0.5); r1 = r0 + int(256 * 0.365 + 0.5)
+r0 = 75; r1 = r0 + 94          # split chosen by the launcher for 3000 tiles (see ens_launch_decoder_bwd)
 for name, sl in (("middle", slice(0, r0)), ("fine", slice(r0, r1)), ("color", slice(r1, 256))):
     s = st[sl].reshape(-1, NSEG)
     tot = s.sum(1)
