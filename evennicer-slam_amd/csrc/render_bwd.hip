@@ -435,6 +435,44 @@ ENS_DEV void own_outer_a(f32x4 (&acc)[NJ], const unsigned (&fb)[4], int ytile0, 
         }
     }
 }
+// One layer's owned weight-gradient tiles in one pass over the slots: dWc (NA tiles), dW (NB tiles) and the bias row.
+// Per slot all operand fragments are read first, then the MFMAs of the NA+NB+1 independent accumulators interleave,
+// so no MFMA waits on its own predecessor and one LDS round trip feeds 4*(NA+NB+1) MFMAs (three separate passes with
+// one or two accumulators each ran at about half the MFMA rate).
+template <int NA, int NB>
+ENS_DEV void own_layer_a(f32x4 (&accA)[NA], int yA, int xA, int ncA, int ntA, f32x4 (&accB)[NB], int yB, int xB, int ncB,
+                         int ntB, f32x4& accBias, int ybias, const unsigned (&fb)[4], int wave) {
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        f32x4 aA[NA], bA[NA], aB[NB], bB[NB];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            int t = wave + 4 * j;
+            t = t < ntA ? t : 0;
+            const int rt = t / ncA, ct = t - rt * ncA;
+            aA[j] = lds4(fb[sl] + (yA + rt) * 1024);
+            bA[j] = lds4(fb[sl] + (xA + ct) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int t = wave + 4 * j;
+            t = t < ntB ? t : 0;
+            const int rt = t / ncB, ct = t - rt * ncB;
+            aB[j] = lds4(fb[sl] + (yB + rt) * 1024);
+            bB[j] = lds4(fb[sl] + (xB + ct) * 1024);
+        }
+        const f32x4 ab = lds4(fb[sl] + ybias * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) accA[j] = MFMA16(aA[j][s], bA[j][s], accA[j]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) accB[j] = MFMA16(aB[j][s], bB[j][s], accB[j]);
+            accBias = MFMA16(ab[s], 1.f, accBias);
+        }
+    }
+}
 ENS_DEV void own_bias_a(f32x4& acc, const unsigned (&fb)[4], int ytile) {
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
@@ -976,19 +1014,18 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 }
             }
             if (want_w) {
-                own_outer_a<CT / 2>(aWc[i], fb, TH, SL::C, CT, 2 * CT, wave);                     // dWc_i
-                if constexpr (i == 0) {
-                    own_outer_a<3>(aW0, fb, TP, SL::EMB, 6, 12, wave);
+                const int ybias = (wave < 2 ? TP : TH) + (wave & 1);                              // db_i | dbc_i
+                if constexpr (i == 0) {                                                           // dWc_i, dW_i, bias
+                    own_layer_a<CT / 2, 3>(aWc[i], TH, SL::C, CT, 2 * CT, aW0, TP, SL::EMB, 6, 12, aB[i], ybias, fb, wave);
                 } else if constexpr (i == 3) {
-                    own_outer_a<4>(aW3, fb, TP, SL::EMB, 8, 16, wave);                           // [emb | h2] contiguous
+                    own_layer_a<CT / 2, 4>(aWc[i], TH, SL::C, CT, 2 * CT, aW3, TP, SL::EMB, 8, 16, aB[i], ybias, fb, wave);   // [emb | h2] contiguous
                 } else if constexpr (i == 1) {
-                    own_outer_a<1>(aW1, fb, TP, TX, 2, 4, wave);
+                    own_layer_a<CT / 2, 1>(aWc[i], TH, SL::C, CT, 2 * CT, aW1, TP, TX, 2, 4, aB[i], ybias, fb, wave);
                 } else if constexpr (i == 2) {
-                    own_outer_a<1>(aW2, fb, TP, TX, 2, 4, wave);
+                    own_layer_a<CT / 2, 1>(aWc[i], TH, SL::C, CT, 2 * CT, aW2, TP, TX, 2, 4, aB[i], ybias, fb, wave);
                 } else {
-                    own_outer_a<1>(aW4, fb, TP, TX, 2, 4, wave);
+                    own_layer_a<CT / 2, 1>(aWc[i], TH, SL::C, CT, 2 * CT, aW4, TP, TX, 2, 4, aB[i], ybias, fb, wave);
                 }
-                own_bias_a(aB[i], fb, (wave < 2 ? TP : TH) + (wave & 1));                        // db_i | dbc_i
                 STAMP(7)    // owned dW MFMAs
             }
             if (want_c) lin_lds_swz<2, 2, 32, OCT>(dc, wb, swd, dh);                      // dC += Wc_i^T dh_i
