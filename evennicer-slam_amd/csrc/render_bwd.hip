@@ -824,20 +824,24 @@ struct XyzSlotsS {                     // slot = workspace block order, then the
 };
 constexpr int RB_SAVED = 96 * 32 + 1024 + 16 * 96 + 96 * 4;           // layer-0 chunk: W0^T | Wc0^T | B (padded) | B^T
 
-template <int CT, int NOUT>
+// WW = false: no decoder-parameter gradients (tracker iterations; mapper stages that optimise no decoder): no
+// deposits, no owned dW tiles, no accumulators, no slot fill -- under 256 registers, two workgroups per CU.
+template <int CT, int NOUT, bool WW>
 ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float* smem) {
     constexpr XyzLay L{CT * 16};
     constexpr int GF = L.fwd_floats();
     constexpr int NE = NOUT == 4 ? 3 : 1;                          // outputs that carry gradient
     using SL = XyzSlotsS<CT>;
-    constexpr int SLOT = SL::TILES * 256;                          // floats
+    constexpr int SLOT = WW ? SL::TILES * 256 : 512;               // floats (light variant: the 2-tile scatter staging only)
+    constexpr int STG = WW ? SL::H1 * 256 : 0;
     constexpr int RB = RB_SAVED;
     static_assert(RB_SAVED >= 128 * 32 + 1024, "ring buffer must hold the largest W^T|Wc^T chunk");
     constexpr int RING_BYTES = 2 * RB * 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
     const float* __restrict__ pk = A.sc.packed[kind];
     float* gpk = A.gpacked[kind];
-    const bool want_w = gpk != nullptr, want_g = A.ggrid[kind].data != nullptr, want_r = A.g_ro != nullptr;
+    const bool want_w = WW && gpk != nullptr;       // (kept a run-time flag in the WW variant: folding it costs 30 spills)
+    const bool want_g = A.ggrid[kind].data != nullptr, want_r = A.g_ro != nullptr;
     const bool want_c = want_g || want_r;
     float* ring = smem;
     float* slots = smem + 2 * RB;
@@ -882,7 +886,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     unsigned round_no = 0, rp = 0;                                  // rp: ring buffer of this round's first chunk
     // The feature-gradient scatter of a tile is deferred into the next executed round (after its first barrier): the
     // ~30 atomics of a tile then drain under that round's MFMAs instead of in front of its loads (vmcnt is in order).
-    float* const stg = slots + wave * SLOT + SL::H1 * 256;          // dC as [sample][32]; H1 is idle until layer 3
+    float* const stg = slots + wave * SLOT + STG;                   // dC as [sample][32]; H1 is idle until layer 3
     f32x4 rec_prev = splat4(0.f);
     bool pend = false;
     auto scatter_pending = [&]() {
@@ -950,16 +954,16 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         // ---- forward activations from the workspace: deposit tiles straight into this wave's LDS slot (async),
         //      h4 and the ReLU masks into registers
         const float* __restrict__ wsb = A.act_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * ACT_STRIDE;
-        {
+        f32x4 h4[2] = {splat4(0.f), splat4(0.f)};
+        if constexpr (WW) {
             float* myslot = slots + wave * SLOT;
 #pragma unroll
             for (int t = 0; t < SL::FILL; ++t)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsb + t * 256 + lane * 4),
                                                  (__attribute__((address_space(3))) void*)(myslot + t * 256), 16, 0, 0);
+            h4[0] = ld4(wsb + ACT_H4 + lane * 4);
+            h4[1] = ld4(wsb + ACT_H4 + 256 + lane * 4);
         }
-        f32x4 h4[2];
-        h4[0] = ld4(wsb + ACT_H4 + lane * 4);
-        h4[1] = ld4(wsb + ACT_H4 + 256 + lane * 4);
         f32x4 rec = splat4(0.f);
         if (want_g) rec = ld4(wsb + ACT_VOX + p * 4);
         unsigned mbits[5] = {mw.x & 255u, (mw.x >> 8) & 255u, (mw.x >> 16) & 255u, (mw.x >> 24) & 255u, mw.y & 255u};
@@ -1050,9 +1054,13 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         if (want_r || want_w) {
             constexpr int OBP = (96 * 32 + 1024) * 4, OBT = OBP + 16 * 96 * 4;
             // coordinate q of sample p from the XYZ tile (feature i = q)
-            const float pc = q < 3 ? *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(
-                                         lds0 + RING_BYTES + (wave * SLOT + SL::Q * 256 + (p >> 2) * 64 + q * 4 + (p & 3)) * 4))
-                                   : 0.f;
+            float pc = 0.f;
+            if constexpr (WW) {
+                if (q < 3) pc = *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(
+                                    lds0 + RING_BYTES + (wave * SLOT + SL::Q * 256 + (p >> 2) * 64 + q * 4 + (p & 3)) * 4));
+            } else {
+                if (q < 3) pc = wsb[SL::Q * 256 + (p >> 2) * 64 + q * 4 + (p & 3)];       // same tile, straight from the workspace
+            }
 #pragma unroll
             for (int t = 0; t < 6; ++t) {                               // cos(arg) recomputed: cheaper than carrying it
                 const float a = *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(ring0 + OBT + ((16 * t + p) * 4 + q) * 4));
@@ -1333,12 +1341,28 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(BwdArgs A) {
     const int kind = A.role_kind[role];
     switch (kind) {
         case 0: feat_role(A, wg, n_wg, ens_smem); break;
-        case 1: if constexpr (SAVED) xyz_role_saved<2, 1>(A, 1, wg, n_wg, ens_smem); else xyz_role<2, 1>(A, 1, wg, n_wg, ens_smem); break;
-        case 2: if constexpr (SAVED) xyz_role_saved<4, 1>(A, 2, wg, n_wg, ens_smem); else xyz_role<4, 1>(A, 2, wg, n_wg, ens_smem); break;
-        case 3: if constexpr (SAVED) xyz_role_saved<2, 4>(A, 3, wg, n_wg, ens_smem); else xyz_role<2, 4>(A, 3, wg, n_wg, ens_smem); break;
+        case 1: if constexpr (SAVED) xyz_role_saved<2, 1, true>(A, 1, wg, n_wg, ens_smem); else xyz_role<2, 1>(A, 1, wg, n_wg, ens_smem); break;
+        case 2: if constexpr (SAVED) xyz_role_saved<4, 1, true>(A, 2, wg, n_wg, ens_smem); else xyz_role<4, 1>(A, 2, wg, n_wg, ens_smem); break;
+        case 3: if constexpr (SAVED) xyz_role_saved<2, 4, true>(A, 3, wg, n_wg, ens_smem); else xyz_role<2, 4>(A, 3, wg, n_wg, ens_smem); break;
         default: break;
     }
 }
+
+// Saved-activation backward of decoders whose parameters get no gradient: the dX chain, the feature-gradient scatter
+// and the ray-gradient hand-off only.  No accumulators -> two workgroups per CU overlap each other's latencies.
+__global__ __launch_bounds__(256, 2) void decoder_bwd_light_kernel(BwdArgs A) {
+    int role = 0;
+#pragma unroll
+    for (int r = 1; r < 4; ++r) role = (r < A.n_roles && (int)blockIdx.x >= A.role_begin[r]) ? r : role;
+    const int wg = blockIdx.x - A.role_begin[role], n_wg = A.role_begin[role + 1] - A.role_begin[role];
+    switch (A.role_kind[role]) {
+        case 1: xyz_role_saved<2, 1, false>(A, 1, wg, n_wg, ens_smem); break;
+        case 2: xyz_role_saved<4, 1, false>(A, 2, wg, n_wg, ens_smem); break;
+        case 3: xyz_role_saved<2, 4, false>(A, 3, wg, n_wg, ens_smem); break;
+        default: break;
+    }
+}
+constexpr int lds_bytes_light() { return (2 * RB_SAVED + 4 * 512) * 4; }
 
 // deposit slots of the 4 waves; the packed-layout flush image aliases them at the end of the kernel
 constexpr int lds_bytes_xyz(int ct) { return (cmax(XyzLay{ct * 16}.fwd_floats(), 4 * (23 + ct) * 256) + 2 * ring_floats(ct)) * 4; }
@@ -1420,55 +1444,6 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
     }
     if (n2 == 0) return 0;
     const int64_t n_tiles = (int64_t)n_rays * ntl;
-    int total = device_cus();
-    const int64_t max_useful = (n_tiles + 3) / 4 * n2;
-    if (total > max_useful) total = (int)max_useful;
-    if (total < n2) total = n2;
-    A.n_roles = n2;
-    // Workgroups per role.  A workgroup takes 4 tiles per round, so a role with n workgroups needs
-    // ceil(groups / n) rounds of relative cost cc: pick the split whose slowest role finishes first (the proportional
-    // split wastes up to one round of the slowest role: 4-11 % at 1000 rays).  Searched once per (shape, roles).
-    int split[3] = {0, 0, 0};
-    {
-        static thread_local int c_key[4] = {-1, -1, -1, -1}, c_split[3];
-        const int groups = (int)((n_tiles + 3) / 4);
-        int mask = 0;
-        for (int i = 0; i < n2; ++i) mask |= 1 << kk[i];
-        if (c_key[0] == groups && c_key[1] == total && c_key[2] == mask && c_key[3] == stage) {
-            for (int i = 0; i < 3; ++i) split[i] = c_split[i];
-        } else {
-            auto rounds = [&](int n) { return (groups + n - 1) / n; };
-            if (n2 == 1) {
-                split[0] = total;
-            } else if (n2 == 2) {
-                float best = 1e30f;
-                for (int a = 1; a < total; ++a) {
-                    const float t = fmaxf(rounds(a) * cc[0], rounds(total - a) * cc[1]);
-                    if (t < best) { best = t; split[0] = a; split[1] = total - a; }
-                }
-            } else {
-                float best = 1e30f;
-                for (int a = 1; a < total - 1; ++a) {
-                    const float ta = rounds(a) * cc[0];
-                    if (ta >= best) continue;
-                    for (int b = 1; b < total - a; ++b) {
-                        const float t = fmaxf(ta, fmaxf(rounds(b) * cc[1], rounds(total - a - b) * cc[2]));
-                        if (t < best) { best = t; split[0] = a; split[1] = b; split[2] = total - a - b; }
-                    }
-                }
-            }
-            c_key[0] = groups; c_key[1] = total; c_key[2] = mask; c_key[3] = stage;
-            for (int i = 0; i < 3; ++i) c_split[i] = split[i];
-        }
-    }
-    int begin = 0;
-    for (int i = 0; i < n2; ++i) {
-        A.role_kind[i] = kk[i];
-        A.role_begin[i] = begin;
-        begin += split[i];
-    }
-    A.role_begin[n2] = total;
-    for (int i = n2; i < 4; ++i) A.role_kind[i] = -1;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel<false>),
@@ -1478,12 +1453,77 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
             return -2;
         attr_set = true;
     }
-    if (A.act_ws != nullptr) {
-        decoder_bwd_kernel<true><<<dim3(total), dim3(256), lds_saved, st>>>(A);      // ray gradients: ens_launch_ray_grad_bwd
-    } else {
-        decoder_bwd_kernel<false><<<dim3(total), dim3(256), lds, st>>>(A);
+    // Roles whose decoder gets no parameter gradient run in the light kernel (saved-activation path only); the others
+    // in the persistent one.  Each launch splits its workgroups over its roles by integer rounds: a workgroup takes 4
+    // tiles per round, so a role with n workgroups needs ceil(groups / n) rounds of relative cost cc -- pick the split
+    // whose slowest role finishes first (the proportional split wastes up to one round of the slowest role: 4-11 % at
+    // 1000 rays).  Searched once per (shape, roles).
+    const int groups = (int)((n_tiles + 3) / 4);
+    auto launch_subset = [&](const int* ks, const float* cs, int n, bool light) -> int {
+        if (n == 0) return 0;
+        int total = device_cus() * (light ? 2 : 1);
+        const int64_t max_useful = (int64_t)groups * n;
+        if (total > max_useful) total = (int)max_useful;
+        if (total < n) total = n;
+        int split[3] = {0, 0, 0};
+        static thread_local int c_key[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}}, c_split[2][3];
+        int mask = 0;
+        for (int i = 0; i < n; ++i) mask |= 1 << ks[i];
+        int* key = c_key[light ? 1 : 0];
+        int* cached = c_split[light ? 1 : 0];
+        if (key[0] == groups && key[1] == total && key[2] == mask && key[3] == stage) {
+            for (int i = 0; i < 3; ++i) split[i] = cached[i];
+        } else {
+            auto rounds = [&](int m) { return (groups + m - 1) / m; };
+            if (n == 1) {
+                split[0] = total;
+            } else if (n == 2) {
+                float best = 1e30f;
+                for (int a = 1; a < total; ++a) {
+                    const float t = fmaxf(rounds(a) * cs[0], rounds(total - a) * cs[1]);
+                    if (t < best) { best = t; split[0] = a; split[1] = total - a; }
+                }
+            } else {
+                float best = 1e30f;
+                for (int a = 1; a < total - 1; ++a) {
+                    const float ta = rounds(a) * cs[0];
+                    if (ta >= best) continue;
+                    for (int b2 = 1; b2 < total - a; ++b2) {
+                        const float t = fmaxf(ta, fmaxf(rounds(b2) * cs[1], rounds(total - a - b2) * cs[2]));
+                        if (t < best) { best = t; split[0] = a; split[1] = b2; split[2] = total - a - b2; }
+                    }
+                }
+            }
+            key[0] = groups; key[1] = total; key[2] = mask; key[3] = stage;
+            for (int i = 0; i < 3; ++i) cached[i] = split[i];
+        }
+        BwdArgs B = A;
+        for (int k = 0; k < 4; ++k) { B.ggrid[k] = DevGrid{nullptr, 0, 0, 0}; B.gpacked[k] = nullptr; }
+        B.n_roles = n;
+        int begin = 0;
+        for (int i = 0; i < n; ++i) {
+            B.role_kind[i] = ks[i];
+            B.role_begin[i] = begin;
+            B.ggrid[ks[i]] = A.ggrid[ks[i]];
+            B.gpacked[ks[i]] = A.gpacked[ks[i]];
+            begin += split[i];
+        }
+        B.role_begin[n] = total;
+        for (int i = n; i < 4; ++i) B.role_kind[i] = -1;
+        if (light) decoder_bwd_light_kernel<<<dim3(total), dim3(256), lds_bytes_light(), st>>>(B);
+        else if (A.act_ws != nullptr) decoder_bwd_kernel<true><<<dim3(total), dim3(256), lds_saved, st>>>(B);   // ray gradients: ens_launch_ray_grad_bwd
+        else decoder_bwd_kernel<false><<<dim3(total), dim3(256), lds, st>>>(B);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    };
+    int hk[3], lk[3], nh = 0, nl = 0;
+    float hc[3], lc[3];
+    for (int i = 0; i < n2; ++i) {
+        const bool light = A.act_ws != nullptr && kk[i] != 0 && A.gpacked[kk[i]] == nullptr;
+        if (light) { lk[nl] = kk[i]; lc[nl++] = cc[i]; } else { hk[nh] = kk[i]; hc[nh++] = cc[i]; }
     }
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    const int rl = launch_subset(lk, lc, nl, true);
+    if (rl != 0) return rl;
+    return launch_subset(hk, hc, nh, false);
 }
 
 // Second kernel of the saved-activation backward: ray gradients from the decoder kernel's hand-off buffer.
