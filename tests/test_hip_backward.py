@@ -101,6 +101,43 @@ def test_backward_only_rays_need_grad(tiny):
             p.requires_grad_(True)
 
 
+@pytest.mark.parametrize("stage,train", [("middle", ()), ("fine", ()), ("color", ()), ("color", ("color_decoder",)),
+                                         ("fine", ("fine_decoder",))])
+def test_backward_with_fixed_decoders(tiny, stage, train):
+    """Mapper cases: decoders that are not optimised carry no gradient (fix_fine / stages with decoders_lr 0): those
+    roles run in the light kernel, the optimised one (if any) in the persistent kernel -- same grid, ray and decoder
+    gradients as the all-parameters golden."""
+    s, bound, model, grids, rays, renderer = tiny
+    g = load("tiny_" + stage)
+    cot = [torch.from_numpy(g[k]).cuda() for k in ("cot_depth", "cot_var", "cot_color")]
+    for name, p in model.named_parameters():
+        p.requires_grad_(name.split('.')[0] in train)
+        p.grad = None
+    try:
+        cg = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+        ro = rays['rays_o'].clone().requires_grad_(True)
+        rd = rays['rays_d'].clone().requires_grad_(True)
+        depth, var, color = renderer.render_batch_ray(cg, model, rd, ro, 'cuda:0', stage, gt_depth=rays['gt_depth'])
+        ((depth * cot[0]).sum() + (var * cot[1]).sum() + (color * cot[2]).sum()).backward()
+        assert rel_err(ro.grad.cpu().numpy(), g["g_rays_o"]) < GTOL
+        assert rel_err(rd.grad.cpu().numpy(), g["g_rays_d"]) < GTOL
+        for k in GRID_KEYS:
+            if "g_" + k in g:
+                assert rel_err(cg[k].grad.cpu().numpy(), g["g_" + k]) < GTOL, k
+        n_checked = 0
+        for name, p in model.named_parameters():
+            if name.split('.')[0] in train and "gp_" + name in g and np.abs(g["gp_" + name]).max() > 0:
+                assert rel_err(p.grad.cpu().numpy(), g["gp_" + name]) < GTOL, name
+                n_checked += 1
+            elif name.split('.')[0] not in train:
+                assert p.grad is None
+        assert n_checked > 0 or not train
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(True)
+            p.grad = None
+
+
 def test_room0_coarse200_backward():
     from tests.hip_util import model_from_state, renderer_for
     g = load("room0_coarse200")
