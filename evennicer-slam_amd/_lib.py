@@ -66,19 +66,20 @@ _SIGS = {
                                           POINTER(c_double), c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                           c_int32, c_void_p, c_void_p]),
     "enslam_render_fwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
-                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "enslam_activation_floats": (c_size_t, [c_int32, c_int32, c_int32]),
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "enslam_activation_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "enslam_grid_handoff_floats": (c_size_t, [c_int32, c_int32, c_int32]),
     "enslam_eval_points": (ctypes.c_int, [c_int32, c_int64, c_void_p, POINTER(Scene), c_int32, c_void_p, c_void_p]),
     "enslam_render_bwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Grid),
-                                         POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                         POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                         c_void_p]),
     "enslam_composite_fwd": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p]),
     "enslam_composite_bwd": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),
     "enslam_decoder_bwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
-                                          c_void_p, c_void_p, c_void_p, POINTER(Grid), POINTER(c_void_p), c_void_p,
+                                          c_void_p, c_void_p, c_int32, c_void_p, POINTER(Grid), POINTER(c_void_p), c_void_p,
                                           c_void_p, c_void_p]),
     "enslam_rgbd_loss_fwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,
                                             c_void_p]),

@@ -307,7 +307,7 @@ int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const floa
 
 int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                       const double* z_vals, const enslam_scene* scene, double* depth, double* var, float* rgb,
-                      float* raw_out, float* act_ws, void* stream) {
+                      float* raw_out, float* act_ws, int32_t act_light, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
@@ -318,7 +318,7 @@ int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
         for (int k = 1; k < 4; ++k)
             if (d.grid[k].data && (int64_t)d.grid[k].D * d.grid[k].H * d.grid[k].W >= ACT_MAX_VOXELS) return ENSLAM_EUNSUPPORTED;
     return ens_launch_render_fwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, nullptr, 0, 1, d, depth, var,
-                                 rgb, raw_out, stage == ENSLAM_STAGE_COARSE ? nullptr : act_ws, (hipStream_t)stream);
+                                 rgb, raw_out, stage == ENSLAM_STAGE_COARSE ? nullptr : act_ws, act_light != 0, (hipStream_t)stream);
 }
 
 size_t enslam_grid_handoff_floats(int32_t stage, int32_t n_rays, int32_t n_samples) {
@@ -326,9 +326,9 @@ size_t enslam_grid_handoff_floats(int32_t stage, int32_t n_rays, int32_t n_sampl
     return (size_t)n_rays * (size_t)(n_samples / 16) * ACT_SLOTS * DG_STRIDE;
 }
 
-size_t enslam_activation_floats(int32_t stage, int32_t n_rays, int32_t n_samples) {
+size_t enslam_activation_floats(int32_t stage, int32_t n_rays, int32_t n_samples, int32_t act_light) {
     if (stage == ENSLAM_STAGE_COARSE || n_rays <= 0 || n_samples <= 0) return 0;
-    return (size_t)n_rays * (size_t)(n_samples / 16) * ACT_SLOTS * ACT_STRIDE;
+    return (size_t)n_rays * (size_t)(n_samples / 16) * ACT_SLOTS * (act_light ? ACTL_STRIDE : ACT_STRIDE);
 }
 
 int enslam_eval_points(int32_t stage, int64_t n_points, const double* points, const enslam_scene* scene,
@@ -339,7 +339,7 @@ int enslam_eval_points(int32_t stage, int64_t n_points, const double* points, co
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d) || !points || !raw_out) return ENSLAM_EINVAL;
     const int64_t units = (n_points + 47) / 48;
     return ens_launch_render_fwd(stage, 3, units, nullptr, nullptr, nullptr, points, n_points, apply_mask, d, nullptr,
-                                 nullptr, nullptr, raw_out, nullptr, (hipStream_t)stream);
+                                 nullptr, nullptr, raw_out, nullptr, 0, (hipStream_t)stream);
 }
 
 int enslam_composite_fwd(int32_t n_rays, int32_t n_samples, const float* raw, const double* z_vals, double* depth,
@@ -362,8 +362,8 @@ int enslam_composite_bwd(int32_t n_rays, int32_t n_samples, const float* raw, co
 
 int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                        const double* z_vals, const enslam_scene* scene, const float* d_raw, const float* act_ws,
-                       float* dgrid_ws, const enslam_grid* grad_grids, float* const* grad_packed, float* g_rays_o,
-                       float* g_rays_d, void* stream) {
+                       int32_t act_light, float* dgrid_ws, const enslam_grid* grad_grids, float* const* grad_packed,
+                       float* g_rays_o, float* g_rays_d, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
@@ -371,6 +371,9 @@ int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const f
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
     if (!rays_o || !rays_d || !z_vals || !d_raw || !grad_grids || !grad_packed) return ENSLAM_EINVAL;
     if (act_ws != nullptr && g_rays_o != nullptr && dgrid_ws == nullptr && stage != ENSLAM_STAGE_COARSE) return ENSLAM_EINVAL;
+    if (act_ws != nullptr && act_light)                  // the light workspace cannot serve parameter gradients
+        for (int k = 1; k < 4; ++k)
+            if (grad_packed[k] != nullptr) return ENSLAM_EINVAL;
     DevGrid gg[4];
     for (int k = 0; k < 4; ++k) {
         gg[k] = DevGrid{grad_grids[k].data, d.grid[k].D, d.grid[k].H, d.grid[k].W};
@@ -378,7 +381,7 @@ int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const f
             (grad_grids[k].D != d.grid[k].D || grad_grids[k].H != d.grid[k].H || grad_grids[k].W != d.grid[k].W))
             return ENSLAM_EINVAL;
     }
-    return ens_launch_decoder_bwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, d_raw, act_ws, dgrid_ws, gg,
+    return ens_launch_decoder_bwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, d_raw, act_ws, act_light != 0, dgrid_ws, gg,
                                   grad_packed, g_rays_o, g_rays_d, (hipStream_t)stream);
 }
 
@@ -400,11 +403,11 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
                       const double* z_vals, const enslam_scene* scene, const float* raw, const double* depth,
                       const double* g_depth, const double* g_var, const float* g_rgb, const enslam_grid* grad_grids,
                       float* const* grad_packed, float* g_rays_o, float* g_rays_d, float* d_raw, const float* act_ws,
-                      float* dgrid_ws, void* stream) {
+                      int32_t act_light, float* dgrid_ws, void* stream) {
     if (!g_depth && !g_var && !g_rgb) return ENSLAM_EINVAL;
     const int rc = enslam_composite_bwd(n_rays, n_samples, raw, z_vals, depth, g_depth, g_var, g_rgb, d_raw, stream);
     if (rc != ENSLAM_OK) return rc;
-    const int rd = enslam_decoder_bwd(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, d_raw, act_ws, dgrid_ws,
+    const int rd = enslam_decoder_bwd(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, d_raw, act_ws, act_light, dgrid_ws,
                                       grad_grids, grad_packed, g_rays_o, g_rays_d, stream);
     if (rd != ENSLAM_OK || !act_ws || !g_rays_o || !g_rays_d || stage == ENSLAM_STAGE_COARSE) return rd;
     return enslam_ray_grad_bwd(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, dgrid_ws, g_rays_o, g_rays_d,

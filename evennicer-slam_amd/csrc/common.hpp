@@ -89,6 +89,8 @@ constexpr int ACT_H4 = ACT_DEP_TILES_MAX * 256;             // float offset of h
 constexpr int ACT_MASK = ACT_H4 + 2 * 256;                  // float offset of the mask words (128 words)
 constexpr int ACT_VOX = ACT_MASK + 128;                     // float offset of the 16 cell records (vox_record)
 constexpr int ACT_STRIDE = ACT_VOX + 64;                    // floats per (tile, decoder slot)
+// light workspace (no decoder-parameter gradients will be asked for): coordinates tile | mask words | cell records
+constexpr int ACTL_Q = 0, ACTL_MASK = 256, ACTL_VOX = 384, ACTL_STRIDE = 448;
 constexpr int64_t ACT_MAX_VOXELS = (int64_t)1 << 29;        // a cell record keeps the linear voxel index in 29 bits
 constexpr int ACT_SLOTS = 3;                                // decoder slots per tile: middle, fine, color
 // Hand-off from decoder_bwd_kernel to grid_bwd_kernel, per (tile, decoder slot): dC in register layout (2 tiles,

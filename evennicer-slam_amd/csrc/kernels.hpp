@@ -75,13 +75,13 @@ int ens_launch_voxel_index(int64_t n, const double* pts, const double* bound, in
                            int* iz, float* fx, float* fy, float* fz, hipStream_t st);
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
-                          double* var, float* rgb, float* raw, float* act_ws, hipStream_t st);
+                          double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st);
 int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* z, double* depth, double* var,
                              float* rgb, float* weights, hipStream_t st);
 int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* z, const double* depth,
                              const double* g_depth, const double* g_var, const float* g_rgb, float* d_raw,
                              hipStream_t st);
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
-                           const DevScene& sc, const float* d_raw, const float* act_ws, float* dgrid_ws,
+                           const DevScene& sc, const float* d_raw, const float* act_ws, int act_light, float* dgrid_ws,
                            const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,
                            hipStream_t st);

@@ -375,6 +375,7 @@ struct BwdArgs {
     const double* z;
     const float* d_raw;
     const float* act_ws;     // forward activations (render_fwd_kernel) or null: recompute
+    int act_light;           // act_ws holds the light layout (coordinates | masks | cell records): light kernel only
     float* dgrid_ws;         // decoder -> grid_bwd_kernel hand-off (saved path): [tile][slot][DG_STRIDE]
     DevScene sc;
     DevGrid ggrid[4];        // gradient accumulators (data may be null)
@@ -898,6 +899,10 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     };
     // d_raw and the ReLU mask words of a tile are fetched one round ahead: their latency (the vote and the first
     // layer wait on them) hides under the previous round
+    // workspace layout: full, or (light variant only) the light one
+    const bool wl = !WW && A.act_light != 0;
+    const int WSS = wl ? ACTL_STRIDE : ACT_STRIDE, WSM = wl ? ACTL_MASK : ACT_MASK, WSV = wl ? ACTL_VOX : ACT_VOX,
+              WSQ = wl ? ACTL_Q : SL::Q * 256;
     auto tile_of = [&](int64_t b) {
         const int64_t tr = b + wave;
         return __builtin_amdgcn_readfirstlane((int)(tr < n_tiles ? tr : n_tiles - 1));
@@ -907,7 +912,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     if ((int64_t)wg * 4 < n_tiles) {
         const int t0 = tile_of((int64_t)wg * 4);
         draw_n = *reinterpret_cast<const f32x4*>(A.d_raw + ((int64_t)t0 * 16 + p) * 4);
-        mw_n = *reinterpret_cast<const uint2*>(A.act_ws + ((int64_t)t0 * ACT_SLOTS + slot_idx) * ACT_STRIDE + ACT_MASK + lane * 2);
+        mw_n = *reinterpret_cast<const uint2*>(A.act_ws + ((int64_t)t0 * ACT_SLOTS + slot_idx) * WSS + WSM + lane * 2);
     }
     for (int64_t base = (int64_t)wg * 4; base < n_tiles; base += stride) {
         const int64_t tile_raw = base + wave;
@@ -918,7 +923,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         if (base + stride < n_tiles) {
             const int t1 = tile_of(base + stride);
             draw_n = *reinterpret_cast<const f32x4*>(A.d_raw + ((int64_t)t1 * 16 + p) * 4);
-            mw_n = *reinterpret_cast<const uint2*>(A.act_ws + ((int64_t)t1 * ACT_SLOTS + slot_idx) * ACT_STRIDE + ACT_MASK + lane * 2);
+            mw_n = *reinterpret_cast<const uint2*>(A.act_ws + ((int64_t)t1 * ACT_SLOTS + slot_idx) * WSS + WSM + lane * 2);
         }
         if (!tvalid) draw = splat4(0.f);
         float dj[NE];                                               // d(loss)/d(output j) of this lane's sample
@@ -953,7 +958,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
 
         // ---- forward activations from the workspace: deposit tiles straight into this wave's LDS slot (async),
         //      h4 and the ReLU masks into registers
-        const float* __restrict__ wsb = A.act_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * ACT_STRIDE;
+        const float* __restrict__ wsb = A.act_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * WSS;
         f32x4 h4[2] = {splat4(0.f), splat4(0.f)};
         if constexpr (WW) {
             float* myslot = slots + wave * SLOT;
@@ -965,7 +970,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             h4[1] = ld4(wsb + ACT_H4 + 256 + lane * 4);
         }
         f32x4 rec = splat4(0.f);
-        if (want_g) rec = ld4(wsb + ACT_VOX + p * 4);
+        if (want_g) rec = ld4(wsb + WSV + p * 4);
         unsigned mbits[5] = {mw.x & 255u, (mw.x >> 8) & 255u, (mw.x >> 16) & 255u, (mw.x >> 24) & 255u, mw.y & 255u};
         unsigned wsw = swz_base_even(lds0, 32, p, q);                  // swizzled-image lane base, ring buffer 0
         const unsigned swd = swz_odd_delta(p);
@@ -1059,7 +1064,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 if (q < 3) pc = *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(
                                     lds0 + RING_BYTES + (wave * SLOT + SL::Q * 256 + (p >> 2) * 64 + q * 4 + (p & 3)) * 4));
             } else {
-                if (q < 3) pc = wsb[SL::Q * 256 + (p >> 2) * 64 + q * 4 + (p & 3)];       // same tile, straight from the workspace
+                if (q < 3) pc = wsb[WSQ + (p >> 2) * 64 + q * 4 + (p & 3)];               // same tile, straight from the workspace
             }
 #pragma unroll
             for (int t = 0; t < 6; ++t) {                               // cos(arg) recomputed: cheaper than carrying it
@@ -1398,11 +1403,12 @@ int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* 
 }
 
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
-                           const DevScene& sc, const float* d_raw, const float* act_ws, float* dgrid_ws,
+                           const DevScene& sc, const float* d_raw, const float* act_ws, int act_light, float* dgrid_ws,
                            const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,
                            hipStream_t st) {
     if (n_rays <= 0) return 0;
     BwdArgs A;
+    A.act_light = act_light;
     A.act_ws = stage == 0 ? nullptr : act_ws;
     A.dgrid_ws = dgrid_ws;
     A.n_rays = n_rays; A.ntl = ntl; A.ro = ro; A.rd = rd; A.z = z; A.d_raw = d_raw; A.sc = sc;
@@ -1533,6 +1539,7 @@ int ens_launch_ray_grad_bwd(int stage, int ntl, int n_rays, const float* ro, con
     if (!dgrid_ws || !g_ro || !g_rd) return -1;
     BwdArgs A;
     A.act_ws = nullptr;
+    A.act_light = 0;
     A.dgrid_ws = dgrid_ws;
     A.n_rays = n_rays; A.ntl = ntl; A.ro = ro; A.rd = rd; A.z = z; A.d_raw = nullptr; A.sc = sc;
     A.g_ro = g_ro; A.g_rd = g_rd;

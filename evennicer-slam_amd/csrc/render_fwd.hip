@@ -37,8 +37,8 @@ ENS_DEV f32x4 sin4(f32x4 v) { return f32x4{ens_sinf(v[0]), ens_sinf(v[1]), ens_s
 // One block of MLP.forward (decoder.py:193-199): h = relu(W_i x + b_i) + (Wc_i c + bc_i).
 template <int I, int CT, int NTL>
 ENS_DEV void xyz_layer(const float* __restrict__ pk, const f32x4 (&emb)[NTL][6], const f32x4 (&c)[NTL][CT],
-                       f32x4 (&h)[NTL][2], unsigned (&mb)[NTL][2], float* const (&ws)[NTL], float* stage, int lane, int p,
-                       int q) {
+                       f32x4 (&h)[NTL][2], unsigned (&mb)[NTL][2], float* const (&ws)[NTL], bool wl, float* stage, int lane,
+                       int p, int q) {
     constexpr XyzLay L{CT * 16};
     f32x4 acc[NTL][2];
 #pragma unroll
@@ -74,12 +74,16 @@ ENS_DEV void xyz_layer(const float* __restrict__ pk, const f32x4 (&emb)[NTL][6],
         if (ws[tl] != nullptr) {                    // backward operands: slot order EMB 0..5 | h2 6 | h0 8 | h1 10 | h3 12
             constexpr int T = I == 2 ? 6 : (I == 0 ? 8 : (I == 1 ? 10 : 12));
             if constexpr (I < 4) {
-                ws_store_dep(ws[tl] + T * 256, h[tl][0], stage, lane, p, q);
-                ws_store_dep(ws[tl] + (T + 1) * 256, h[tl][1], stage, lane, p, q);
+                if (!wl) {
+                    ws_store_dep(ws[tl] + T * 256, h[tl][0], stage, lane, p, q);
+                    ws_store_dep(ws[tl] + (T + 1) * 256, h[tl][1], stage, lane, p, q);
+                }
             } else {                                // h4 feeds the VALU dWo: register layout
-                *reinterpret_cast<f32x4*>(ws[tl] + ACT_H4 + lane * 4) = h[tl][0];
-                *reinterpret_cast<f32x4*>(ws[tl] + ACT_H4 + 256 + lane * 4) = h[tl][1];
-                *reinterpret_cast<uint2*>(ws[tl] + ACT_MASK + lane * 2) = make_uint2(mb[tl][0], mb[tl][1]);
+                if (!wl) {
+                    *reinterpret_cast<f32x4*>(ws[tl] + ACT_H4 + lane * 4) = h[tl][0];
+                    *reinterpret_cast<f32x4*>(ws[tl] + ACT_H4 + 256 + lane * 4) = h[tl][1];
+                }
+                *reinterpret_cast<uint2*>(ws[tl] + (wl ? ACTL_MASK : ACT_MASK) + lane * 2) = make_uint2(mb[tl][0], mb[tl][1]);
             }
         }
     }
@@ -90,7 +94,7 @@ ENS_DEV void xyz_layer(const float* __restrict__ pk, const f32x4 (&emb)[NTL][6],
 // ws[tl]: activation-workspace block of (tile tl, this decoder) or nullptr (nothing saved)
 template <int CT, int NTL>
 ENS_DEV void mlp_xyz_fwd(const float* __restrict__ pk, const float (&pc)[NTL], const f32x4 (&c)[NTL][CT],
-                         f32x4 (&o)[NTL], float* const (&ws)[NTL], float* stage, int lane, int p, int q) {
+                         f32x4 (&o)[NTL], float* const (&ws)[NTL], bool wl, float* stage, int lane, int p, int q) {
     constexpr XyzLay L{CT * 16};
     f32x4 emb[NTL][6];
 #pragma unroll
@@ -102,24 +106,26 @@ ENS_DEV void mlp_xyz_fwd(const float* __restrict__ pk, const float (&pc)[NTL], c
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
         if (ws[tl] != nullptr) {
+            if (!wl) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) ws_store_dep(ws[tl] + t * 256, emb[tl][t], stage, lane, p, q);
+                for (int t = 0; t < 6; ++t) ws_store_dep(ws[tl] + t * 256, emb[tl][t], stage, lane, p, q);
 #pragma unroll
-            for (int t = 0; t < CT; ++t) ws_store_dep(ws[tl] + (14 + t) * 256, c[tl][t], stage, lane, p, q);
+                for (int t = 0; t < CT; ++t) ws_store_dep(ws[tl] + (14 + t) * 256, c[tl][t], stage, lane, p, q);
+            }
             // sample coordinates as a feature tile (features 0..2 = x,y,z live on q == 0 lanes): dB^T operand
             const float cx = __shfl(pc[tl], p), cy = __shfl(pc[tl], 16 + p), cz = __shfl(pc[tl], 32 + p);
-            ws_store_dep(ws[tl] + (14 + CT) * 256, q == 0 ? f32x4{cx, cy, cz, 0.f} : splat4(0.f), stage, lane, p, q);
+            ws_store_dep(ws[tl] + (wl ? ACTL_Q : (14 + CT) * 256), q == 0 ? f32x4{cx, cy, cz, 0.f} : splat4(0.f), stage, lane, p, q);
         }
     }
     f32x4 h[NTL][2];
     unsigned mb[NTL][2];
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) mb[tl][0] = mb[tl][1] = 0u;
-    xyz_layer<0, CT, NTL>(pk, emb, c, h, mb, ws, stage, lane, p, q);
-    xyz_layer<1, CT, NTL>(pk, emb, c, h, mb, ws, stage, lane, p, q);
-    xyz_layer<2, CT, NTL>(pk, emb, c, h, mb, ws, stage, lane, p, q);
-    xyz_layer<3, CT, NTL>(pk, emb, c, h, mb, ws, stage, lane, p, q);
-    xyz_layer<4, CT, NTL>(pk, emb, c, h, mb, ws, stage, lane, p, q);
+    xyz_layer<0, CT, NTL>(pk, emb, c, h, mb, ws, wl, stage, lane, p, q);
+    xyz_layer<1, CT, NTL>(pk, emb, c, h, mb, ws, wl, stage, lane, p, q);
+    xyz_layer<2, CT, NTL>(pk, emb, c, h, mb, ws, wl, stage, lane, p, q);
+    xyz_layer<3, CT, NTL>(pk, emb, c, h, mb, ws, wl, stage, lane, p, q);
+    xyz_layer<4, CT, NTL>(pk, emb, c, h, mb, ws, wl, stage, lane, p, q);
     out_layer<NTL>(o, pk + L.oWo(), pk + L.obo(), h, p, q);
 }
 
@@ -181,8 +187,9 @@ __global__ __launch_bounds__(64, NTL == 1 ? 3 : 1) void render_fwd_kernel(int64_
                                                         const double* __restrict__ points, int64_t n_points,
                                                         int apply_mask, int tiles_per_ray, DevScene sc, double* __restrict__ depth,
                                                         double* __restrict__ var, float* __restrict__ rgb,
-                                                        float* __restrict__ raw_out, float* __restrict__ act_ws) {
+                                                        float* __restrict__ raw_out, float* __restrict__ act_ws, int wl) {
     __shared__ __attribute__((aligned(16))) float ws_stage[256];
+    const int WSS = wl ? ACTL_STRIDE : ACT_STRIDE, WSV = wl ? ACTL_VOX : ACT_VOX;
     constexpr int S = 16 * NTL;
     const int lane = threadIdx.x, p = lane & 15, q = lane >> 4;
     const bool tile_mode = tiles_per_ray > 0;
@@ -225,10 +232,10 @@ __global__ __launch_bounds__(64, NTL == 1 ? 3 : 1) void render_fwd_kernel(int64_
     float* ws2[NTL];
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
-        float* b = (act_ws != nullptr && points == nullptr) ? act_ws + ((unit * NTL + tl) * ACT_SLOTS) * (int64_t)ACT_STRIDE : nullptr;
+        float* b = (act_ws != nullptr && points == nullptr) ? act_ws + ((unit * NTL + tl) * ACT_SLOTS) * (int64_t)WSS : nullptr;
         ws0[tl] = b;
-        ws1[tl] = b ? b + ACT_STRIDE : nullptr;
-        ws2[tl] = b ? b + 2 * ACT_STRIDE : nullptr;
+        ws1[tl] = b ? b + WSS : nullptr;
+        ws2[tl] = b ? b + 2 * WSS : nullptr;
     }
 
     if constexpr (STAGE == 0) {
@@ -245,21 +252,21 @@ __global__ __launch_bounds__(64, NTL == 1 ? 3 : 1) void render_fwd_kernel(int64_
         for (int tl = 0; tl < NTL; ++tl) {
             const Vox v = make_vox(pw[tl], sc.lo, sc.hi, sc.grid[1]);
             gather8(v, sc.grid[1], q, cm[tl][0], cm[tl][1]);
-            if (ws0[tl] != nullptr && q == 0) *reinterpret_cast<f32x4*>(ws0[tl] + ACT_VOX + p * 4) = vox_record(v, sc.grid[1]);
+            if (ws0[tl] != nullptr && q == 0) *reinterpret_cast<f32x4*>(ws0[tl] + WSV + p * 4) = vox_record(v, sc.grid[1]);
         }
-        mlp_xyz_fwd<2, NTL>(sc.packed[1], pc, cm, occ, ws0, ws_stage, lane, p, q);
+        mlp_xyz_fwd<2, NTL>(sc.packed[1], pc, cm, occ, ws0, wl != 0, ws_stage, lane, p, q);
         if constexpr (STAGE >= 2) {
             f32x4 cf[NTL][4];
 #pragma unroll
             for (int tl = 0; tl < NTL; ++tl) {
                 const Vox v = make_vox(pw[tl], sc.lo, sc.hi, sc.grid[2]);
                 gather8(v, sc.grid[2], q, cf[tl][0], cf[tl][1]);
-                if (ws1[tl] != nullptr && q == 0) *reinterpret_cast<f32x4*>(ws1[tl] + ACT_VOX + p * 4) = vox_record(v, sc.grid[2]);
+                if (ws1[tl] != nullptr && q == 0) *reinterpret_cast<f32x4*>(ws1[tl] + WSV + p * 4) = vox_record(v, sc.grid[2]);
                 cf[tl][2] = cm[tl][0];                                    // decoder.py:184-187 concat
                 cf[tl][3] = cm[tl][1];
             }
             f32x4 of[NTL];
-            mlp_xyz_fwd<4, NTL>(sc.packed[2], pc, cf, of, ws1, ws_stage, lane, p, q);
+            mlp_xyz_fwd<4, NTL>(sc.packed[2], pc, cf, of, ws1, wl != 0, ws_stage, lane, p, q);
 #pragma unroll
             for (int tl = 0; tl < NTL; ++tl) occ[tl][0] = of[tl][0] + occ[tl][0];   // fine_occ + middle_occ
         }
@@ -269,9 +276,9 @@ __global__ __launch_bounds__(64, NTL == 1 ? 3 : 1) void render_fwd_kernel(int64_
             for (int tl = 0; tl < NTL; ++tl) {
                 const Vox v = make_vox(pw[tl], sc.lo, sc.hi, sc.grid[3]);
                 gather8(v, sc.grid[3], q, cc[tl][0], cc[tl][1]);
-                if (ws2[tl] != nullptr && q == 0) *reinterpret_cast<f32x4*>(ws2[tl] + ACT_VOX + p * 4) = vox_record(v, sc.grid[3]);
+                if (ws2[tl] != nullptr && q == 0) *reinterpret_cast<f32x4*>(ws2[tl] + WSV + p * 4) = vox_record(v, sc.grid[3]);
             }
-            mlp_xyz_fwd<2, NTL>(sc.packed[3], pc, cc, col, ws2, ws_stage, lane, p, q);
+            mlp_xyz_fwd<2, NTL>(sc.packed[3], pc, cc, col, ws2, wl != 0, ws_stage, lane, p, q);
         }
     }
 
@@ -341,7 +348,7 @@ constexpr int fwd_ring_lds_bytes(int stage) { return (2 * fwd_ring_floats(stage)
 // layer 0 follows in the ring (nullptr: none).  NEXT_CD: its fc_c width.
 template <int CT, int C0, int RB, int NEXT_CD>
 ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict__ pk_next, float* ring, float pc,
-                          const f32x4 (&c)[CT], f32x4& o, float* ws, float* stage, unsigned w32, unsigned w96,
+                          const f32x4 (&c)[CT], f32x4& o, float* ws, bool wl, float* stage, unsigned w32, unsigned w96,
                           unsigned w128, unsigned wcd, unsigned wq, int wave, int lane, int p, int q) {
     constexpr XyzLay L{CT * 16};
     constexpr int CD = CT * 16;
@@ -352,12 +359,14 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
         emb[t] = sin4(MFMA16(a, pc, splat4(0.f)));
     }
     if (ws != nullptr) {
+        if (!wl) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t) ws_store_dep(ws + t * 256, emb[t], stage, lane, p, q);
+            for (int t = 0; t < 6; ++t) ws_store_dep(ws + t * 256, emb[t], stage, lane, p, q);
 #pragma unroll
-        for (int t = 0; t < CT; ++t) ws_store_dep(ws + (14 + t) * 256, c[t], stage, lane, p, q);
+            for (int t = 0; t < CT; ++t) ws_store_dep(ws + (14 + t) * 256, c[t], stage, lane, p, q);
+        }
         const float cx = __shfl(pc, p), cy = __shfl(pc, 16 + p), cz = __shfl(pc, 32 + p);
-        ws_store_dep(ws + (14 + CT) * 256, q == 0 ? f32x4{cx, cy, cz, 0.f} : splat4(0.f), stage, lane, p, q);
+        ws_store_dep(ws + (wl ? ACTL_Q : (14 + CT) * 256), q == 0 ? f32x4{cx, cy, cz, 0.f} : splat4(0.f), stage, lane, p, q);
     }
     f32x4 h[5][2];
     unsigned mb0 = 0u, mb1 = 0u;
@@ -394,12 +403,16 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
         if (ws != nullptr) {
             constexpr int T = i == 2 ? 6 : (i == 0 ? 8 : (i == 1 ? 10 : 12));
             if constexpr (i < 4) {
-                ws_store_dep(ws + T * 256, h[i][0], stage, lane, p, q);
-                ws_store_dep(ws + (T + 1) * 256, h[i][1], stage, lane, p, q);
+                if (!wl) {
+                    ws_store_dep(ws + T * 256, h[i][0], stage, lane, p, q);
+                    ws_store_dep(ws + (T + 1) * 256, h[i][1], stage, lane, p, q);
+                }
             } else {
-                *reinterpret_cast<f32x4*>(ws + ACT_H4 + lane * 4) = h[4][0];
-                *reinterpret_cast<f32x4*>(ws + ACT_H4 + 256 + lane * 4) = h[4][1];
-                *reinterpret_cast<uint2*>(ws + ACT_MASK + lane * 2) = make_uint2(mb0, mb1);
+                if (!wl) {
+                    *reinterpret_cast<f32x4*>(ws + ACT_H4 + lane * 4) = h[4][0];
+                    *reinterpret_cast<f32x4*>(ws + ACT_H4 + 256 + lane * 4) = h[4][1];
+                }
+                *reinterpret_cast<uint2*>(ws + (wl ? ACTL_MASK : ACT_MASK) + lane * 2) = make_uint2(mb0, mb1);
             }
         }
         __syncthreads();                // next chunk landed; all waves done with this buffer
@@ -418,8 +431,10 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
                                                                  const float* __restrict__ rays_o,
                                                                  const float* __restrict__ rays_d,
                                                                  const double* __restrict__ z_vals, DevScene sc,
-                                                                 float* __restrict__ raw_out, float* __restrict__ act_ws) {
+                                                                 float* __restrict__ raw_out, float* __restrict__ act_ws, int wli) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
+    const bool wl = wli != 0;
+    const int WSS = wl ? ACTL_STRIDE : ACT_STRIDE, WSV = wl ? ACTL_VOX : ACT_VOX;
     constexpr int RB = fwd_ring_floats(STAGE);
     float* ring = fsm;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
@@ -448,30 +463,30 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     unsigned w128 = lds0 + (p * 128 + 4 * q) * 4, wq = lds0 + q * 16;
     opaque(w32); opaque(w64); opaque(w96); opaque(w128); opaque(wq);
 
-    float* wsb = (act_ws != nullptr && tvalid) ? act_ws + (tile * ACT_SLOTS) * (int64_t)ACT_STRIDE : nullptr;
+    float* wsb = (act_ws != nullptr && tvalid) ? act_ws + (tile * ACT_SLOTS) * (int64_t)WSS : nullptr;
     f32x4 occ = splat4(0.f), col = splat4(0.f);
 
     f32x4 cm[2];
     {
         const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[1]);
         gather8(v, sc.grid[1], q, cm[0], cm[1]);
-        if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + ACT_VOX + p * 4) = vox_record(v, sc.grid[1]);
+        if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + WSV + p * 4) = vox_record(v, sc.grid[1]);
     }
     __syncthreads();                                                                   // chunk 0 landed
     mlp_xyz_ring<2, 0, RB, (STAGE >= 2 ? 64 : 0)>(sc.packed[1], STAGE >= 2 ? sc.packed[2] : nullptr, ring, pc, cm, occ, wsb,
-                                                   stage, w32, w96, w128, w32, wq, wave, lane, p, q);
+                                                   wl, stage, w32, w96, w128, w32, wq, wave, lane, p, q);
     if constexpr (STAGE >= 2) {
         f32x4 cf[4];
         {
             const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[2]);
             gather8(v, sc.grid[2], q, cf[0], cf[1]);
-            if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + ACT_STRIDE + ACT_VOX + p * 4) = vox_record(v, sc.grid[2]);
+            if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + WSS + WSV + p * 4) = vox_record(v, sc.grid[2]);
         }
         cf[2] = cm[0];
         cf[3] = cm[1];
         f32x4 of;
         mlp_xyz_ring<4, 5, RB, (STAGE == 3 ? 32 : 0)>(sc.packed[2], STAGE == 3 ? sc.packed[3] : nullptr, ring, pc, cf, of,
-                                                      wsb ? wsb + ACT_STRIDE : nullptr, stage, w32, w96, w128, w64, wq, wave,
+                                                      wsb ? wsb + WSS : nullptr, wl, stage, w32, w96, w128, w64, wq, wave,
                                                       lane, p, q);
         occ[0] = of[0] + occ[0];                                                        // fine_occ + middle_occ
     }
@@ -480,9 +495,9 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
         {
             const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[3]);
             gather8(v, sc.grid[3], q, cc[0], cc[1]);
-            if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + 2 * ACT_STRIDE + ACT_VOX + p * 4) = vox_record(v, sc.grid[3]);
+            if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + 2 * WSS + WSV + p * 4) = vox_record(v, sc.grid[3]);
         }
-        mlp_xyz_ring<2, 10, RB, 0>(sc.packed[3], nullptr, ring, pc, cc, col, wsb ? wsb + 2 * ACT_STRIDE : nullptr, stage,
+        mlp_xyz_ring<2, 10, RB, 0>(sc.packed[3], nullptr, ring, pc, cc, col, wsb ? wsb + 2 * WSS : nullptr, wl, stage,
                                    w32, w96, w128, w32, wq, wave, lane, p, q);
     }
     if (q == 0 && tvalid) {                                                             // rows 0..3 live on q == 0 lanes
@@ -528,14 +543,14 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(int S, const float* _
 
 template <int STAGE>
 int launch_stage(int ntl, int64_t n_units, const float* ro, const float* rd, const double* z, const double* pts,
-                 int64_t n_points, int apply_mask, int tpr, float* act_ws, const DevScene& sc, double* depth, double* var, float* rgb, float* raw,
+                 int64_t n_points, int apply_mask, int tpr, float* act_ws, int wl, const DevScene& sc, double* depth, double* var, float* rgb, float* raw,
                  hipStream_t st) {
     if (n_units <= 0) return 0;
     const dim3 grid((unsigned)n_units), block(64);
     switch (ntl) {
-        case 1: render_fwd_kernel<STAGE, 1><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, act_ws); break;
-        case 2: render_fwd_kernel<STAGE, 2><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, act_ws); break;
-        case 3: render_fwd_kernel<STAGE, 3><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, act_ws); break;
+        case 1: render_fwd_kernel<STAGE, 1><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, act_ws, wl); break;
+        case 2: render_fwd_kernel<STAGE, 2><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, act_ws, wl); break;
+        case 3: render_fwd_kernel<STAGE, 3><<<grid, block, 0, st>>>(n_units, ro, rd, z, pts, n_points, apply_mask, tpr, sc, depth, var, rgb, raw, act_ws, wl); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -552,7 +567,7 @@ int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* 
 
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
-                          double* var, float* rgb, float* raw, float* act_ws, hipStream_t st) {
+                          double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st) {
     // Ray mode with raw requested and a moderate ray count: tile-per-wave decoders + separate compositing (more
     // waves in flight).  Large batches (full-image renders) already fill the chip with one wave per ray.
     int tpr = 0;
@@ -572,17 +587,17 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
             attr_set = true;
         }
         const dim3 grid((unsigned)((n_units + 3) / 4)), block(256);
-        if (stage == 1) render_fwd_ring_kernel<1><<<grid, block, fwd_ring_lds_bytes(1), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws);
-        else if (stage == 2) render_fwd_ring_kernel<2><<<grid, block, fwd_ring_lds_bytes(2), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws);
-        else render_fwd_ring_kernel<3><<<grid, block, fwd_ring_lds_bytes(3), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws);
+        if (stage == 1) render_fwd_ring_kernel<1><<<grid, block, fwd_ring_lds_bytes(1), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
+        else if (stage == 2) render_fwd_ring_kernel<2><<<grid, block, fwd_ring_lds_bytes(2), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
+        else render_fwd_ring_kernel<3><<<grid, block, fwd_ring_lds_bytes(3), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
         if (hipGetLastError() != hipSuccess) return -2;
         return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st);
     }
     switch (stage) {
-        case 0: rc = launch_stage<0>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, sc, depth, var, rgb, raw, st); break;
-        case 1: rc = launch_stage<1>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, sc, depth, var, rgb, raw, st); break;
-        case 2: rc = launch_stage<2>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, sc, depth, var, rgb, raw, st); break;
-        case 3: rc = launch_stage<3>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, sc, depth, var, rgb, raw, st); break;
+        case 0: rc = launch_stage<0>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, act_light, sc, depth, var, rgb, raw, st); break;
+        case 1: rc = launch_stage<1>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, act_light, sc, depth, var, rgb, raw, st); break;
+        case 2: rc = launch_stage<2>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, act_light, sc, depth, var, rgb, raw, st); break;
+        case 3: rc = launch_stage<3>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, act_light, sc, depth, var, rgb, raw, st); break;
         default: return -1;
     }
     if (rc != 0 || tpr == 0) return rc;

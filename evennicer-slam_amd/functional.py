@@ -433,13 +433,16 @@ class _RenderFn(torch.autograd.Function):
         raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
         # a backward will follow: let the forward park the backward's operands (else the backward recomputes them)
         act = None
+        # no decoder parameter wants a gradient (tracker; mapper stages with fixed decoders): the light workspace
+        act_light = int(not any(ctx.needs_input_grad[5 + nk:]))
         if any(ctx.needs_input_grad):
-            n_act = lib.enslam_activation_floats(L.STAGE[plan.stage], N, S)
+            n_act = lib.enslam_activation_floats(L.STAGE[plan.stage], N, S, act_light)
             if 0 < n_act * 4 <= ACT_WORKSPACE_LIMIT_BYTES and max(d[0] * d[1] * d[2] for d in dims.values()) < (1 << 29):
                 act = torch.empty(n_act, dtype=torch.float32, device=dev)
         L.check(lib.enslam_render_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                      _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), st), "enslam_render_fwd")
-        ctx.plan, ctx.S, ctx.dims = plan, S, dims
+                                      _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, st),
+                "enslam_render_fwd")
+        ctx.plan, ctx.S, ctx.dims, ctx.act_light = plan, S, dims, act_light
         ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act, flags)
         ctx.grid_shapes = [tuple(g.shape) for g in grids]
         ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
@@ -527,7 +530,8 @@ class _RenderFn(torch.autograd.Function):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         L.check(lib.enslam_decoder_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                       _ptr(d_raw), _ptr(act), _ptr(dgw), gg, gpk, p_ro, p_rd, st), "enslam_decoder_bwd")
+                                       _ptr(d_raw), _ptr(act), ctx.act_light, _ptr(dgw), gg, gpk, p_ro, p_rd, st),
+                "enslam_decoder_bwd")
         if ev is not None:
             e1.record()
             ev.append((e0, e1))

@@ -166,14 +166,17 @@ int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const floa
  * raw_out (may be NULL) receives the per-sample (r,g,b,occ) needed by enslam_render_bwd. */
 int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                       const double *z_vals, const enslam_scene *scene, double *depth, double *var, float *rgb,
-                      float *raw_out, float *act_ws, void *stream);
+                      float *raw_out, float *act_ws, int32_t act_light, void *stream);
 
 /* float32 count of the activation workspace `act_ws` for a batch (0 for the coarse stage, which always
  * recomputes).  When enslam_render_fwd is given a workspace of this size it also writes, per 16-sample tile and
  * decoder, the operands the backward needs (embedding, grid features, hidden activations, ReLU masks), and
  * enslam_decoder_bwd / enslam_render_bwd given the same buffer read them instead of recomputing the decoder
- * forward.  NULL in both places selects recomputation (no extra memory, slower backward). */
-size_t enslam_activation_floats(int32_t stage, int32_t n_rays, int32_t n_samples);
+ * forward.  NULL in both places selects recomputation (no extra memory, slower backward).
+ * act_light != 0 (same value in the size query, the forward and the backward): the backward will be asked for no
+ * decoder-parameter gradient (tracker iterations, mapper stages with fixed decoders), so only the sample
+ * coordinates, the ReLU masks and the trilinear cell records are kept: 1.8 KB instead of 22 KB per tile and decoder. */
+size_t enslam_activation_floats(int32_t stage, int32_t n_rays, int32_t n_samples, int32_t act_light);
 /* float32 count of the scratch buffer `dgrid_ws` the backward needs when it runs from `act_ws` AND ray gradients
  * are requested (decoder kernel -> ray-gradient kernel hand-off: feature gradient and embedding position gradient per
  * tile and decoder).  dgrid_ws may be NULL when g_rays_o is NULL.  act_ws needs every grid below 2^29 voxels. */
@@ -197,7 +200,7 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
                       const double *z_vals, const enslam_scene *scene, const float *raw, const double *depth,
                       const double *g_depth, const double *g_var, const float *g_rgb,
                       const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o, float *g_rays_d,
-                      float *d_raw, const float *act_ws, float *dgrid_ws, void *stream);
+                      float *d_raw, const float *act_ws, int32_t act_light, float *dgrid_ws, void *stream);
 
 /* The two halves of enslam_render_bwd, callable on their own.
  * enslam_composite_bwd: backward of raw2outputs_nerf_color (common.py:284-296): d(depth,var,rgb) -> d_raw [N*S,4].
@@ -212,8 +215,8 @@ int enslam_composite_bwd(int32_t n_rays, int32_t n_samples, const float *raw, co
                          float *d_raw, void *stream);
 int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                        const double *z_vals, const enslam_scene *scene, const float *d_raw, const float *act_ws,
-                       float *dgrid_ws, const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o,
-                       float *g_rays_d, void *stream);
+                       int32_t act_light, float *dgrid_ws, const enslam_grid *grad_grids, float *const *grad_packed,
+                       float *g_rays_o, float *g_rays_d, void *stream);
 int enslam_ray_grad_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                         const double *z_vals, const enslam_scene *scene, float *dgrid_ws, float *g_rays_o,
                         float *g_rays_d, void *stream);
