@@ -78,3 +78,57 @@ def raw2outputs_nerf_color(raw, z_vals, rays_d, occupancy=False, device='cuda:0'
         raise NotImplementedError("volume-density compositing (occupancy=False) is the iMAP mode, out of scope")
     from . import functional as EF
     return EF.composite(raw, z_vals)
+
+
+# ------------------------------------------------------------------------------------------------
+# camera tensor <-> pose (reference: src/common.py:189-254).  The tracker and the BA mapper optimise a 7-vector
+# [qr, qi, qj, qk, tx, ty, tz]; its gradient reaches the path through rays_o / rays_d.
+# ------------------------------------------------------------------------------------------------
+def quad2rotation(quad):
+    """Rotation matrices [B,3,3] of (unnormalised) quaternions [B,4] = (real, i, j, k); differentiable."""
+    qr, qi, qj, qk = quad.unbind(-1)
+    two_s = 2.0 / (quad * quad).sum(-1)
+    rows = (
+        1 - two_s * (qj ** 2 + qk ** 2), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
+        two_s * (qi * qj + qk * qr), 1 - two_s * (qi ** 2 + qk ** 2), two_s * (qj * qk - qi * qr),
+        two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi ** 2 + qj ** 2),
+    )
+    return torch.stack(rows, -1).reshape(quad.shape[:-1] + (3, 3))
+
+
+def get_camera_from_tensor(inputs):
+    """[.., 7] (quaternion, translation) -> camera-to-world [.., 3, 4]."""
+    single = inputs.dim() == 1
+    x = inputs[None] if single else inputs
+    RT = torch.cat([quad2rotation(x[:, :4]), x[:, 4:, None]], 2)
+    return RT[0] if single else RT
+
+
+def get_tensor_from_camera(RT, Tquad=False):
+    """camera-to-world [3|4, 4] -> 7-vector (quaternion first, or translation first with Tquad).  The reference
+    goes through mathutils.Matrix.to_quaternion on the host; this is the same conversion (largest-diagonal branch,
+    real part >= 0 up to the sign convention of a unit quaternion) in float64 torch ops, result float32 on RT's device."""
+    if not torch.is_tensor(RT):
+        RT = torch.from_numpy(np.asarray(RT))
+    dev = RT.device
+    M = RT.detach().to('cpu', torch.float64)
+    R, T = M[:3, :3], M[:3, 3]
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = [float(v) for v in R.reshape(-1)]
+    tr = m00 + m11 + m22
+    if tr > 0:
+        s = 2.0 * (tr + 1.0) ** 0.5
+        q = [0.25 * s, (m21 - m12) / s, (m02 - m20) / s, (m10 - m01) / s]
+    elif m00 > m11 and m00 > m22:
+        s = 2.0 * (1.0 + m00 - m11 - m22) ** 0.5
+        q = [(m21 - m12) / s, 0.25 * s, (m01 + m10) / s, (m02 + m20) / s]
+    elif m11 > m22:
+        s = 2.0 * (1.0 + m11 - m00 - m22) ** 0.5
+        q = [(m02 - m20) / s, (m01 + m10) / s, 0.25 * s, (m12 + m21) / s]
+    else:
+        s = 2.0 * (1.0 + m22 - m00 - m11) ** 0.5
+        q = [(m10 - m01) / s, (m02 + m20) / s, (m12 + m21) / s, 0.25 * s]
+    quad = torch.tensor(q, dtype=torch.float64)
+    if quad[0] < 0:
+        quad = -quad
+    out = torch.cat([T, quad]) if Tquad else torch.cat([quad, T])
+    return out.float().to(dev)

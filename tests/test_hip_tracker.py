@@ -1,0 +1,54 @@
+"""-m gpu: one camera iteration of the tracker (pose -> rays -> HIP render -> uncertainty-weighted loss -> pose
+gradient) against the fixture produced by the reference's own statements (tests/golden/tiny_tracker_iter.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pose_gradient_matches_reference_fixture():
+    import evennicer_slam_amd as E
+    from tests.hip_util import DEV, tiny_on_gpu
+    g = load("tiny_tracker_iter")
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    H, W, fx, fy, cx, cy = [float(x) for x in g['cam']]
+    He, We = int(g['edge'][0]), int(g['edge'][1])
+    for p in model.parameters():                       # the tracker optimises the camera only (Tracker.py:248-260)
+        p.requires_grad_(False)
+    try:
+        ct = torch.from_numpy(g['camera_tensor']).to(DEV).requires_grad_(True)
+        c2w = E.common.get_camera_from_tensor(ct)
+        assert np.array_equal(c2w.detach().cpu().numpy(), g['c2w'])
+        # the reference's pixel draw (the RNG streams of CPU and HIP generators differ: identical indices are fed)
+        idx = torch.from_numpy(g['idx']).to(DEV)
+        ww = int(W) - 2 * We
+        i = (We + idx % ww).float()
+        j = (He + idx // ww).float()
+        ro, rd = E.common.get_rays_from_uv(i, j, c2w, int(H), int(W), fx, fy, cx, cy, DEV)
+        assert np.allclose(rd.detach().cpu().numpy(), g['rays_d_all'], rtol=0, atol=1e-6)
+        gd_img = torch.from_numpy(g['gt_depth']).to(DEV)
+        gc_img = torch.from_numpy(g['gt_color']).to(DEV)
+        pix = (j.long() * int(W) + i.long())
+        gd, gc = gd_img.reshape(-1)[pix], gc_img.reshape(-1, 3)[pix]
+        with torch.no_grad():                          # Tracker.py:164-170
+            t = (bound.to(DEV).float().unsqueeze(0) - ro.detach().unsqueeze(-1)) / rd.detach().unsqueeze(-1)
+            t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
+            inside = t >= gd
+        assert np.array_equal(inside.cpu().numpy(), g['inside_mask'])
+        ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]
+        depth, unc, color = renderer.render_batch_ray(grids, model, rd, ro, DEV, 'color', gt_depth=gd)
+        assert rel_err(depth.detach().cpu().numpy(), g['depth']) <= 1e-4
+        assert rel_err(color.detach().cpu().numpy(), g['color']) <= 1e-4
+        unc = unc.detach()
+        mask = gd > 0
+        loss = (torch.abs(gd - depth) / torch.sqrt(unc + 1e-10))[mask].sum()
+        loss = loss + float(g['w_color_loss']) * torch.abs(gc - color)[mask].sum()
+        assert abs(loss.item() - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+        loss.backward()
+        assert rel_err(ct.grad.cpu().numpy(), g['g_camera_tensor']) <= 1e-3
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(True)
