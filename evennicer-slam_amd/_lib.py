@@ -50,6 +50,14 @@ _SIGS = {
                                           POINTER(c_void_p), c_void_p]),
     "enslam_grids_convert_sparse": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64),
                                                    POINTER(c_void_p), POINTER(c_void_p), c_int32, c_void_p]),
+    "enslam_pose_rays_fwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float,
+                                            ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p]),
+    "enslam_pose_rays_bwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float,
+                                            ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "enslam_tracker_loss_fwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float,
+                                               c_void_p, c_void_p]),
+    "enslam_tracker_loss_bwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "enslam_adam_masked": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                           POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), POINTER(c_void_p),
                                           ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p]),

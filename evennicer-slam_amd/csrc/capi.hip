@@ -229,6 +229,38 @@ int enslam_zero_blocks(int32_t n, float* const* dst, const int64_t* n_voxels, co
     return ens_launch_zero_blocks(job, flat, n_flat, (hipStream_t)stream);
 }
 
+int enslam_tracker_loss_fwd(int32_t n, const double* depth, const double* uncertainty, const float* color,
+                            const float* gt_depth, const float* gt_color, float w_color, double* loss, void* stream) {
+    if (n < 0 || !loss || (n > 0 && (!depth || !uncertainty || !gt_depth)) || ((color == nullptr) != (gt_color == nullptr)))
+        return ENSLAM_EINVAL;
+    return ens_launch_tracker_loss(n, depth, uncertainty, color, gt_depth, gt_color, w_color, nullptr, loss, nullptr, nullptr,
+                                   (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+int enslam_tracker_loss_bwd(int32_t n, const double* depth, const double* uncertainty, const float* color,
+                            const float* gt_depth, const float* gt_color, float w_color, const double* g_loss,
+                            double* g_depth, float* g_color, void* stream) {
+    if (n < 0 || !g_loss || (n > 0 && (!depth || !uncertainty || !gt_depth || !g_depth)) ||
+        ((color == nullptr) != (gt_color == nullptr)))
+        return ENSLAM_EINVAL;
+    if (n == 0) return ENSLAM_OK;
+    return ens_launch_tracker_loss(n, depth, uncertainty, color, gt_depth, gt_color, w_color, g_loss, nullptr, g_depth,
+                                   g_color, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+int enslam_pose_rays_fwd(int32_t n, const float* camera_tensor, const float* pix_i, const float* pix_j, float fx,
+                         float fy, float cx, float cy, float* rays_o, float* rays_d, void* stream) {
+    if (n < 0 || !camera_tensor || (n > 0 && (!pix_i || !pix_j || !rays_o || !rays_d))) return ENSLAM_EINVAL;
+    if (n == 0) return ENSLAM_OK;
+    return ens_launch_pose_rays(n, camera_tensor, pix_i, pix_j, fx, fy, cx, cy, nullptr, nullptr, rays_o, rays_d, nullptr,
+                                (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+int enslam_pose_rays_bwd(int32_t n, const float* camera_tensor, const float* pix_i, const float* pix_j, float fx,
+                         float fy, float cx, float cy, const float* g_rays_o, const float* g_rays_d,
+                         float* g_camera_tensor, void* stream) {
+    if (n < 0 || !camera_tensor || !g_camera_tensor || (n > 0 && (!pix_i || !pix_j))) return ENSLAM_EINVAL;
+    return ens_launch_pose_rays(n, camera_tensor, pix_i, pix_j, fx, fy, cx, cy, g_rays_o, g_rays_d, nullptr, nullptr,
+                                g_camera_tensor, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+
 int enslam_adam_masked(int32_t n, float* const* param, float* const* grad, float* const* exp_avg,
                        float* const* exp_avg_sq, const uint8_t* const* mask, const int64_t* n_voxels,
                        const double* const* lr, const int32_t* const* step, double beta1, double beta2, double eps,

@@ -59,6 +59,11 @@ int ens_launch_transpose(const float* src, float* dst, int64_t n_vox, bool to_vo
 int ens_launch_convert(const ConvJob& job, bool to_voxel_major, hipStream_t st);
 int ens_launch_ray_grad_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
                             const DevScene& sc, float* dgrid_ws, float* g_ro, float* g_rd, hipStream_t st);
+int ens_launch_tracker_loss(int n, const double* depth, const double* unc, const float* color, const float* gd,
+                            const float* gc, float w, const double* g_loss, double* loss, double* g_depth, float* g_color,
+                            hipStream_t st);
+int ens_launch_pose_rays(int n, const float* ct, const float* pi, const float* pj, float fx, float fy, float cx, float cy,
+                         const float* g_ro, const float* g_rd, float* ro, float* rd, float* g_ct, hipStream_t st);
 int ens_launch_adam(const AdamJob& job, hipStream_t st);
 int ens_launch_adam_tensors(const AdamTensorsJob& job, hipStream_t st);
 int ens_launch_zero_blocks(const ConvJob& job, float* flat, int64_t n_flat, hipStream_t st);

@@ -140,6 +140,146 @@ __global__ __launch_bounds__(1024) void rgbd_loss_fwd_kernel(int n, const double
     }
 }
 ENS_DEV float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// ------------------------------------------------------------------ tracker glue (Tracker.py:141-197)
+// Tracker's RGB-D loss (:179-195, handle_dynamic off):  sum_{gd>0} |gd - d| / sqrt(u + 1e-10)  +  w * sum_{gd>0} |gc - c|
+__global__ __launch_bounds__(1024) void tracker_loss_fwd_kernel(int n, const double* __restrict__ depth,
+                                                                const double* __restrict__ unc,
+                                                                const float* __restrict__ color,
+                                                                const float* __restrict__ gd, const float* __restrict__ gc,
+                                                                float w, double* __restrict__ loss) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float g = gd[i];
+        if (!(g > 0.f)) continue;
+        acc += fabs((double)g - depth[i]) / sqrt(unc[i] + 1e-10);
+        if (color != nullptr) {
+            float c = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) c += fabsf(gc[i * 3 + a] - color[i * 3 + a]);
+            acc += (double)w * (double)c;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        acc = red[threadIdx.x];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (threadIdx.x == 0) loss[0] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void tracker_loss_bwd_kernel(int n, const double* __restrict__ depth,
+                                                               const double* __restrict__ unc,
+                                                               const float* __restrict__ color,
+                                                               const float* __restrict__ gd, const float* __restrict__ gc,
+                                                               float w, const double* __restrict__ g_loss,
+                                                               double* __restrict__ g_depth, float* __restrict__ g_color) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double g = g_loss[0];
+    const float t = gd[i];
+    const bool on = t > 0.f;
+    const double diff = (double)t - depth[i];
+    g_depth[i] = on ? (diff > 0.0 ? -g : (diff < 0.0 ? g : 0.0)) / sqrt(unc[i] + 1e-10) : 0.0;
+    if (color != nullptr && g_color != nullptr) {
+        const float gw = (float)g * w;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g_color[i * 3 + a] = on ? -gw * sgnf(gc[i * 3 + a] - color[i * 3 + a]) : 0.f;
+    }
+}
+
+// camera tensor (unnormalised quaternion qr,qi,qj,qk + translation) -> rays through pixels (i, j):
+// common.py:189-229 (quad2rotation, get_camera_from_tensor) + :74-89 (get_rays_from_uv) in one launch.
+struct PoseR { float r[3][3]; float s; };
+ENS_DEV PoseR pose_rotation(const float* __restrict__ ct) {
+    const float qr = ct[0], qi = ct[1], qj = ct[2], qk = ct[3];
+    PoseR o;
+    o.s = 2.0f / (((qr * qr + qi * qi) + qj * qj) + qk * qk);
+    const float s = o.s;
+    o.r[0][0] = 1.f - s * (qj * qj + qk * qk); o.r[0][1] = s * (qi * qj - qk * qr); o.r[0][2] = s * (qi * qk + qj * qr);
+    o.r[1][0] = s * (qi * qj + qk * qr); o.r[1][1] = 1.f - s * (qi * qi + qk * qk); o.r[1][2] = s * (qj * qk - qi * qr);
+    o.r[2][0] = s * (qi * qk - qj * qr); o.r[2][1] = s * (qj * qk + qi * qr); o.r[2][2] = 1.f - s * (qi * qi + qj * qj);
+    return o;
+}
+__global__ __launch_bounds__(256) void pose_rays_fwd_kernel(int n, const float* __restrict__ ct,
+                                                            const float* __restrict__ pi, const float* __restrict__ pj,
+                                                            float fx, float fy, float cx, float cy,
+                                                            float* __restrict__ ro, float* __restrict__ rd) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const PoseR R = pose_rotation(ct);
+    const float d0 = (pi[k] - cx) / fx, d1 = -(pj[k] - cy) / fy, d2 = -1.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        rd[k * 3 + a] = (d0 * R.r[a][0] + d1 * R.r[a][1]) + d2 * R.r[a][2];
+        ro[k * 3 + a] = ct[4 + a];
+    }
+}
+// d loss / d camera tensor from the ray gradients: G[a][b] = sum_n g_rd[n][a] dir[n][b], g_T = sum_n g_ro[n], then the
+// chain through R = I + s P(q), s = 2/|q|^2.  One workgroup, float64 accumulation, deterministic.
+__global__ __launch_bounds__(1024) void pose_rays_bwd_kernel(int n, const float* __restrict__ ct,
+                                                             const float* __restrict__ pi, const float* __restrict__ pj,
+                                                             float fx, float fy, float cx, float cy,
+                                                             const float* __restrict__ g_ro, const float* __restrict__ g_rd,
+                                                             float* __restrict__ g_ct) {
+    __shared__ double red[16][12];
+    double acc[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = 0.0;
+    for (int k = threadIdx.x; k < n; k += 1024) {
+        const double d[3] = {(double)((pi[k] - cx) / fx), (double)(-(pj[k] - cy) / fy), -1.0};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double g = g_rd ? (double)g_rd[k * 3 + a] : 0.0;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[a * 3 + b] += g * d[b];
+            acc[9 + a] += g_ro ? (double)g_ro[k * 3 + a] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[e] += __shfl_xor(acc[e], o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) red[threadIdx.x >> 6][e] = acc[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double G[3][3], gT[3];
+        for (int e = 0; e < 12; ++e) {
+            double v = 0.0;
+            for (int w = 0; w < 16; ++w) v += red[w][e];
+            if (e < 9) G[e / 3][e % 3] = v; else gT[e - 9] = v;
+        }
+        const double qr = ct[0], qi = ct[1], qj = ct[2], qk = ct[3];
+        const double nn = qr * qr + qi * qi + qj * qj + qk * qk, s = 2.0 / nn;
+        const double P[3][3] = {{-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr},
+                                {qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr},
+                                {qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)}};
+        double dLds = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) dLds += G[a][b] * P[a][b];
+        const double dr = -qk * G[0][1] + qj * G[0][2] + qk * G[1][0] - qi * G[1][2] - qj * G[2][0] + qi * G[2][1];
+        const double di = qj * G[0][1] + qk * G[0][2] + qj * G[1][0] - 2 * qi * G[1][1] - qr * G[1][2] + qk * G[2][0] +
+                          qr * G[2][1] - 2 * qi * G[2][2];
+        const double dj = -2 * qj * G[0][0] + qi * G[0][1] + qr * G[0][2] + qi * G[1][0] + qk * G[1][2] - qr * G[2][0] +
+                          qk * G[2][1] - 2 * qj * G[2][2];
+        const double dk = -2 * qk * G[0][0] - qr * G[0][1] + qi * G[0][2] + qr * G[1][0] - 2 * qk * G[1][1] + qj * G[1][2] +
+                          qi * G[2][0] + qj * G[2][1];
+        const double ds = -s * s;                       // ds/dq_x = ds * q_x
+        g_ct[0] = (float)(s * dr + dLds * ds * qr);
+        g_ct[1] = (float)(s * di + dLds * ds * qi);
+        g_ct[2] = (float)(s * dj + dLds * ds * qj);
+        g_ct[3] = (float)(s * dk + dLds * ds * qk);
+        g_ct[4] = (float)gT[0]; g_ct[5] = (float)gT[1]; g_ct[6] = (float)gT[2];
+    }
+}
 __global__ __launch_bounds__(256) void rgbd_loss_bwd_kernel(int n, const double* __restrict__ depth,
                                                             const float* __restrict__ color,
                                                             const float* __restrict__ gd, const float* __restrict__ gc,
@@ -476,6 +616,27 @@ int ens_launch_rgbd_loss(int n, const double* depth, const float* color, const f
         rgbd_loss_fwd_kernel<<<1, 1024, 0, st>>>(n, depth, color, gd, gc, w, loss);
     } else if (n > 0) {
         rgbd_loss_bwd_kernel<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(n, depth, color, gd, gc, w, g_loss, g_depth, g_color);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_tracker_loss(int n, const double* depth, const double* unc, const float* color, const float* gd,
+                            const float* gc, float w, const double* g_loss, double* loss, double* g_depth, float* g_color,
+                            hipStream_t st) {
+    if (g_loss == nullptr) {
+        tracker_loss_fwd_kernel<<<1, 1024, 0, st>>>(n, depth, unc, color, gd, gc, w, loss);
+    } else if (n > 0) {
+        tracker_loss_bwd_kernel<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(n, depth, unc, color, gd, gc, w, g_loss, g_depth, g_color);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_pose_rays(int n, const float* ct, const float* pi, const float* pj, float fx, float fy, float cx, float cy,
+                         const float* g_ro, const float* g_rd, float* ro, float* rd, float* g_ct, hipStream_t st) {
+    if (g_ct == nullptr) {
+        if (n > 0) pose_rays_fwd_kernel<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(n, ct, pi, pj, fx, fy, cx, cy, ro, rd);
+    } else {
+        pose_rays_bwd_kernel<<<1, 1024, 0, st>>>(n, ct, pi, pj, fx, fy, cx, cy, g_ro, g_rd, g_ct);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -399,12 +399,18 @@ class _RenderFn(torch.autograd.Function):
         # arrive in the device layout (plan.vm) need none of this.
         vmg = plan.vm
         dims = {k: (vmg[k].dims if k in vmg else tuple(g.shape[2:])) for k, g in zip(plan.kinds, grids)}
-        dense = [(i, k) for i, k in enumerate(plan.kinds) if k not in vmg]
+        # grids without gradient (tracker, render_img, Mesher): one full conversion per grid version, cached -- the map
+        # does not change between the camera iterations of a frame, so nothing is marked or converted per call
+        static = [(i, k) for i, k in enumerate(plan.kinds) if k not in vmg and not ctx.needs_input_grad[5 + i]]
+        dense = [(i, k) for i, k in enumerate(plan.kinds) if k not in vmg and ctx.needs_input_grad[5 + i]]
         nblk = [(dims[k][0] * dims[k][1] * dims[k][2] + 63) // 64 for _, k in dense]
         arena = _ZeroArena(dev, 2 * sum(nblk) + 4 * sum(lib.enslam_packed_floats(k) for k in plan.kinds) + 256)
         flags = [None] * nk
         grids_vm, packed = {k: vmg[k].vm for k in vmg}, {}
         _last_flags.clear()
+        if static:
+            for (i, k), vm in zip(static, _grid_cache.get_many([grids[i] for i, _ in static])):
+                grids_vm[k] = vm
         if dense:
             flag_buf = arena.take(sum(nblk), torch.uint8)
             fptr = (ctypes.c_void_p * 4)()

@@ -126,6 +126,25 @@ int enslam_grids_convert_sparse(int32_t n, const float *const *src, float *const
 int enslam_zero_blocks(int32_t n, float *const *dst, const int64_t *n_voxels, const uint8_t *const *need,
                        float *flat, int64_t n_flat, void *stream);
 
+/* Tracker glue (RGB-D part).
+ * enslam_pose_rays_fwd: camera tensor float32 [7] = (qr,qi,qj,qk, tx,ty,tz), pixels (pix_i = column, pix_j = row,
+ *   float32 [n]) -> rays_o, rays_d float32 [n,3]: quad2rotation + get_camera_from_tensor (common.py:189-229) and
+ *   get_rays_from_uv (:74-89) in one launch.  enslam_pose_rays_bwd: ray gradients (either may be NULL) ->
+ *   g_camera_tensor float32 [7] (written, not accumulated); one workgroup, float64 sums, deterministic.
+ * enslam_tracker_loss_fwd/bwd: Tracker.py:179-195 with handle_dynamic off:
+ *   sum_{gt_depth>0} |gt_depth - depth| / sqrt(uncertainty + 1e-10)  +  w_color * sum_{gt_depth>0} |gt_color - color|
+ *   (colour term when color/gt_color are given); the uncertainty carries no gradient (:179). */
+int enslam_pose_rays_fwd(int32_t n, const float *camera_tensor, const float *pix_i, const float *pix_j, float fx,
+                         float fy, float cx, float cy, float *rays_o, float *rays_d, void *stream);
+int enslam_pose_rays_bwd(int32_t n, const float *camera_tensor, const float *pix_i, const float *pix_j, float fx,
+                         float fy, float cx, float cy, const float *g_rays_o, const float *g_rays_d,
+                         float *g_camera_tensor, void *stream);
+int enslam_tracker_loss_fwd(int32_t n, const double *depth, const double *uncertainty, const float *color,
+                            const float *gt_depth, const float *gt_color, float w_color, double *loss, void *stream);
+int enslam_tracker_loss_bwd(int32_t n, const double *depth, const double *uncertainty, const float *color,
+                            const float *gt_depth, const float *gt_color, float w_color, const double *g_loss,
+                            double *g_depth, float *g_color, void *stream);
+
 /* Mapper glue.  torch.optim.Adam (defaults) on voxel-major grids [V,32], restricted to the voxels whose
  * mask byte is 1 -- how Mapper.optimize_map optimises val_grad = val[mask] (Mapper.py:328-361, 573-575) without the
  * val[mask] = val_grad re-materialisation (:448-458, :596-602).  Per grid i: param / grad / exp_avg / exp_avg_sq are

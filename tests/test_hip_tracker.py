@@ -52,3 +52,41 @@ def test_pose_gradient_matches_reference_fixture():
     finally:
         for p in model.parameters():
             p.requires_grad_(True)
+
+
+def test_fused_pose_rays_and_loss_match_torch_route():
+    """tracker.rays_from_camera_tensor / losses.tracker_loss against the plain-torch formulation of the same
+    statements (common.get_camera_from_tensor + get_rays_from_uv; Tracker.py:187-195), values and gradients."""
+    import evennicer_slam_amd as E
+    from tests.hip_util import DEV
+    g = torch.Generator().manual_seed(3)
+    n = 300
+    i = (torch.rand(n, generator=g) * 1199).floor().to(DEV)
+    j = (torch.rand(n, generator=g) * 679).floor().to(DEV)
+    fx, fy, cx, cy = 600.0, 600.0, 599.5, 339.5
+    ct0 = torch.tensor([0.7, -0.2, 0.6, 0.1, 3.0, 1.0, -0.5])
+    cot_o, cot_d = torch.randn(n, 3, generator=g).to(DEV), torch.randn(n, 3, generator=g).to(DEV)
+    a = ct0.clone().to(DEV).requires_grad_(True)
+    ro, rd = E.tracker.rays_from_camera_tensor(a, i, j, fx, fy, cx, cy)
+    ((ro * cot_o).sum() + (rd * cot_d).sum()).backward()
+    b = ct0.clone().to(DEV).requires_grad_(True)
+    ro2, rd2 = E.common.get_rays_from_uv(i, j, E.common.get_camera_from_tensor(b), 680, 1200, fx, fy, cx, cy, DEV)
+    ((ro2 * cot_o).sum() + (rd2 * cot_d).sum()).backward()
+    assert float((rd - rd2).abs().max()) <= 2e-6 and torch.equal(ro, ro2.contiguous())
+    assert float((a.grad - b.grad).abs().max()) <= 1e-4 * float(b.grad.abs().max())
+    # loss
+    depth = (torch.rand(n, generator=g).double() * 3).to(DEV).requires_grad_(True)
+    unc = (torch.rand(n, generator=g).double() * 0.1).to(DEV)
+    color = torch.rand(n, 3, generator=g).to(DEV).requires_grad_(True)
+    gd = (torch.rand(n, generator=g) * 3).to(DEV)
+    gd[::7] = 0.0
+    gc = torch.rand(n, 3, generator=g).to(DEV)
+    loss = E.losses.tracker_loss(depth, unc, color, gd, gc, 0.5)
+    loss.backward()
+    d2, c2 = depth.detach().clone().requires_grad_(True), color.detach().clone().requires_grad_(True)
+    mask = gd > 0
+    ref = (torch.abs(gd - d2) / torch.sqrt(unc + 1e-10))[mask].sum() + 0.5 * torch.abs(gc - c2)[mask].sum()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())
+    assert float((depth.grad - d2.grad).abs().max()) <= 1e-9 * float(d2.grad.abs().max())
+    assert torch.equal(color.grad, c2.grad)

@@ -24,15 +24,21 @@ color_img = torch.rand(H, W, 3, generator=g).to(dev)
 ct = torch.tensor([1.0, 0.0, 0.0, 0.0, 3.0, 1.0, 0.0], device=dev, requires_grad=True)
 opt = FusedAdam([ct], lr=1e-3)
 edge = 100
+FUSED = os.environ.get('FUSED', '1') == '1'
 one = {}
 
 def it():
     opt.zero_grad()
-    c2w = E.common.get_camera_from_tensor(ct)
-    ro, rd, gd, gc = E.common.get_samples(edge, H - edge, edge, W - edge, N, H, W, fx, fy, cx, cy, c2w, depth_img, color_img, dev)
-    depth, unc, color = renderer.render_batch_ray(grids, model, rd, ro, dev, 'color', gt_depth=gd)
-    m = (gd > 0).to(depth.dtype)
-    loss = (torch.abs(gd - depth) / torch.sqrt(unc.detach() + 1e-10) * m).sum() + 0.5 * (torch.abs(gc - color) * m[:, None].float()).sum()
+    if FUSED:
+        ro, rd, gd, gc = E.tracker.get_samples_from_camera_tensor(edge, H - edge, edge, W - edge, N, H, W, fx, fy, cx, cy, ct, depth_img, color_img, dev)
+        depth, unc, color = renderer.render_batch_ray(grids, model, rd, ro, dev, 'color', gt_depth=gd)
+        loss = E.losses.tracker_loss(depth, unc, color, gd, gc, 0.5)
+    else:
+        c2w = E.common.get_camera_from_tensor(ct)
+        ro, rd, gd, gc = E.common.get_samples(edge, H - edge, edge, W - edge, N, H, W, fx, fy, cx, cy, c2w, depth_img, color_img, dev)
+        depth, unc, color = renderer.render_batch_ray(grids, model, rd, ro, dev, 'color', gt_depth=gd)
+        m = (gd > 0).to(depth.dtype)
+        loss = (torch.abs(gd - depth) / torch.sqrt(unc.detach() + 1e-10) * m).sum() + 0.5 * (torch.abs(gc - color) * m[:, None].float()).sum()
     if 'one' not in one: one['one'] = torch.ones_like(loss)
     loss.backward(gradient=one['one'])
     opt.step()
@@ -53,4 +59,4 @@ opt.zero_grad()
 import gc as _gc; _gc.collect()
 gs = GraphedStep(it)
 tg, loss = timed(gs.replay, int(os.environ.get('STEPS', 200)))
-print(f"tracker iteration, room0, {N} rays x 48, colour stage: eager {te * 1e6:.1f} us, hipGraph {tg * 1e6:.1f} us/iter ({N / tg / 1e6:.2f} M rays/s), loss {float(loss.item()):.3f}")
+print(f"tracker iteration ({'fused pose/loss glue' if FUSED else 'torch pose/loss glue'}), room0, {N} rays x 48, colour stage: eager {te * 1e6:.1f} us, hipGraph {tg * 1e6:.1f} us/iter ({N / tg / 1e6:.2f} M rays/s), loss {float(loss.item()):.3f}")
