@@ -91,6 +91,45 @@ def test_no_surface_samples_32(tiny):
         p_.grad = None
 
 
+@pytest.mark.parametrize("n_samples,n_surface,stage", [(32, 0, "color"), (16, 0, "color"), (16, 16, "fine"), (16, 0, "middle")])
+def test_other_sample_counts_forward_and_backward(tiny, n_samples, n_surface, stage):
+    """S = 32 and S = 16 (2 and 1 tiles per ray): outputs and every gradient against the oracle."""
+    from tests.hip_util import cfg_like, renderer_for
+    s, bound, model, grids, rays, renderer = tiny
+    params, ogrids, obound, _ = tiny_scene()
+    r = renderer_for(bound, cfg=cfg_like(n_samples, n_surface))
+    for p_ in model.parameters():
+        p_.grad = None
+    cg = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+    gro, grd = rays['rays_o'].clone().requires_grad_(True), rays['rays_d'].clone().requires_grad_(True)
+    d, v, c = r.render_batch_ray(cg, model, grd, gro, 'cuda:0', stage, gt_depth=rays['gt_depth'])
+    (d.sum() + 0.5 * v.sum() + c.sum()).backward()
+    op = {k: t.clone().requires_grad_(True) for k, t in params.items()}
+    og = {k: t.clone().requires_grad_(True) for k, t in ogrids.items()}
+    ro, rd, gd = [torch.from_numpy(s[k]) for k in ("rays_o", "rays_d", "gt_depth")]
+    oro, ord_ = ro.clone().requires_grad_(True), rd.clone().requires_grad_(True)
+    d0, v0, c0 = R.render_batch_ray(op, og, ord_, oro, stage, obound, gt_depth=gd, n_samples=n_samples, n_surface=n_surface)
+    (d0.sum() + 0.5 * v0.sum() + c0.sum()).backward()
+    assert rel_err(d.detach().cpu().numpy(), d0.detach().numpy()) < 1e-4
+    assert rel_err(v.detach().cpu().numpy(), v0.detach().numpy()) < 1e-4
+    assert rel_err(c.detach().cpu().numpy(), c0.detach().numpy()) < 1e-4
+    assert rel_err(grd.grad.cpu().numpy(), ord_.grad.numpy()) < 1e-3
+    assert rel_err(gro.grad.cpu().numpy(), oro.grad.numpy()) < 1e-3
+    checked = 0
+    for k in og:
+        if og[k].grad is not None and float(og[k].grad.abs().max()) > 0:
+            assert rel_err(cg[k].grad.cpu().numpy(), og[k].grad.numpy()) < 1e-3, k
+            checked += 1
+    for name, p_ in model.named_parameters():
+        ref = op[name].grad
+        if ref is not None and float(ref.abs().max()) > 0:
+            assert rel_err(p_.grad.cpu().numpy(), ref.numpy()) < 1e-3, name
+            checked += 1
+    assert checked >= 10
+    for p_ in model.parameters():
+        p_.grad = None
+
+
 def test_points_on_grid_borders_and_outside(tiny):
     """eval_points on the bound's faces, corners and far outside: border clamp + occ = 100 mask, as the oracle."""
     s, bound, model, grids, rays, renderer = tiny
