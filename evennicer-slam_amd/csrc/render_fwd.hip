@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "lds_util.hpp"
+#include "stamps.hpp"
 
 #define IC(n) std::integral_constant<int, n>{}
 
@@ -21,6 +22,9 @@ ENS_DEV unsigned fwd_pos_bits(const f32x4& v) {
 // Write one register tile to the workspace in the backward's deposit layout: transpose through a wave-private
 // 1 KB LDS tile, then one coalesced 16-byte store per lane.
 ENS_DEV void ws_store_dep(float* __restrict__ ws_tile, const f32x4& x, float* stage, int lane, int p, int q) {
+    // (storing component-major [r][lane] with plain dword stores and turning the tile in the backward's
+    // global_load_lds by addressing was tried: forward -2.6 us, backward +10 us -- the strided 16-byte source runs cost
+    // more than the LDS round trip here, which other waves hide)
     float* d = stage + (p >> 2) * 64 + (p & 3) + 16 * q;
 #pragma unroll
     for (int r = 0; r < 4; ++r) d[4 * r] = x[r];
@@ -349,7 +353,7 @@ constexpr int fwd_ring_lds_bytes(int stage) { return (2 * fwd_ring_floats(stage)
 template <int CT, int C0, int RB, int NEXT_CD>
 ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict__ pk_next, float* ring, float pc,
                           const f32x4 (&c)[CT], f32x4& o, float* ws, bool wl, float* stage, unsigned w32, unsigned w96,
-                          unsigned w128, unsigned wcd, unsigned wq, int wave, int lane, int p, int q) {
+                          unsigned w128, unsigned wcd, unsigned wq, int wave, int lane, int p, int q, StampCtx& sx) {
     constexpr XyzLay L{CT * 16};
     constexpr int CD = CT * 16;
     f32x4 emb[6];
@@ -358,6 +362,7 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
         const float a = pk[L.oBT() + (16 * t + p) * 4 + q];
         emb[t] = sin4(MFMA16(a, pc, splat4(0.f)));
     }
+    FST(sx, 1)      // embedding: B^T loads, MFMA, sin
     if (ws != nullptr) {
         if (!wl) {
 #pragma unroll
@@ -368,6 +373,7 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
         const float cx = __shfl(pc, p), cy = __shfl(pc, 16 + p), cz = __shfl(pc, 32 + p);
         ws_store_dep(ws + (wl ? ACTL_Q : (14 + CT) * 256), q == 0 ? f32x4{cx, cy, cz, 0.f} : splat4(0.f), stage, lane, p, q);
     }
+    FST(sx, 2)      // workspace stores of emb / c / coordinates
     f32x4 h[5][2];
     unsigned mb0 = 0u, mb1 = 0u;
     auto layer = [&](auto ic) {
@@ -400,6 +406,7 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
         lin_lds<2, CT, CD, OC>(acc, wcd, c);
         h[i][0] = acc[0];
         h[i][1] = acc[1];
+        FST(sx, 3)  // layer: prefetch issue, bias, fragment reads + MFMAs, relu
         if (ws != nullptr) {
             constexpr int T = i == 2 ? 6 : (i == 0 ? 8 : (i == 1 ? 10 : 12));
             if constexpr (i < 4) {
@@ -415,7 +422,9 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
                 *reinterpret_cast<uint2*>(ws + (wl ? ACTL_MASK : ACT_MASK) + lane * 2) = make_uint2(mb0, mb1);
             }
         }
+        FST(sx, 4)  // workspace stores of h
         __syncthreads();                // next chunk landed; all waves done with this buffer
+        FST(sx, 5)  // barrier (+ wait for the next chunk)
     };
     layer(IC(0)); layer(IC(1)); layer(IC(2)); layer(IC(3)); layer(IC(4));
     // output layer (tiny): weights straight from global
@@ -424,6 +433,7 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
     hh[0][1] = h[4][1];
     out_layer<1>(oo, pk + L.oWo(), pk + L.obo(), hh, p, q);
     o = oo[0];
+    FST(sx, 6)      // output layer (weights from global)
 }
 
 template <int STAGE>
@@ -435,6 +445,8 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     const bool wl = wli != 0;
     const int WSS = wl ? ACTL_STRIDE : ACT_STRIDE, WSV = wl ? ACTL_VOX : ACT_VOX;
+    StampCtx sx;
+    FST_INIT(sx)
     constexpr int RB = fwd_ring_floats(STAGE);
     float* ring = fsm;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
@@ -472,9 +484,11 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
         gather8(v, sc.grid[1], q, cm[0], cm[1]);
         if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + WSV + p * 4) = vox_record(v, sc.grid[1]);
     }
+    FST(sx, 0)      // geometry + first gather
     __syncthreads();                                                                   // chunk 0 landed
+    FST(sx, 5)
     mlp_xyz_ring<2, 0, RB, (STAGE >= 2 ? 64 : 0)>(sc.packed[1], STAGE >= 2 ? sc.packed[2] : nullptr, ring, pc, cm, occ, wsb,
-                                                   wl, stage, w32, w96, w128, w32, wq, wave, lane, p, q);
+                                                   wl, stage, w32, w96, w128, w32, wq, wave, lane, p, q, sx);
     if constexpr (STAGE >= 2) {
         f32x4 cf[4];
         {
@@ -484,10 +498,11 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
         }
         cf[2] = cm[0];
         cf[3] = cm[1];
+        FST(sx, 7)  // later gathers
         f32x4 of;
         mlp_xyz_ring<4, 5, RB, (STAGE == 3 ? 32 : 0)>(sc.packed[2], STAGE == 3 ? sc.packed[3] : nullptr, ring, pc, cf, of,
                                                       wsb ? wsb + WSS : nullptr, wl, stage, w32, w96, w128, w64, wq, wave,
-                                                      lane, p, q);
+                                                      lane, p, q, sx);
         occ[0] = of[0] + occ[0];                                                        // fine_occ + middle_occ
     }
     if constexpr (STAGE == 3) {
@@ -497,14 +512,26 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
             gather8(v, sc.grid[3], q, cc[0], cc[1]);
             if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + 2 * WSS + WSV + p * 4) = vox_record(v, sc.grid[3]);
         }
+        FST(sx, 7)
         mlp_xyz_ring<2, 10, RB, 0>(sc.packed[3], nullptr, ring, pc, cc, col, wsb ? wsb + 2 * WSS : nullptr, wl, stage,
-                                   w32, w96, w128, w32, wq, wave, lane, p, q);
+                                   w32, w96, w128, w32, wq, wave, lane, p, q, sx);
     }
     if (q == 0 && tvalid) {                                                             // rows 0..3 live on q == 0 lanes
         const float o = inb ? occ[0] : 100.f;                                           // Renderer.py:58
         *reinterpret_cast<f32x4*>(raw_out + sidx * 4) = f32x4{col[0], col[1], col[2], o};
     }
+    FST(sx, 8)
+    FST_FLUSH(sx, blockIdx.x, wave, lane)
 }
+
+#ifdef ENS_STAMPS
+}  // namespace
+extern "C" int enslam_debug_set_stamp_buffer_fwd(void* p) {
+    unsigned long long* v = (unsigned long long*)p;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &v, sizeof(v)) == hipSuccess ? 0 : -2;
+}
+namespace {
+#endif
 
 // raw2outputs_nerf_color on its own (common.py:256-297, occupancy branch): one wave per ray.
 __global__ __launch_bounds__(64) void composite_fwd_kernel(int S, const float* __restrict__ raw,
