@@ -254,7 +254,22 @@ ENS_DEV void ens_sincosf(float x, float& s, float& c) {
     s = (n & 2) ? -ss : ss;
     c = ((n + 1) & 2) ? -cc : cc;
 }
-ENS_DEV float ens_sinf(float x) { float s, c; ens_sincosf(x, s, c); return s; }
+// sin alone: the same reduction and the same two polynomials, but only the one the quadrant selects is evaluated
+// (coefficients chosen by n & 1) -- bit-identical to the s of ens_sincosf.
+ENS_DEV float ens_sinf(float x) {
+    const double xd = (double)x;
+    const double k = rint(xd * 0.63661977236758134308);
+    const float r = (float)fma(-k, 1.57079632679489661923, xd);
+    const int n = (int)k;
+    const bool odd = n & 1;
+    const float z = r * r;
+    const float k3 = odd ? 2.443315711809948e-5f : -1.9515295891e-4f;
+    const float k2 = odd ? -1.388731625493765e-3f : 8.3321608736e-3f;
+    const float k1 = odd ? 4.166664568298827e-2f : -1.6666654611e-1f;
+    const float t = fmaf(fmaf(k3, z, k2), z, k1) * z;
+    const float v = fmaf(t, odd ? z : r, odd ? fmaf(-0.5f, z, 1.f) : r);
+    return (n & 2) ? -v : v;
+}
 
 // wave-wide helpers (64 lanes)
 ENS_DEV float wave_sum(float v) {
