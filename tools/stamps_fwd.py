@@ -1,4 +1,5 @@
-"""Run the stamps build of the forward ring kernel and print the share of wave cycles per segment."""
+"""(make -C evennicer-slam_amd/csrc stamps; ENSLAM_LIB=build/exp/libexp_stamps.so python tools/stamps_fwd.py)
+Run the stamps build of the forward ring kernel and print the share of wave cycles per segment."""
 import ctypes, os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
