@@ -168,7 +168,12 @@ def packed_decoders(items, arena=None):
                 torch.zeros(sum(sizes), dtype=torch.float32, device=items[stale[0][0]][2][0].device))
         pieces = flat.split(sizes)
         for j, (i, cache, key) in enumerate(stale):
-            _check_params(items[i][1], items[i][2])
+            # an optimiser step changes versions, not storage: the shape checks and the pointer struct of unchanged
+            # storages are reused (they are half of the host cost of a re-pack)
+            where = tuple(k[:2] for k in key)
+            if where != getattr(cache, 'where', None):
+                _check_params(items[i][1], items[i][2])
+                cache.where, cache.struct = where, _fill_params_struct(items[i][1], items[i][2])
             cache.key, cache.packed = key, pieces[j]
             out[i] = pieces[j]
         for g0 in range(0, len(stale), 3):
@@ -177,7 +182,7 @@ def packed_decoders(items, arena=None):
             kinds, structs, ptrs = (ctypes.c_int32 * n)(), (L.MlpParams * n)(), (ctypes.c_void_p * n)()
             for j, (i, cache, key) in enumerate(grp):
                 kinds[j] = items[i][1]
-                structs[j] = _fill_params_struct(items[i][1], items[i][2])
+                structs[j] = cache.struct
                 ptrs[j] = cache.packed.data_ptr()
             L.check(lib.enslam_pack_mlp_multi(n, kinds, structs, ptrs, _stream()), "enslam_pack_mlp_multi")
     return out

@@ -18,7 +18,7 @@ def step():
     for t in leaves: t.grad = None
     ro.grad = None; rd.grad = None
     d, v, c = renderer.render_batch_ray(grids, model, rd, ro, dev, 'color', gt_depth=gd)
-    bench.mapper_loss(d, c, gd, gc, 'color').backward()
+    E.losses.rgbd_loss(d, c, gd, gc, 0.2).backward()
 for _ in range(20): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
