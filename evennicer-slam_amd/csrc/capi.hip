@@ -328,13 +328,20 @@ int enslam_grid_from_voxel_major(const float* src, float* dst, int64_t n_voxels,
 int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const float* rays_o, const float* rays_d,
                        const float* gt_depth, const double* bound_host, const float* t_lin, const double* t_surf,
                        int32_t lindisp, const float* t_rand, float* scratch, int32_t depth_max_given, double* z_vals,
-                       void* stream) {
+                       int32_t mark_stage, const enslam_scene* mark_scene, uint8_t* const* mark_flags, void* stream) {
     if (n_rays < 0 || n_lin < 1 || n_surf < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (!rays_o || !rays_d || !bound_host || !t_lin || !z_vals) return ENSLAM_EINVAL;
     if (gt_depth != nullptr && (scratch == nullptr || (n_surf > 0 && t_surf == nullptr))) return ENSLAM_EINVAL;
+    MarkArgs mk;
+    const bool marking = mark_scene != nullptr && mark_flags != nullptr;
+    if (marking) {
+        if (mark_stage < 0 || mark_stage > 3 || !to_dev_scene(mark_scene, mk.sc)) return ENSLAM_EINVAL;
+        mk.kmask = mark_stage == 0 ? 1 : (mark_stage == 1 ? 2 : (mark_stage == 2 ? 6 : 14));
+        for (int k = 0; k < 4; ++k) mk.flags[k] = mark_flags[k];
+    }
     return ens_launch_sample(n_rays, n_lin, n_surf, rays_o, rays_d, gt_depth, bound_host, t_lin, t_surf, lindisp,
-                             t_rand, scratch, depth_max_given, z_vals, (hipStream_t)stream);
+                             t_rand, scratch, depth_max_given, z_vals, marking ? &mk : nullptr, (hipStream_t)stream);
 }
 
 int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,

@@ -69,9 +69,14 @@ int ens_launch_adam_tensors(const AdamTensorsJob& job, hipStream_t st);
 int ens_launch_zero_blocks(const ConvJob& job, float* flat, int64_t n_flat, hipStream_t st);
 int ens_launch_mark_blocks(int stage, int n_rays, int S, const float* ro, const float* rd, const double* z,
                            const DevScene& sc, uint8_t* const* flags, hipStream_t st);
+struct MarkArgs {                // optional block marking inside the sampler (mark_blocks_kernel's work, one launch less)
+    DevScene sc;                 // bounds and grid dims (data pointers unused)
+    int kmask;                   // grids to mark (bit k)
+    uint8_t* flags[4];
+};
 int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
                       const double* bound, const float* t_lin, const double* t_surf, int lindisp,
-                      const float* t_rand, float* scratch, int dmax_given, double* z, hipStream_t st);
+                      const float* t_rand, float* scratch, int dmax_given, double* z, const MarkArgs* mark, hipStream_t st);
 int ens_launch_rgbd_loss(int n, const double* depth, const float* color, const float* gd, const float* gc, float w,
                          const double* g_loss, double* loss, double* g_depth, float* g_color, hipStream_t st);
 int ens_launch_ray_points(int n_rays, int S, const float* ro, const float* rd, const double* z, const double* bound,

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
                                                      const double* __restrict__ t_surf, int lindisp,
                                                      const float* __restrict__ t_rand,
                                                      const float* __restrict__ dmax, int dmax_inline,
-                                                     double* __restrict__ zout) {
+                                                     double* __restrict__ zout, MarkArgs mk) {
     const int ray = blockIdx.x, lane = threadIdx.x;
     float dmax0 = 0.f, dmax1 = 0.f;                     // max(gt_depth) over the batch and fl32(max * 1.2f)
     if (gd != nullptr) {
@@ -108,7 +108,25 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
             }
         }
     }
-    if (lane < S) zout[(int64_t)ray * S + lane] = z;
+    if (lane < S) {
+        zout[(int64_t)ray * S + lane] = z;
+        if (mk.kmask) {                                  // flag the 64-voxel blocks this sample's 8 corners sit in
+            double pw[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pw[a] = (double)ro[ray * 3 + a] + (double)rd[ray * 3 + a] * z;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!((mk.kmask >> k) & 1) || mk.flags[k] == nullptr) continue;
+                const Vox v = make_vox(pw, k == 0 ? mk.sc.clo : mk.sc.lo, k == 0 ? mk.sc.chi : mk.sc.hi, mk.sc.grid[k]);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    int64_t idx; float w;
+                    corner(v, mk.sc.grid[k], c, idx, w);
+                    mk.flags[k][idx >> 6] = 1;
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ mapper RGB-D loss (Mapper.py:553-562)
@@ -599,14 +617,16 @@ int ens_launch_mark_blocks(int stage, int n_rays, int S, const float* ro, const 
 
 int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
                       const double* b, const float* t_lin, const double* t_surf, int lindisp, const float* t_rand,
-                      float* scratch, int dmax_given, double* z, hipStream_t st) {
+                      float* scratch, int dmax_given, double* z, const MarkArgs* mark, hipStream_t st) {
     if (n_rays <= 0) return 0;
     if (n_lin + n_surf > MAX_S || n_lin < 1) return -1;
     const int dmax_inline = (gd != nullptr && !dmax_given && n_rays <= 4096) ? 1 : 0;
+    MarkArgs mk;
+    if (mark != nullptr) mk = *mark; else { mk.kmask = 0; for (int k = 0; k < 4; ++k) mk.flags[k] = nullptr; }
     if (gd != nullptr && !dmax_given && !dmax_inline) depth_max_kernel<<<1, 1024, 0, st>>>(n_rays, gd, scratch);
     sample_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(n_rays, n_lin, gd ? n_surf : 0, ro, rd, gd, b[0], b[1],
                                                                  b[2], b[3], b[4], b[5], t_lin, t_surf, lindisp,
-                                                                 t_rand, scratch, dmax_inline, z);
+                                                                 t_rand, scratch, dmax_inline, z, mk);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -396,10 +396,6 @@ class _RenderFn(torch.autograd.Function):
         gd = gt_depth.detach().contiguous().float().reshape(-1) if gt_depth is not None else None
         z = torch.empty((N, S), dtype=torch.float64, device=dev)
         scratch = plan.depth_max if plan.depth_max is not None else torch.empty(2, dtype=torch.float32, device=dev)
-        L.check(lib.enslam_sample_rays(N, plan.n_lin, plan.n_surf, _ptr(ro), _ptr(rd), _ptr(gd), plan.bound6,
-                                       _ptr(plan.t_lin), _ptr(plan.t_surf), plan.lindisp, _ptr(t_rand),
-                                       _ptr(scratch), int(plan.depth_max is not None), _ptr(z), st),
-                "enslam_sample_rays")
         # blocks of 64 voxels this batch touches, per grid (one zeroed byte buffer for all grids).  Grids that
         # arrive in the device layout (plan.vm) need none of this.
         vmg = plan.vm
@@ -413,10 +409,8 @@ class _RenderFn(torch.autograd.Function):
         flags = [None] * nk
         grids_vm, packed = {k: vmg[k].vm for k in vmg}, {}
         _last_flags.clear()
-        if static:
-            for (i, k), vm in zip(static, _grid_cache.get_many([grids[i] for i, _ in static])):
-                grids_vm[k] = vm
-        if dense:
+        msc, fptr = None, None
+        if dense:                       # the sampler marks the blocks of the samples it places
             flag_buf = arena.take(sum(nblk), torch.uint8)
             fptr = (ctypes.c_void_p * 4)()
             msc = L.Scene()
@@ -426,8 +420,15 @@ class _RenderFn(torch.autograd.Function):
                 fptr[k] = fl.data_ptr()
                 msc.grids[k].D, msc.grids[k].H, msc.grids[k].W = dims[k]
                 _last_flags[id(grids[i])] = fl
-            L.check(lib.enslam_mark_blocks(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(msc), fptr, st),
-                    "enslam_mark_blocks")
+        L.check(lib.enslam_sample_rays(N, plan.n_lin, plan.n_surf, _ptr(ro), _ptr(rd), _ptr(gd), plan.bound6,
+                                       _ptr(plan.t_lin), _ptr(plan.t_surf), plan.lindisp, _ptr(t_rand),
+                                       _ptr(scratch), int(plan.depth_max is not None), _ptr(z), L.STAGE[plan.stage],
+                                       ctypes.byref(msc) if msc is not None else None, fptr, st),
+                "enslam_sample_rays")
+        if static:
+            for (i, k), vm in zip(static, _grid_cache.get_many([grids[i] for i, _ in static])):
+                grids_vm[k] = vm
+        if dense:
             dense_grids = [grids[i] for i, _ in dense]
             for (i, k), vm in zip(dense, _grid_cache.get_many_sparse(dense_grids, [flags[i] for i, _ in dense], arena)):
                 grids_vm[k] = vm
@@ -670,7 +671,7 @@ def sample_rays(rays_o, rays_d, gt_depth, bound, n_lin, n_surf, lindisp=False, t
     L.check(lib.enslam_sample_rays(N, n_lin, n_surf, _ptr(rays_o.contiguous().float()),
                                    _ptr(rays_d.contiguous().float()), _ptr(gd), bound6(bound), _ptr(t_lin),
                                    _ptr(t_surf), int(bool(lindisp)), _ptr(t_rand), _ptr(scratch),
-                                   int(depth_max is not None), _ptr(z), _stream()), "enslam_sample_rays")
+                                   int(depth_max is not None), _ptr(z), 0, None, None, _stream()), "enslam_sample_rays")
     return z
 
 

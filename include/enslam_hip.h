@@ -162,7 +162,9 @@ int enslam_adam_tensors(int32_t n, float *const *param, const float *const *grad
                         float *const *exp_avg_sq, const int64_t *numel, const double *lr, const int32_t *step,
                         double beta1, double beta2, double eps, void *stream);
 
-/* Sample distances along rays.  Replaces Renderer.render_batch_ray lines 83-171
+/* Sample distances along rays (mark_scene / mark_flags non-NULL: also does enslam_mark_blocks' work for stage mark_stage
+ * on the samples it has just placed -- one launch less per render call).
+ *   Replaces Renderer.render_batch_ray lines 83-171
  * (src/utils/Renderer.py): near/far from gt_depth and the AABB exit, n_lin linear samples,
  * n_surf near-surface samples (gt_depth>0: [0.95d,1.05d]; else [0.001,max d]), ascending merge.
  *   t_lin   float32 [n_lin]  = torch.linspace(0,1,n_lin)
@@ -177,7 +179,7 @@ int enslam_adam_tensors(int32_t n, float *const *param, const float *const *grad
 int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const float *rays_o, const float *rays_d,
                        const float *gt_depth, const double *bound_host, const float *t_lin, const double *t_surf,
                        int32_t lindisp, const float *t_rand, float *scratch, int32_t depth_max_given, double *z_vals,
-                       void *stream);
+                       int32_t mark_stage, const enslam_scene *mark_scene, uint8_t *const *mark_flags, void *stream);
 
 /* Forward of Renderer.render_batch_ray lines 173-181 + eval_points (Renderer.py:24-62) +
  * NICE.forward (decoder.py:312-342) + raw2outputs_nerf_color (common.py:256-297, occupancy):
