@@ -9,7 +9,7 @@ bool is_xyz(int kind) { return kind == ENSLAM_MLP_MIDDLE || kind == ENSLAM_MLP_F
 int cdim(int kind) { return kind == ENSLAM_MLP_FINE ? 64 : 32; }
 int nout(int kind) { return kind == ENSLAM_MLP_COLOR ? 4 : 1; }
 
-int g_seg_dec = 0;                  // decoder slot recorded in segments built next (multi-decoder jobs)
+thread_local int g_seg_dec = 0;     // decoder slot recorded in segments built next (multi-decoder jobs)
 
 void add(PackJob& j, float* src, int off, int rows, int cols, int src_ld, int dst_ld, int tr) {
     if (src == nullptr || j.n >= ENS_MAX_SEGS) return;
@@ -194,6 +194,71 @@ bool make_conv_job(int32_t n, const float* const* src, float* const* dst, const 
     return true;
 }
 }  // namespace
+
+namespace {
+void empty_conv_job(ConvJob& job) {
+    job.n = 0;
+    for (int i = 0; i < 4; ++i) { job.src[i] = nullptr; job.dst[i] = nullptr; job.V[i] = 0; job.need[i] = nullptr; job.valid[i] = nullptr; }
+    for (int i = 0; i < 5; ++i) job.block_begin[i] = 0;
+}
+}  // namespace
+
+int enslam_step_prepare(int32_t n_dec, const int32_t* kinds, const enslam_mlp_params* params, float* const* packed,
+                        int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                        const uint8_t* const* need, uint8_t* const* valid, int32_t n_zero, float* const* zero_dst,
+                        const int64_t* zero_voxels, const uint8_t* const* zero_need, float* flat, int64_t n_flat,
+                        void* stream) {
+    if (n_dec < 0 || n_dec > 3 || n_conv < 0 || n_conv > 4 || n_zero < 0 || n_zero > 4 || n_flat < 0 || (n_flat > 0 && !flat))
+        return ENSLAM_EINVAL;
+    PackJob pj;
+    clear_job(pj);
+    if (n_dec > 0 && (!kinds || !params || !packed)) return ENSLAM_EINVAL;
+    for (int i = 0; i < n_dec; ++i) {
+        if (!packed[i]) return ENSLAM_EINVAL;
+        g_seg_dec = i;
+        pj.packed[i] = packed[i];
+        const bool ok = build_job(kinds[i], params[i], true, pj, true);
+        g_seg_dec = 0;
+        if (!ok) return ENSLAM_EINVAL;
+    }
+    ConvJob cj, zj;
+    empty_conv_job(cj);
+    empty_conv_job(zj);
+    if (n_conv > 0) {
+        if (!need) return ENSLAM_EINVAL;
+        for (int i = 0; i < n_conv; ++i)
+            if (!need[i]) return ENSLAM_EINVAL;
+        if (!make_conv_job(n_conv, src, dst, n_voxels, need, valid, true, cj)) return ENSLAM_EINVAL;
+    }
+    if (n_zero > 0 && !make_conv_job(n_zero, nullptr, zero_dst, zero_voxels, zero_need, nullptr, false, zj)) return ENSLAM_EINVAL;
+    return ens_launch_step(pj, false, cj, true, zj, flat, n_flat, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+
+int enslam_step_finish(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                       const uint8_t* const* need, int32_t n_dec, const int32_t* kinds, const float* const* packed_grads,
+                       const enslam_mlp_params* grads, void* stream) {
+    if (n_dec < 0 || n_dec > 4 || n_conv < 0 || n_conv > 4) return ENSLAM_EINVAL;
+    PackJob pj;
+    clear_job(pj);
+    if (n_dec > 0 && (!kinds || !packed_grads || !grads)) return ENSLAM_EINVAL;
+    for (int i = 0; i < n_dec; ++i) {
+        if (!packed_grads[i] || (!is_xyz(kinds[i]) && kinds[i] != ENSLAM_MLP_COARSE)) return ENSLAM_EINVAL;
+        g_seg_dec = i;
+        pj.packed[i] = const_cast<float*>(packed_grads[i]);
+        build_job(kinds[i], grads[i], false, pj, true);
+    }
+    g_seg_dec = 0;
+    ConvJob cj, zj;
+    empty_conv_job(cj);
+    empty_conv_job(zj);
+    if (n_conv > 0) {
+        if (!need) return ENSLAM_EINVAL;
+        for (int i = 0; i < n_conv; ++i)
+            if (!need[i]) return ENSLAM_EINVAL;
+        if (!make_conv_job(n_conv, src, dst, n_voxels, need, nullptr, true, cj)) return ENSLAM_EINVAL;
+    }
+    return ens_launch_step(pj, true, cj, false, zj, nullptr, 0, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
 
 int enslam_grids_convert(int32_t n, const float* const* src, float* const* dst, const int64_t* n_voxels,
                          int32_t to_voxel_major, void* stream) {

@@ -64,6 +64,8 @@ int ens_launch_tracker_loss(int n, const double* depth, const double* unc, const
                             hipStream_t st);
 int ens_launch_pose_rays(int n, const float* ct, const float* pi, const float* pj, float fx, float fy, float cx, float cy,
                          const float* g_ro, const float* g_rd, float* ro, float* rd, float* g_ct, hipStream_t st);
+int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_vm, const ConvJob& zj, float* flat,
+                    int64_t n_flat, hipStream_t st);
 int ens_launch_adam(const AdamJob& job, hipStream_t st);
 int ens_launch_adam_tensors(const AdamTensorsJob& job, hipStream_t st);
 int ens_launch_zero_blocks(const ConvJob& job, float* flat, int64_t n_flat, hipStream_t st);

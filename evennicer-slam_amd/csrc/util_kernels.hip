@@ -351,11 +351,11 @@ __global__ void voxel_index_kernel(int64_t n, const double* __restrict__ pts, do
 ENS_DEV void to_vm_block(const float* __restrict__ src, float* __restrict__ dst, int64_t V, int64_t blk);
 ENS_DEV void from_vm_block(const float* __restrict__ src, float* __restrict__ dst, int64_t V, int64_t blk);
 
-__global__ __launch_bounds__(256) void convert_kernel(ConvJob job, int to_vm) {
+ENS_DEV void convert_body(const ConvJob& job, int to_vm, int b) {
     int g = 0;
 #pragma unroll
-    for (int i = 1; i < 4; ++i) g = (i < job.n && (int)blockIdx.x >= job.block_begin[i]) ? i : g;
-    const int64_t blk = blockIdx.x - job.block_begin[g];
+    for (int i = 1; i < 4; ++i) g = (i < job.n && b >= job.block_begin[i]) ? i : g;
+    const int64_t blk = b - job.block_begin[g];
     const uint8_t* need = job.need[g];
     if (need != nullptr) {                                   // sparse path (block-uniform decisions)
         const bool needed = need[blk] != 0;
@@ -379,23 +379,27 @@ __global__ __launch_bounds__(256) void convert_kernel(ConvJob job, int to_vm) {
     if (to_vm) to_vm_block(job.src[g], job.dst[g], job.V[g], blk);
     else from_vm_block(job.src[g], job.dst[g], job.V[g], blk);
 }
+__global__ __launch_bounds__(256) void convert_kernel(ConvJob job, int to_vm) { convert_body(job, to_vm, (int)blockIdx.x); }
 
 // zero the flagged 64-voxel blocks (8 KB each) of voxel-major buffers
-__global__ __launch_bounds__(256) void zero_blocks_kernel(ConvJob job, float* __restrict__ flat, int64_t n_flat) {
-    if ((int)blockIdx.x >= job.block_begin[job.n]) {    // trailing blocks: a flat float range (2048 floats each)
-        const int64_t e0 = ((int64_t)blockIdx.x - job.block_begin[job.n]) * 2048;
+ENS_DEV void zero_body(const ConvJob& job, float* __restrict__ flat, int64_t n_flat, int b) {
+    if (b >= job.block_begin[job.n]) {                  // trailing blocks: a flat float range (2048 floats each)
+        const int64_t e0 = ((int64_t)b - job.block_begin[job.n]) * 2048;
         for (int64_t e = e0 + threadIdx.x; e < e0 + 2048 && e < n_flat; e += 256) flat[e] = 0.f;
         return;
     }
     int g = 0;
 #pragma unroll
-    for (int i = 1; i < 4; ++i) g = (i < job.n && (int)blockIdx.x >= job.block_begin[i]) ? i : g;
-    const int64_t blk = blockIdx.x - job.block_begin[g];
+    for (int i = 1; i < 4; ++i) g = (i < job.n && b >= job.block_begin[i]) ? i : g;
+    const int64_t blk = b - job.block_begin[g];
     if (job.need[g] != nullptr && job.need[g][blk] == 0) return;
     const int64_t v0 = blk * 64, V = job.V[g];
     f32x4* dst = reinterpret_cast<f32x4*>(job.dst[g] + v0 * 32);
     const int64_t n4 = (V - v0 < 64 ? V - v0 : 64) * 8;
     for (int e = threadIdx.x; e < n4; e += 256) dst[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__global__ __launch_bounds__(256) void zero_blocks_kernel(ConvJob job, float* __restrict__ flat, int64_t n_flat) {
+    zero_body(job, flat, n_flat, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------ masked Adam on voxel-major grids
@@ -552,16 +556,31 @@ ENS_DEV void from_vm_block(const float* __restrict__ src, float* __restrict__ ds
 }
 
 // ------------------------------------------------------------------ decoder re-layout
-__global__ __launch_bounds__(256) void pack_kernel(PackJob job, float* __restrict__ packed, int unpack) {
-    const PackSeg s = job.seg[blockIdx.x];
+ENS_DEV void pack_body(const PackJob& job, float* __restrict__ packed, int unpack, int seg, int y, int ny) {
+    const PackSeg s = job.seg[seg];
     const int n = s.rows * s.cols;
-    for (int e = blockIdx.y * 256 + threadIdx.x; e < n; e += 256 * gridDim.y) {
+    for (int e = y * 256 + threadIdx.x; e < n; e += 256 * ny) {
         const int r = e / s.cols, c = e - r * s.cols;
         float* src = s.src + ((s.transpose & 1) ? (int64_t)c * s.src_ld + r : (int64_t)r * s.src_ld + c);
         const int cs = (s.transpose & 2) ? ((((c >> 2) ^ ((r & 15) >> 1)) << 2) | (c & 3)) : c;   // lds_util.hpp: swizzled image
         float* dst = (job.packed[s.dec] ? job.packed[s.dec] : packed) + s.off + r * s.dst_ld + cs;
         if (unpack) *src = *dst; else *dst = *src;
     }
+}
+__global__ __launch_bounds__(256) void pack_kernel(PackJob job, float* __restrict__ packed, int unpack) {
+    pack_body(job, packed, unpack, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// The independent small jobs around a render call in ONE launch (each was a 4-6 us kernel of its own): workgroup
+// ranges [decoder (un)packing | grid layout conversion | accumulator clearing].  Before the forward: pack the decoders,
+// convert the touched blocks to voxel-major, clear the gradient accumulators.  After the backward: transposed-back
+// grid gradients and unpacked decoder gradients.
+__global__ __launch_bounds__(256) void step_kernel(PackJob pj, int unpack, ConvJob cj, int to_vm, ConvJob zj,
+                                                   float* __restrict__ flat, int64_t n_flat, int nb_pack, int nb_conv) {
+    const int b = blockIdx.x;
+    if (b < nb_pack) pack_body(pj, nullptr, unpack, b >> 2, b & 3, 4);
+    else if (b < nb_pack + nb_conv) convert_body(cj, to_vm, b - nb_pack);
+    else zero_body(zj, flat, n_flat, b - nb_pack - nb_conv);
 }
 
 }  // namespace
@@ -583,6 +602,17 @@ int ens_launch_transpose(const float* src, float* dst, int64_t V, bool to_vm, hi
 int ens_launch_convert(const ConvJob& job, bool to_vm, hipStream_t st) {
     if (job.n <= 0 || job.block_begin[job.n] <= 0) return 0;
     convert_kernel<<<dim3(job.block_begin[job.n]), dim3(256), 0, st>>>(job, to_vm ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_vm, const ConvJob& zj, float* flat,
+                    int64_t n_flat, hipStream_t st) {
+    const int nb_pack = pj.n * 4, nb_conv = cj.n > 0 ? cj.block_begin[cj.n] : 0;
+    const int64_t nb_zero = (zj.n > 0 ? zj.block_begin[zj.n] : 0) + (flat != nullptr && n_flat > 0 ? (n_flat + 2047) / 2048 : 0);
+    const int64_t nb = (int64_t)nb_pack + nb_conv + nb_zero;
+    if (nb <= 0) return 0;
+    step_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(pj, unpack ? 1 : 0, cj, to_vm ? 1 : 0, zj, flat, flat ? n_flat : 0,
+                                                          nb_pack, nb_conv);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

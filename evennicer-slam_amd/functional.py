@@ -147,9 +147,10 @@ class _PackCache:
 _pack_caches = weakref.WeakKeyDictionary()      # decoder module -> _PackCache
 
 
-def packed_decoders(items, arena=None):
+def packed_decoders(items, arena=None, defer=False):
     """Packed forms of several decoders [(module, kind, params)]; stale ones are rebuilt with ONE zero-fill and ONE
-    launch (up to three decoders per launch)."""
+    launch (up to three decoders per launch).  defer=True (at most three stale decoders): nothing is launched, the
+    second return value holds the arguments (n, kinds, structs, ptrs) for enslam_step_prepare, or None."""
     out, stale = [], []
     for i, (dec, kind, ps) in enumerate(items):
         cache = _pack_caches.get(dec)
@@ -176,6 +177,7 @@ def packed_decoders(items, arena=None):
                 cache.where, cache.struct = where, _fill_params_struct(items[i][1], items[i][2])
             cache.key, cache.packed = key, pieces[j]
             out[i] = pieces[j]
+        deferred = None
         for g0 in range(0, len(stale), 3):
             grp = stale[g0:g0 + 3]
             n = len(grp)
@@ -184,7 +186,14 @@ def packed_decoders(items, arena=None):
                 kinds[j] = items[i][1]
                 structs[j] = cache.struct
                 ptrs[j] = cache.packed.data_ptr()
-            L.check(lib.enslam_pack_mlp_multi(n, kinds, structs, ptrs, _stream()), "enslam_pack_mlp_multi")
+            if defer and len(stale) <= 3:
+                deferred = (n, kinds, structs, ptrs)
+            else:
+                L.check(lib.enslam_pack_mlp_multi(n, kinds, structs, ptrs, _stream()), "enslam_pack_mlp_multi")
+        if defer:
+            return out, deferred
+    elif defer:
+        return out, None
     return out
 
 
@@ -260,7 +269,7 @@ class _GridCache:
         return out
 
 
-    def get_many_sparse(self, grids, need, arena=None):
+    def get_many_sparse(self, grids, need, arena=None, defer=False):
         """Voxel-major copies in which (at least) the 64-voxel blocks flagged in need[i] (uint8 tensors) are valid.
         Every entry carries a `valid` bitmap; one launch converts the blocks that are needed and not yet valid."""
         n = len(grids)
@@ -286,6 +295,8 @@ class _GridCache:
             srcs[i], dsts[i], vs[i] = src.data_ptr(), vm.data_ptr(), vm.shape[0]
             needs[i], valids[i] = need[i].data_ptr(), valid.data_ptr()
             out.append(vm)
+        if defer:                    # the caller launches (enslam_step_prepare); `keep` pins the sources until then
+            return out, (n, srcs, dsts, vs, needs, valids, keep)
         L.check(L.lib().enslam_grids_convert_sparse(n, srcs, dsts, vs, needs, valids, 1, _stream()),
                 "enslam_grids_convert_sparse")
         return out
@@ -377,6 +388,47 @@ class RenderPlan:
         self.vm = {}                            # kind -> VoxelMajorGrid for grids passed in the device layout
 
 
+class _Accumulators:
+    """The buffers a render backward adds into: voxel-major grid gradients (only the touched blocks are ever cleared,
+    read or transposed back) and one flat buffer of packed-layout decoder gradients and ray gradients.  Laid out in
+    the forward, because the launch that prepares the forward's inputs clears them as well."""
+
+    def __init__(self, plan, dims, needs, N, dev, lib):
+        nk = len(plan.kinds)
+        self.need_rays = bool(needs[1] or needs[2])
+        self.need_grid = {k: bool(needs[5 + i]) for i, k in enumerate(plan.kinds)}
+        off, self.need_par = 5 + nk, {}
+        for k in plan.kinds:
+            n = plan.n_params[k]
+            self.need_par[k] = any(needs[off:off + n])
+            off += n
+        sizes = []
+        for k in plan.kinds:
+            D, H, W = dims[k]
+            sizes.append(D * H * W * 32 if (self.need_grid[k] and k not in plan.vm) else 0)
+        for k in plan.kinds:
+            sizes.append(lib.enslam_packed_grad_floats(k) if self.need_par[k] else 0)
+        sizes.append(6 * N if self.need_rays else 0)
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        self.sizes, self.offs = sizes, offs
+        self.n_grid = offs[nk]
+        self.n_flat = offs[-1] - self.n_grid
+        self.gbuf = torch.empty(max(self.n_grid, 1), dtype=torch.float32, device=dev)
+        self.zbuf = torch.empty(max(self.n_flat, 1), dtype=torch.float32, device=dev)
+        self.clean = False          # set by the launch that cleared them; a backward consumes it
+
+    def zero_args(self, plan, flags):
+        """(n, dsts, n_voxels, need flags) of the grid accumulators for enslam_zero_blocks / enslam_step_prepare."""
+        zl = [(i, k) for i, k in enumerate(plan.kinds) if self.need_grid[k] and k not in plan.vm]
+        n = len(zl)
+        dsts, vs, nd = (ctypes.c_void_p * max(n, 1))(), (ctypes.c_int64 * max(n, 1))(), (ctypes.c_void_p * max(n, 1))()
+        for j, (i, k) in enumerate(zl):
+            dsts[j], vs[j], nd[j] = self.gbuf.data_ptr() + 4 * self.offs[i], self.sizes[i] // 32, flags[i].data_ptr()
+        return n, dsts, vs, nd
+
+
 class _RenderFn(torch.autograd.Function):
     """inputs: plan, rays_o, rays_d, gt_depth|None, t_rand|None, then for each kind in plan.kinds: grid,
     then for each kind: its parameters.  Outputs depth f64 [N], var f64 [N], rgb f32 [N,3]."""
@@ -428,16 +480,31 @@ class _RenderFn(torch.autograd.Function):
         if static:
             for (i, k), vm in zip(static, _grid_cache.get_many([grids[i] for i, _ in static])):
                 grids_vm[k] = vm
+        conv_args = None
         if dense:
             dense_grids = [grids[i] for i, _ in dense]
-            for (i, k), vm in zip(dense, _grid_cache.get_many_sparse(dense_grids, [flags[i] for i, _ in dense], arena)):
+            vms, conv_args = _grid_cache.get_many_sparse(dense_grids, [flags[i] for i, _ in dense], arena, defer=True)
+            for (i, k), vm in zip(dense, vms):
                 grids_vm[k] = vm
         po, items = nk, []
         for k in plan.kinds:
             items.append((plan.decoders[k], k, tensors[po:po + plan.n_params[k]]))
             po += plan.n_params[k]
-        for k, pk in zip(plan.kinds, packed_decoders(items, arena)):
+        pks, pack_args = packed_decoders(items, arena, defer=True)
+        for k, pk in zip(plan.kinds, pks):
             packed[k] = pk
+        # ONE launch: pack the stale decoders, convert the touched blocks, clear the backward's accumulators
+        accum = _Accumulators(plan, dims, ctx.needs_input_grad, N, dev, lib) if any(ctx.needs_input_grad) else None
+        nd_, kinds_, structs_, ptrs_ = pack_args if pack_args is not None else (0, None, None, None)
+        nc_, srcs_, dsts_, vs_, needs_, valids_, keep_ = conv_args if conv_args is not None else (0, None, None, None, None, None, None)
+        nz_, zd_, zv_, zn_ = accum.zero_args(plan, flags) if accum is not None else (0, None, None, None)
+        if nd_ or nc_ or accum is not None:
+            L.check(lib.enslam_step_prepare(nd_, kinds_, structs_, ptrs_, nc_, srcs_, dsts_, vs_, needs_, valids_, nz_, zd_, zv_, zn_,
+                                            _ptr(accum.zbuf) if accum is not None else None,
+                                            accum.n_flat if accum is not None else 0, st), "enslam_step_prepare")
+            if accum is not None:
+                accum.clean = True
+        del keep_
         sc = _scene_struct(plan.stage, plan.bound6, plan.coarse_bound6, grids_vm, dims, packed)
         depth = torch.empty(N, dtype=torch.float64, device=dev)
         var = torch.empty(N, dtype=torch.float64, device=dev)
@@ -454,7 +521,7 @@ class _RenderFn(torch.autograd.Function):
         L.check(lib.enslam_render_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                       _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, st),
                 "enslam_render_fwd")
-        ctx.plan, ctx.S, ctx.dims, ctx.act_light = plan, S, dims, act_light
+        ctx.plan, ctx.S, ctx.dims, ctx.act_light, ctx.accum = plan, S, dims, act_light, accum
         ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act, flags)
         ctx.grid_shapes = [tuple(g.shape) for g in grids]
         ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
@@ -468,14 +535,8 @@ class _RenderFn(torch.autograd.Function):
         N, dev, st = ro.shape[0], ro.device, _stream()
         nk = len(plan.kinds)
         needs = ctx.needs_input_grad            # (plan, ro, rd, gd, t_rand, grids..., params...)
-        need_rays = needs[1] or needs[2]
-        need_grid = {k: needs[5 + i] for i, k in enumerate(plan.kinds)}
-        off = 5 + nk
-        need_par = {}
-        for k in plan.kinds:
-            n = plan.n_params[k]
-            need_par[k] = any(needs[off:off + n])
-            off += n
+        accum = ctx.accum
+        need_rays, need_grid, need_par = accum.need_rays, accum.need_grid, accum.need_par
 
         def prep(g, dtype, shape):
             if g is None:
@@ -488,38 +549,25 @@ class _RenderFn(torch.autograd.Function):
         sc = _scene_struct(plan.stage, plan.bound6, plan.coarse_bound6, grids_vm, ctx.dims, packed)
         gg = (L.Grid * 4)()
         gpk = (ctypes.c_void_p * 4)()
-        # ONE zero-filled buffer holds every accumulator the kernels add into
+        # accumulators: laid out and cleared by the forward's prepare launch (cleared again here on a repeated backward)
         vmg = plan.vm               # grids in the device layout accumulate into their own grad_vm (kept clear by the optimiser)
-        sizes = []
+        sizes, offs, n_grid, n_flat, gbuf, zbuf = accum.sizes, accum.offs, accum.n_grid, accum.n_flat, accum.gbuf, accum.zbuf
         for k in plan.kinds:
             D, H, W = ctx.dims[k]
             gg[k].D, gg[k].H, gg[k].W = D, H, W
-            sizes.append(D * H * W * 32 if (need_grid[k] and k not in vmg) else 0)
             if need_grid[k] and k in vmg:
                 gg[k].data = vmg[k].grad_vm.data_ptr()
                 vmg[k].has_grad = True
-        for k in plan.kinds:
-            sizes.append(lib.enslam_packed_grad_floats(k) if need_par[k] else 0)
-        sizes.append(6 * N if need_rays else 0)
-        offs = [0]
-        for n in sizes:
-            offs.append(offs[-1] + n)
-        # grid-gradient accumulators: only the blocks this batch touches are zeroed (and later transposed back);
-        # decoder / ray accumulators are small and zero-filled whole
-        n_grid = offs[nk]
-        gbuf = torch.empty(max(n_grid, 1), dtype=torch.float32, device=dev)
-        n_flat = offs[-1] - n_grid
-        zbuf = torch.empty(max(n_flat, 1), dtype=torch.float32, device=dev)      # zeroed by the launch below
         gbase, zbase = gbuf.data_ptr(), zbuf.data_ptr() - 4 * n_grid
         g_grids_vm, g_packed = {}, {}
-        zl = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k] and k not in vmg]
-        n = len(zl)
-        dsts, vs, need_ptrs = (ctypes.c_void_p * max(n, 1))(), (ctypes.c_int64 * max(n, 1))(), (ctypes.c_void_p * max(n, 1))()
-        for j, (i, k) in enumerate(zl):
-            g_grids_vm[k] = gbase + 4 * offs[i]
-            gg[k].data = g_grids_vm[k]
-            dsts[j], vs[j], need_ptrs[j] = g_grids_vm[k], sizes[i] // 32, flags[i].data_ptr()
-        L.check(lib.enslam_zero_blocks(n, dsts, vs, need_ptrs, _ptr(zbuf), n_flat, st), "enslam_zero_blocks")
+        for i, k in enumerate(plan.kinds):
+            if need_grid[k] and k not in vmg:
+                g_grids_vm[k] = gbase + 4 * offs[i]
+                gg[k].data = g_grids_vm[k]
+        if not accum.clean:
+            n, dsts, vs, need_ptrs = accum.zero_args(plan, flags)
+            L.check(lib.enslam_zero_blocks(n, dsts, vs, need_ptrs, _ptr(zbuf), n_flat, st), "enslam_zero_blocks")
+        accum.clean = False
         for i, k in enumerate(plan.kinds):
             if need_par[k]:
                 g_packed[k] = zbase + 4 * offs[nk + i]
@@ -551,38 +599,36 @@ class _RenderFn(torch.autograd.Function):
             L.check(lib.enslam_ray_grad_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                             _ptr(dgw), p_ro, p_rd, st), "enslam_ray_grad_bwd")
         out = [None, g_ro if needs[1] else None, g_rd if needs[2] else None, None, None]
-        # grid gradients back to the callers' [1,32,D,H,W] layout: one launch for all grids
+        # ONE launch: grid gradients back to the callers' [1,32,D,H,W] layout + decoder gradients unpacked into views of
+        # one flat buffer shaped like the parameters
         conv = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k] and k not in vmg]
         grid_out = {}
-        if conv:
-            n = len(conv)
-            srcs, dsts, vs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)()
-            need_ptrs = (ctypes.c_void_p * n)()
-            for j, (i, k) in enumerate(conv):
-                g = torch.empty(ctx.grid_shapes[i], dtype=torch.float32, device=dev)
-                grid_out[k] = g
-                srcs[j], dsts[j], vs[j], need_ptrs[j] = g_grids_vm[k], g.data_ptr(), sizes[i] // 32, flags[i].data_ptr()
-            L.check(lib.enslam_grids_convert_sparse(n, srcs, dsts, vs, need_ptrs, None, 0, st), "enslam_grids_convert_sparse")
+        nc = len(conv)
+        srcs, dsts, vs = (ctypes.c_void_p * max(nc, 1))(), (ctypes.c_void_p * max(nc, 1))(), (ctypes.c_int64 * max(nc, 1))()
+        need_ptrs = (ctypes.c_void_p * max(nc, 1))()
+        for j, (i, k) in enumerate(conv):
+            g = torch.empty(ctx.grid_shapes[i], dtype=torch.float32, device=dev)
+            grid_out[k] = g
+            srcs[j], dsts[j], vs[j], need_ptrs[j] = g_grids_vm[k], g.data_ptr(), sizes[i] // 32, flags[i].data_ptr()
         for k in plan.kinds:
             out.append(grid_out.get(k))
-        # decoder gradients: one flat buffer, views shaped like the parameters, one unpack launch
         pm = iter(ctx.param_meta)
         shapes_by_kind = {k: [next(pm) for _ in range(plan.n_params[k])] for k in plan.kinds}
         kinds_p = [k for k in plan.kinds if need_par[k]]
         views_by_kind = {}
+        npk = len(kinds_p)
+        kind_arr, pk_arr, structs = (ctypes.c_int32 * max(npk, 1))(), (ctypes.c_void_p * max(npk, 1))(), (L.MlpParams * max(npk, 1))()
         if kinds_p:
             all_sizes = [int(torch.Size(sh).numel()) for k in kinds_p for sh in shapes_by_kind[k]]
             pflat = torch.empty(sum(all_sizes), dtype=torch.float32, device=dev)
-            pieces = pflat.split(all_sizes)
-            it = iter(pieces)
-            n = len(kinds_p)
-            kind_arr, pk_arr, structs = (ctypes.c_int32 * n)(), (ctypes.c_void_p * n)(), (L.MlpParams * n)()
+            it = iter(pflat.split(all_sizes))
             for j, k in enumerate(kinds_p):
                 views = [next(it).view(sh) for sh in shapes_by_kind[k]]
                 views_by_kind[k] = views
                 kind_arr[j], pk_arr[j] = k, g_packed[k]
                 structs[j] = _fill_params_struct(k, views)
-            L.check(lib.enslam_unpack_mlp_grads_multi(n, kind_arr, pk_arr, structs, st), "unpack_mlp_grads_multi")
+        if nc or npk:
+            L.check(lib.enslam_step_finish(nc, srcs, dsts, vs, need_ptrs, npk, kind_arr, pk_arr, structs, st), "enslam_step_finish")
         for k in plan.kinds:
             out += views_by_kind.get(k, [None] * plan.n_params[k])
         ctx.keep = None

@@ -162,6 +162,19 @@ int enslam_adam_tensors(int32_t n, float *const *param, const float *const *grad
                         float *const *exp_avg_sq, const int64_t *numel, const double *lr, const int32_t *step,
                         double beta1, double beta2, double eps, void *stream);
 
+/* The small independent jobs around a render call in ONE launch each (they are 4-6 us kernels when issued separately):
+ * enslam_step_prepare = enslam_pack_mlp_multi (n_dec decoders) + enslam_grids_convert_sparse to voxel-major (n_conv
+ *   grids) + enslam_zero_blocks (n_zero accumulators and the flat range); any of the three parts may be empty.
+ * enslam_step_finish  = enslam_grids_convert_sparse back to [32,V] (gradients) + enslam_unpack_mlp_grads_multi. */
+int enslam_step_prepare(int32_t n_dec, const int32_t *kinds, const enslam_mlp_params *params, float *const *packed,
+                        int32_t n_conv, const float *const *src, float *const *dst, const int64_t *n_voxels,
+                        const uint8_t *const *need, uint8_t *const *valid, int32_t n_zero, float *const *zero_dst,
+                        const int64_t *zero_voxels, const uint8_t *const *zero_need, float *flat, int64_t n_flat,
+                        void *stream);
+int enslam_step_finish(int32_t n_conv, const float *const *src, float *const *dst, const int64_t *n_voxels,
+                       const uint8_t *const *need, int32_t n_dec, const int32_t *kinds,
+                       const float *const *packed_grads, const enslam_mlp_params *grads, void *stream);
+
 /* Sample distances along rays (mark_scene / mark_flags non-NULL: also does enslam_mark_blocks' work for stage mark_stage
  * on the samples it has just placed -- one launch less per render call).
  *   Replaces Renderer.render_batch_ray lines 83-171
