@@ -631,9 +631,7 @@ class _RenderFn(torch.autograd.Function):
             L.check(lib.enslam_step_finish(nc, srcs, dsts, vs, need_ptrs, npk, kind_arr, pk_arr, structs, st), "enslam_step_finish")
         for k in plan.kinds:
             out += views_by_kind.get(k, [None] * plan.n_params[k])
-        ctx.keep = None
-        del gbuf, zbuf
-        return tuple(out)
+        return tuple(out)       # (the saved buffers go with the graph; kept so that retain_graph backwards work)
 
 
 # The forward keeps the backward's operands (1.3 KB per sample and decoder: 172 MB at 1000 rays x 48, colour

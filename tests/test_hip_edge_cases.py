@@ -179,3 +179,31 @@ def test_sparse_layout_cache_fills_incrementally(tiny):
         raw = renderer.eval_points(p.cuda(), model, g2, 'color', 'cuda:0')
         ref = R.eval_points(params, ogrids, p, 'color', obound)
         assert rel_err(raw.cpu().numpy(), ref.numpy()) < 1e-4
+
+
+def test_backward_twice_with_retain_graph(tiny):
+    """The accumulators are cleared by the forward's prepare launch; a second backward over the same graph clears
+    them again itself: identical gradients both times."""
+    s, bound, model, grids, rays, renderer = tiny
+    for p_ in model.parameters():
+        p_.grad = None
+    cg = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+    ro, rd = rays['rays_o'].clone().requires_grad_(True), rays['rays_d'].clone().requires_grad_(True)
+    d, v, c = renderer.render_batch_ray(cg, model, rd, ro, 'cuda:0', 'color', gt_depth=rays['gt_depth'])
+    loss = d.sum() + c.sum()
+    loss.backward(retain_graph=True)
+    first = {k: t.grad.clone() for k, t in cg.items() if t.grad is not None}
+    first_ro = ro.grad.clone()
+    w0 = model.color_decoder.pts_linears[0].weight.grad.clone()
+    for t in cg.values():
+        t.grad = None
+    ro.grad = None
+    for p_ in model.parameters():
+        p_.grad = None
+    loss.backward()
+    for k, g in first.items():
+        assert float((cg[k].grad - g).abs().max()) <= 1e-5 * float(g.abs().max()), k
+    assert float((ro.grad - first_ro).abs().max()) <= 1e-5 * float(first_ro.abs().max())
+    assert float((model.color_decoder.pts_linears[0].weight.grad - w0).abs().max()) <= 1e-5 * float(w0.abs().max())
+    for p_ in model.parameters():
+        p_.grad = None
