@@ -1,0 +1,52 @@
+"""-m gpu: the C ABI's error conventions (include/enslam_hip.h: 0 on success, negative ENSLAM_E* otherwise; no
+exceptions, no aborts) exercised with bad arguments, and the Python binding turning them into EnslamError."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EINVAL, ELAUNCH, EUNSUPPORTED = -1, -2, -3
+
+
+def test_bad_arguments_return_error_codes():
+    import evennicer_slam_amd as E
+    L = E._lib
+    lib = L.lib()
+    dev = torch.device('cuda', 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sc = L.Scene()
+    ro = torch.zeros(4, 3, device=dev)
+    z = torch.zeros(4, 48, dtype=torch.float64, device=dev)
+    out_d = torch.zeros(4, dtype=torch.float64, device=dev)
+    out_c = torch.zeros(4, 3, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    # empty scene: the stage's grids / decoders are missing
+    assert lib.enslam_render_fwd(3, 4, 48, P(ro), P(ro), P(z), ctypes.byref(sc), P(out_d), P(out_d), P(out_c), None, None, 0, st) == EINVAL
+    # unsupported sample count
+    assert lib.enslam_render_fwd(3, 4, 40, P(ro), P(ro), P(z), ctypes.byref(sc), P(out_d), P(out_d), P(out_c), None, None, 0, st) == EUNSUPPORTED
+    # negative ray count / zero rays
+    assert lib.enslam_render_fwd(3, -1, 48, P(ro), P(ro), P(z), ctypes.byref(sc), P(out_d), P(out_d), P(out_c), None, None, 0, st) == EINVAL
+    assert lib.enslam_render_fwd(3, 0, 48, None, None, None, ctypes.byref(sc), None, None, None, None, None, 0, st) == 0
+    # NULL where a pointer is required
+    assert lib.enslam_grid_to_voxel_major(None, P(ro), 4, st) == EINVAL
+    assert lib.enslam_composite_fwd(4, 65, P(ro), P(z), P(out_d), P(out_d), P(out_c), None, st) != 0           # S > 64
+    assert lib.enslam_adam_tensors(73, None, None, None, None, None, None, None, 0.9, 0.999, 1e-8, st) == EUNSUPPORTED
+    assert lib.enslam_pose_rays_fwd(4, None, P(ro), P(ro), 1.0, 1.0, 0.0, 0.0, P(ro), P(ro), st) == EINVAL
+    assert lib.enslam_tracker_loss_fwd(4, P(out_d), P(out_d), P(out_c), P(ro), None, 0.5, P(out_d), st) == EINVAL   # colour without gt
+    assert lib.enslam_step_prepare(4, None, None, None, 0, None, None, None, None, None, 0, None, None, None, None, 0, st) == EINVAL
+    assert lib.enslam_step_prepare(0, None, None, None, 0, None, None, None, None, None, 0, None, None, None, None, 0, st) == 0
+    torch.cuda.synchronize()
+    assert lib.enslam_abi_version() >= 1
+    assert lib.enslam_activation_floats(0, 100, 48, 0) == 0                     # the coarse stage keeps no workspace
+    assert lib.enslam_activation_floats(3, 100, 48, 1) < lib.enslam_activation_floats(3, 100, 48, 0)
+
+
+def test_binding_raises_enslam_error_with_the_entry_name():
+    import evennicer_slam_amd as E
+    with pytest.raises(E.EnslamError, match="some_entry"):
+        E._lib.check(-1, "some_entry")
+    assert E._lib.check(0, "ok") is None
+    with pytest.raises(E.EnslamError):                         # CPU tensors never reach the kernels
+        E.functional._require_hip(torch.zeros(3), "x")
