@@ -598,7 +598,11 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
     // Ray mode with raw requested and a moderate ray count: tile-per-wave decoders + separate compositing (more
     // waves in flight).  Large batches (full-image renders) already fill the chip with one wave per ray.
     int tpr = 0;
-    if (pts == nullptr && raw != nullptr && n_units <= 32768) {
+    static const int64_t tile_mode_max = [] {                 // tuning aid: ENSLAM_TILE_MODE_MAX_RAYS
+        const char* e = getenv("ENSLAM_TILE_MODE_MAX_RAYS");
+        return e ? (int64_t)atoll(e) : (int64_t)32768;
+    }();
+    if (pts == nullptr && raw != nullptr && n_units <= tile_mode_max) {
         tpr = ntl;
         n_units *= ntl;
         ntl = 1;
