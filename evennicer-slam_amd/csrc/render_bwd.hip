@@ -815,7 +815,10 @@ constexpr int RB_SAVED = 96 * 32 + 1024 + 16 * 96 + 96 * 4;           // layer-0
 
 // WW = false: no decoder-parameter gradients (tracker iterations; mapper stages that optimise no decoder): no
 // deposits, no owned dW tiles, no accumulators, no slot fill -- under 256 registers, two workgroups per CU.
-template <int CT, int NOUT, bool WW>
+// SPLIT = true: this is the chain half of decoder_bwd_split_kernel (waves 0..3 of an 8-wave workgroup): it deposits the
+// operands but leaves every owned weight-gradient tile to the dW waves (xyz_dw_loop), which run one barrier phase
+// behind on the same SIMDs.
+template <int CT, int NOUT, bool WW, bool SPLIT = false>
 ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float* smem) {
     constexpr XyzLay L{CT * 16};
     constexpr int GF = L.fwd_floats();
@@ -1012,7 +1015,9 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             }
             if (want_w) {
                 const int ybias = (wave < 2 ? TP : TH) + (wave & 1);                              // db_i | dbc_i
-                if constexpr (i == 0) {                                                           // dWc_i, dW_i, bias
+                if constexpr (SPLIT) {
+                    // the dW waves do it
+                } else if constexpr (i == 0) {                                                    // dWc_i, dW_i, bias
                     own_layer_a<CT / 2, 3>(aWc[i], TH, SL::C, CT, 2 * CT, aW0, TP, SL::EMB, 6, 12, aB[i], ybias, fb, wave);
                 } else if constexpr (i == 3) {
                     own_layer_a<CT / 2, 4>(aWc[i], TH, SL::C, CT, 2 * CT, aW3, TP, SL::EMB, 8, 16, aB[i], ybias, fb, wave);   // [emb | h2] contiguous
@@ -1070,7 +1075,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 dep_tile<SL::EMB + 0>(dep, demb[0]); dep_tile<SL::EMB + 1>(dep, demb[1]); dep_tile<SL::EMB + 2>(dep, demb[2]);
                 dep_tile<SL::EMB + 3>(dep, demb[3]); dep_tile<SL::EMB + 4>(dep, demb[4]); dep_tile<SL::EMB + 5>(dep, demb[5]);
                 __syncthreads();
-                own_outer_a<2>(aBT, fb, SL::EMB, SL::Q, 1, 6, wave);                              // dB^T
+                if constexpr (!SPLIT) own_outer_a<2>(aBT, fb, SL::EMB, SL::Q, 1, 6, wave);           // dB^T
             }
             if (want_r) lin_lds_swz<1, 6, 96, OBP>(dpe, swz_base_even(ring0, 96, p, q), swd, demb);   // rows 0..2: dp (q == 0 lanes)
         }
@@ -1097,25 +1102,28 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     // ---- flush: stage the owned tiles into a packed-layout LDS image, then coalesced global atomics
     if (want_w) {
         float* sacc = slots;
+        const int nthr = SPLIT ? 512 : 256;
         __syncthreads();
-        for (int e = threadIdx.x; e < GF; e += 256) sacc[e] = 0.f;
+        for (int e = threadIdx.x; e < GF; e += nthr) sacc[e] = 0.f;
         __syncthreads();
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < 5; ++i) {
 #pragma unroll
-            for (int j = 0; j < CT / 2; ++j) stage_tile(sacc + L.oWc(i), CT * 16, 0, CT, wave + 4 * j, aWc[i][j], 32, CT * 16, p, q);
-            stage_bias(sacc + (wave < 2 ? L.ob(i) : L.obc(i)), wave & 1, aB[i], 32, p, q);
+                for (int j = 0; j < CT / 2; ++j) stage_tile(sacc + L.oWc(i), CT * 16, 0, CT, wave + 4 * j, aWc[i][j], 32, CT * 16, p, q);
+                stage_bias(sacc + (wave < 2 ? L.ob(i) : L.obc(i)), wave & 1, aB[i], 32, p, q);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) stage_tile(sacc + L.oW(0), 96, 0, 6, wave + 4 * j, aW0[j], 32, 96, p, q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) stage_tile(sacc + L.oW(3), 128, 0, 8, wave + 4 * j, aW3[j], 32, 128, p, q);
+            stage_tile(sacc + L.oW(1), 32, 0, 2, wave, aW1[0], 32, 32, p, q);
+            stage_tile(sacc + L.oW(2), 32, 0, 2, wave, aW2[0], 32, 32, p, q);
+            stage_tile(sacc + L.oW(4), 32, 0, 2, wave, aW4[0], 32, 32, p, q);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (wave + 4 * j < 6) stage_tile(sacc + L.oBT(), 4, 0, 1, wave + 4 * j, aBT[j], 93, 3, p, q);
         }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) stage_tile(sacc + L.oW(0), 96, 0, 6, wave + 4 * j, aW0[j], 32, 96, p, q);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) stage_tile(sacc + L.oW(3), 128, 0, 8, wave + 4 * j, aW3[j], 32, 128, p, q);
-        stage_tile(sacc + L.oW(1), 32, 0, 2, wave, aW1[0], 32, 32, p, q);
-        stage_tile(sacc + L.oW(2), 32, 0, 2, wave, aW2[0], 32, 32, p, q);
-        stage_tile(sacc + L.oW(4), 32, 0, 2, wave, aW4[0], 32, 32, p, q);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (wave + 4 * j < 6) stage_tile(sacc + L.oBT(), 4, 0, 1, wave + 4 * j, aBT[j], 93, 3, p, q);
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
 #pragma unroll
@@ -1129,10 +1137,97 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             if (lane == 0) lds_add(sacc + L.obo() + j, bsum);
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < GF; e += 256) {
+        for (int e = threadIdx.x; e < GF; e += nthr) {
             const float vsum = sacc[e];
             if (vsum != 0.f) atomicAdd(gpk + e, vsum);
         }
+    }
+}
+
+// The dW half of decoder_bwd_split_kernel (waves 4..7): the owned weight-gradient tiles of xyz_role_saved, one barrier
+// phase behind the chain waves that deposit their operands -- its MFMAs fill the gaps of the chain waves' latencies on
+// the same SIMDs.  Executes exactly the barriers of the chain half: vote, 5 layers, 2 in the tail, 3 in the flush.
+template <int CT, int NOUT>
+ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* smem) {
+    constexpr XyzLay L{CT * 16};
+    constexpr int GF = L.fwd_floats();
+    using SL = XyzSlotsS<CT>;
+    constexpr int SLOT = SL::TILES * 256;
+    constexpr int RB = RB_SAVED;
+    constexpr int RING_BYTES = 2 * RB * 4;
+    const int lane = threadIdx.x & 63, ow = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 4, p = lane & 15, q = lane >> 4;
+    float* gpk = A.gpacked[kind];
+    float* slots = smem + 2 * RB;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)smem;
+    f32x4 aWc[5][CT / 2], aW0[3], aW1[1], aW2[1], aW3[4], aW4[1], aB[5], aBT[2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        aB[i] = splat4(0.f);
+#pragma unroll
+        for (int j = 0; j < CT / 2; ++j) aWc[i][j] = splat4(0.f);
+    }
+    aW0[0] = aW0[1] = aW0[2] = aW1[0] = aW2[0] = aW4[0] = splat4(0.f);
+    aW3[0] = aW3[1] = aW3[2] = aW3[3] = splat4(0.f);
+    aBT[0] = aBT[1] = splat4(0.f);
+    unsigned fb[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
+    const int64_t n_tiles = (int64_t)A.n_rays * A.ntl;
+    const int64_t stride = (int64_t)n_wg * 4;
+    unsigned round_no = 0;
+    auto own = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
+        constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);
+        __syncthreads();                    // layer i's deposits are in place
+        const int ybias = (ow < 2 ? TP : TH) + (ow & 1);
+        if constexpr (i == 0) {
+            own_layer_a<CT / 2, 3>(aWc[i], TH, SL::C, CT, 2 * CT, aW0, TP, SL::EMB, 6, 12, aB[i], ybias, fb, ow);
+        } else if constexpr (i == 3) {
+            own_layer_a<CT / 2, 4>(aWc[i], TH, SL::C, CT, 2 * CT, aW3, TP, SL::EMB, 8, 16, aB[i], ybias, fb, ow);
+        } else if constexpr (i == 1) {
+            own_layer_a<CT / 2, 1>(aWc[i], TH, SL::C, CT, 2 * CT, aW1, TP, TX, 2, 4, aB[i], ybias, fb, ow);
+        } else if constexpr (i == 2) {
+            own_layer_a<CT / 2, 1>(aWc[i], TH, SL::C, CT, 2 * CT, aW2, TP, TX, 2, 4, aB[i], ybias, fb, ow);
+        } else {
+            own_layer_a<CT / 2, 1>(aWc[i], TH, SL::C, CT, 2 * CT, aW4, TP, TX, 2, 4, aB[i], ybias, fb, ow);
+        }
+    };
+    for (int64_t base = (int64_t)wg * 4; base < n_tiles; base += stride) {
+        const int par = (int)(round_no & 1);
+        ++round_no;
+        __syncthreads();                    // vote
+        const int any4 = ens_vote[par][0] | ens_vote[par][1] | ens_vote[par][2] | ens_vote[par][3];
+        if (!any4) continue;
+        own(IC(4)); own(IC(3)); own(IC(2)); own(IC(1)); own(IC(0));
+        __syncthreads();                    // chain waves are done with EMB ...
+        __syncthreads();                    // ... and have deposited d_arg there
+        own_outer_a<2>(aBT, fb, SL::EMB, SL::Q, 1, 6, ow);                                         // dB^T
+    }
+    float* sacc = slots;
+    __syncthreads();
+    for (int e = threadIdx.x; e < GF; e += 512) sacc[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+        for (int j = 0; j < CT / 2; ++j) stage_tile(sacc + L.oWc(i), CT * 16, 0, CT, ow + 4 * j, aWc[i][j], 32, CT * 16, p, q);
+        stage_bias(sacc + (ow < 2 ? L.ob(i) : L.obc(i)), ow & 1, aB[i], 32, p, q);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) stage_tile(sacc + L.oW(0), 96, 0, 6, ow + 4 * j, aW0[j], 32, 96, p, q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage_tile(sacc + L.oW(3), 128, 0, 8, ow + 4 * j, aW3[j], 32, 128, p, q);
+    stage_tile(sacc + L.oW(1), 32, 0, 2, ow, aW1[0], 32, 32, p, q);
+    stage_tile(sacc + L.oW(2), 32, 0, 2, ow, aW2[0], 32, 32, p, q);
+    stage_tile(sacc + L.oW(4), 32, 0, 2, ow, aW4[0], 32, 32, p, q);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (ow + 4 * j < 6) stage_tile(sacc + L.oBT(), 4, 0, 1, ow + 4 * j, aBT[j], 93, 3, p, q);
+    __syncthreads();
+    for (int e = threadIdx.x; e < GF; e += 512) {
+        const float vsum = sacc[e];
+        if (vsum != 0.f) atomicAdd(gpk + e, vsum);
     }
 }
 
@@ -1341,6 +1436,23 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(BwdArgs A) {
     }
 }
 
+// The saved-activation backward with the two MFMA streams of a decoder on separate waves: 8 waves per workgroup, two
+// per SIMD.  Waves 0..3 run the dX chain of one tile each (xyz_role_saved<.., SPLIT>), waves 4..7 accumulate the owned
+// weight-gradient tiles (xyz_dw_loop) from the operands the chain waves deposit, one barrier phase behind.
+__global__ __launch_bounds__(512, 1) void decoder_bwd_split_kernel(BwdArgs A) {
+    int role = 0;
+#pragma unroll
+    for (int r = 1; r < 4; ++r) role = (r < A.n_roles && (int)blockIdx.x >= A.role_begin[r]) ? r : role;
+    const int wg = blockIdx.x - A.role_begin[role], n_wg = A.role_begin[role + 1] - A.role_begin[role];
+    const bool chain = threadIdx.x < 256;
+    switch (A.role_kind[role]) {
+        case 1: if (chain) xyz_role_saved<2, 1, true, true>(A, 1, wg, n_wg, ens_smem); else xyz_dw_loop<2, 1>(A, 1, wg, n_wg, ens_smem); break;
+        case 2: if (chain) xyz_role_saved<4, 1, true, true>(A, 2, wg, n_wg, ens_smem); else xyz_dw_loop<4, 1>(A, 2, wg, n_wg, ens_smem); break;
+        case 3: if (chain) xyz_role_saved<2, 4, true, true>(A, 3, wg, n_wg, ens_smem); else xyz_dw_loop<2, 4>(A, 3, wg, n_wg, ens_smem); break;
+        default: break;
+    }
+}
+
 // Saved-activation backward of decoders whose parameters get no gradient: the dX chain, the feature-gradient scatter
 // and the ray-gradient hand-off only.  No accumulators -> two workgroups per CU overlap each other's latencies.
 __global__ __launch_bounds__(256, 2) void decoder_bwd_light_kernel(BwdArgs A) {
@@ -1443,6 +1555,8 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_xyz(4)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_xyz(4)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_split_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_xyz(4)) != hipSuccess)
             return -2;
         attr_set = true;
@@ -1453,6 +1567,8 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
     // whose slowest role finishes first (the proportional split wastes up to one round of the slowest role: 4-11 % at
     // 1000 rays).  Searched once per (shape, roles).
     const int groups = (int)((n_tiles + 3) / 4);
+    // chain waves + dW waves (decoder_bwd_split_kernel) unless ENS_SPLIT=0 selects the 4-wave kernel (A/B aid)
+    static const bool use_split = [] { const char* e = getenv("ENS_SPLIT"); return e == nullptr || e[0] != '0'; }();
     auto launch_subset = [&](const int* ks, const float* cs, int n, bool light) -> int {
         if (n == 0) return 0;
         int total = device_cus() * (light ? 2 : 1);
@@ -1505,6 +1621,8 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         B.role_begin[n] = total;
         for (int i = n; i < 4; ++i) B.role_kind[i] = -1;
         if (light) decoder_bwd_light_kernel<<<dim3(total), dim3(256), lds_bytes_light(), st>>>(B);
+        else if (A.act_ws != nullptr && use_split && ks[0] != 0)
+            decoder_bwd_split_kernel<<<dim3(total), dim3(512), lds_saved, st>>>(B);
         else if (A.act_ws != nullptr) decoder_bwd_kernel<true><<<dim3(total), dim3(256), lds_saved, st>>>(B);   // ray gradients: ens_launch_ray_grad_bwd
         else decoder_bwd_kernel<false><<<dim3(total), dim3(256), lds, st>>>(B);
         return hipGetLastError() == hipSuccess ? 0 : -2;
