@@ -874,7 +874,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     const int64_t stride = (int64_t)n_wg * 4;
     STAMP_DECL
     STAMP_START
-    prefetch(IC(4), 0);
+    if constexpr (!SPLIT) prefetch(IC(4), 0);                       // (SPLIT: the dW waves stream the ring and fill the slots)
     unsigned round_no = 0, rp = 0;                                  // rp: ring buffer of this round's first chunk
     // The feature-gradient scatter of a tile is deferred into the next executed round (after its first barrier): the
     // ~30 atomics of a tile then drain under that round's MFMAs instead of in front of its loads (vmcnt is in order).
@@ -952,11 +952,13 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         const float* __restrict__ wsb = A.act_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * WSS;
         f32x4 h4[2] = {splat4(0.f), splat4(0.f)};
         if constexpr (WW) {
-            float* myslot = slots + wave * SLOT;
+            if constexpr (!SPLIT) {
+                float* myslot = slots + wave * SLOT;
 #pragma unroll
-            for (int t = 0; t < SL::FILL; ++t)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsb + t * 256 + lane * 4),
-                                                 (__attribute__((address_space(3))) void*)(myslot + t * 256), 16, 0, 0);
+                for (int t = 0; t < SL::FILL; ++t)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsb + t * 256 + lane * 4),
+                                                     (__attribute__((address_space(3))) void*)(myslot + t * 256), 16, 0, 0);
+            }
             h4[0] = ld4(wsb + ACT_H4 + lane * 4);
             h4[1] = ld4(wsb + ACT_H4 + 256 + lane * 4);
         }
@@ -997,7 +999,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             STAMP(6)    // layer deposits (+ tail of previous dX)
             __syncthreads();            // deposits + slot fill visible; this layer's W^T chunk has landed
             STAMP(5)    // barrier wait
-            if constexpr (i > 0) prefetch(IC(i - 1), buf ^ 1); else prefetch(IC(4), buf ^ 1);
+            if constexpr (!SPLIT) { if constexpr (i > 0) prefetch(IC(i - 1), buf ^ 1); else prefetch(IC(4), buf ^ 1); }
             if constexpr (i == 4) scatter_pending();                 // previous tile's atomics, behind this round's loads
             if constexpr (i == 4) { STAMP(1) }      // deferred scatter
             if constexpr (i == 4) {
@@ -1174,12 +1176,30 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
     for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
     const int64_t n_tiles = (int64_t)A.n_rays * A.ntl;
     const int64_t stride = (int64_t)n_wg * 4;
-    unsigned round_no = 0;
+    unsigned round_no = 0, rp = 0;
+    // These waves also do the chain waves' bulk data movement: the W^T ring (one layer ahead) and the slot fills from the
+    // activation workspace -- their barriers (vmcnt(0) included) come late enough for the copies to have landed.
+    const float* __restrict__ pk = A.sc.packed[kind];
+    float* ring = smem;
+    auto prefetch = [&](auto ic, int buf) {
+        constexpr int i = decltype(ic)::value;
+        float* dst = ring + (buf ? RB : 0);
+        ring_load(dst, pk + L.oWT(i), 8 * L.K(i), ow, lane);
+        ring_load(dst + 32 * L.K(i), pk + L.oWcT(i), 256, ow, lane);
+        if constexpr (i == 0) {
+            ring_load(dst + 96 * 32 + 1024, pk + L.oBp(), 16 * 96 / 4, ow, lane);
+            ring_load(dst + 96 * 32 + 1024 + 16 * 96, pk + L.oBT(), 96, ow, lane);
+        }
+    };
+    prefetch(IC(4), 0);
     auto own = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
+        constexpr int kk = 4 - i;
+        const int buf = (kk + rp) & 1;
         constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
         constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);
-        __syncthreads();                    // layer i's deposits are in place
+        __syncthreads();                    // layer i's deposits are in place; its W^T chunk and the slot fills have landed
+        if constexpr (i > 0) prefetch(IC(i - 1), buf ^ 1); else prefetch(IC(4), buf ^ 1);
         const int ybias = (ow < 2 ? TP : TH) + (ow & 1);
         if constexpr (i == 0) {
             own_layer_a<CT / 2, 3>(aWc[i], TH, SL::C, CT, 2 * CT, aW0, TP, SL::EMB, 6, 12, aB[i], ybias, fb, ow);
@@ -1199,7 +1219,18 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         __syncthreads();                    // vote
         const int any4 = ens_vote[par][0] | ens_vote[par][1] | ens_vote[par][2] | ens_vote[par][3];
         if (!any4) continue;
+        {   // slot `ow` <- the operands the forward parked for chain wave ow's tile of this round
+            const int64_t tr = base + ow;
+            const int64_t tile = tr < n_tiles ? tr : n_tiles - 1;
+            const float* __restrict__ wsb = A.act_ws + (tile * ACT_SLOTS + (kind - 1)) * ACT_STRIDE;
+            float* myslot = slots + ow * SLOT;
+#pragma unroll
+            for (int t = 0; t < SL::FILL; ++t)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsb + t * 256 + lane * 4),
+                                                 (__attribute__((address_space(3))) void*)(myslot + t * 256), 16, 0, 0);
+        }
         own(IC(4)); own(IC(3)); own(IC(2)); own(IC(1)); own(IC(0));
+        rp ^= 1;
         __syncthreads();                    // chain waves are done with EMB ...
         __syncthreads();                    // ... and have deposited d_arg there
         own_outer_a<2>(aBT, fb, SL::EMB, SL::Q, 1, 6, ow);                                         // dB^T
