@@ -431,34 +431,46 @@ ENS_DEV void own_outer_a(f32x4 (&acc)[NJ], const unsigned (&fb)[4], int ytile0, 
 template <int NA, int NB>
 ENS_DEV void own_layer_a(f32x4 (&accA)[NA], int yA, int xA, int ncA, int ntA, f32x4 (&accB)[NB], int yB, int xB, int ncB,
                          int ntB, f32x4& accBias, int ybias, const unsigned (&fb)[4], int wave) {
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-        f32x4 aA[NA], bA[NA], aB[NB], bB[NB];
+    // operand fragments of the next slot are requested before the current slot's MFMAs are issued (two register sets),
+    // so the LDS round trip of slot s+1 runs under the MFMAs of slot s
+    constexpr bool PIPE = (NA + NB) <= 4;
+    f32x4 aA[2][NA], bA[2][NA], aB[2][NB], bB[2][NB], ab[2];
+    auto load = [&](int sl, int set) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int t = wave + 4 * j;
             t = t < ntA ? t : 0;
             const int rt = t / ncA, ct = t - rt * ncA;
-            aA[j] = lds4(fb[sl] + (yA + rt) * 1024);
-            bA[j] = lds4(fb[sl] + (xA + ct) * 1024);
+            aA[set][j] = lds4(fb[sl] + (yA + rt) * 1024);
+            bA[set][j] = lds4(fb[sl] + (xA + ct) * 1024);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int t = wave + 4 * j;
             t = t < ntB ? t : 0;
             const int rt = t / ncB, ct = t - rt * ncB;
-            aB[j] = lds4(fb[sl] + (yB + rt) * 1024);
-            bB[j] = lds4(fb[sl] + (xB + ct) * 1024);
+            aB[set][j] = lds4(fb[sl] + (yB + rt) * 1024);
+            bB[set][j] = lds4(fb[sl] + (xB + ct) * 1024);
         }
-        const f32x4 ab = lds4(fb[sl] + ybias * 1024);
+        ab[set] = lds4(fb[sl] + ybias * 1024);
+    };
+    if constexpr (PIPE) load(0, 0);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        const int set = PIPE ? (sl & 1) : 0;
+        if constexpr (PIPE) {
+            if (sl + 1 < 4) load(sl + 1, set ^ 1);
+        } else {
+            load(sl, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
-            for (int j = 0; j < NA; ++j) accA[j] = MFMA16(aA[j][s], bA[j][s], accA[j]);
+            for (int j = 0; j < NA; ++j) accA[j] = MFMA16(aA[set][j][s], bA[set][j][s], accA[j]);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) accB[j] = MFMA16(aB[j][s], bB[j][s], accB[j]);
-            accBias = MFMA16(ab[s], 1.f, accBias);
+            for (int j = 0; j < NB; ++j) accB[j] = MFMA16(aB[set][j][s], bB[set][j][s], accB[j]);
+            accBias = MFMA16(ab[set][s], 1.f, accBias);
         }
     }
 }
