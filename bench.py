@@ -321,9 +321,9 @@ def main():
         traffic = None          # HBM-side bytes per launch from the committed PMC passes (profiles/r01_traffic.json)
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath) and args.rays == 1000 and stage == 'color':
-            traffic = json.load(open(tpath)).get("decoder_bwd_kernel", {}).get("bytes_per_launch")
+            traffic = json.load(open(tpath)).get("decoder_bwd_split_kernel", {}).get("bytes_per_launch")
         out["roofline"] = {
-            "kernel": "decoder_bwd_kernel", "bound": "mfma", "achieved": flops / avg / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+            "kernel": "decoder_bwd_split_kernel", "bound": "mfma", "achieved": flops / avg / 1e12, "peak": PEAK_F32_MFMA / 1e12,
             "unit": "TFLOP/s", "frac": flops / avg / PEAK_F32_MFMA, "traffic": traffic,
             "avg_launch_us": avg * 1e6, "launches": int(len(dur)),
             "step_frac": step_flops / PEAK_F32_MFMA / (elapsed / args.steps),
