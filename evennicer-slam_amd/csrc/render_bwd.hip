@@ -1212,6 +1212,9 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);
         __syncthreads();                    // layer i's deposits are in place; its W^T chunk and the slot fills have landed
         if constexpr (i > 0) prefetch(IC(i - 1), buf ^ 1); else prefetch(IC(4), buf ^ 1);
+#ifdef ENS_EXP_NO_DW
+        return;                             // timing experiment (wrong results): no owned-tile MFMAs
+#endif
         const int ybias = (ow < 2 ? TP : TH) + (ow & 1);
         if constexpr (i == 0) {
             own_layer_a<CT / 2, 3>(aWc[i], TH, SL::C, CT, 2 * CT, aW0, TP, SL::EMB, 6, 12, aB[i], ybias, fb, ow);
