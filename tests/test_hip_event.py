@@ -1,0 +1,115 @@
+"""-m gpu: the tracker's camera iteration with the event term (TrackerIteration.optimize_cam_in_batch: pose -> rays ->
+HIP render of the rescaled image and of the random pixel batch -> U-Net -> event + RGB-D losses -> pose gradient)
+against tests/golden/tiny_event_iter.npz (the reference's own statements, functions and network)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+class _RecordingOptimizer:
+    """stands in for the camera Adam: keeps the gradient the iteration hands to step()"""
+
+    def __init__(self, p):
+        self.p, self.grad, self.steps = p, None, 0
+
+    def zero_grad(self):
+        self.p.grad = None
+
+    def step(self):
+        self.grad = None if self.p.grad is None else self.p.grad.detach().clone()
+        self.steps += 1
+
+
+def _setup(fx, handle_dynamic=True, blur=True, activate=True):
+    import evennicer_slam_amd as E
+    from tests.hip_util import DEV, cfg_like, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    H, W, fxx, fy, cx, cy = [float(x) for x in fx['cam']]
+    cfg = cfg_like()
+    cfg['tracking'] = {'device': DEV, 'w_color_loss': float(fx['w_color_loss']), 'ignore_edge_W': int(fx['edge'][1]),
+                       'ignore_edge_H': int(fx['edge'][0]), 'handle_dynamic': handle_dynamic, 'use_color_in_tracking': True}
+    cfg['event'] = {'activate_events': activate, 'blur': blur, 'kernel_sizes': [int(k) for k in fx['kernel_sizes']],
+                    'kernel_weights': [float(k) for k in fx['kernel_weights']],
+                    'unblurred_weight': float(fx['unblurred_weight']), 'balancer': float(fx['balancer'])}
+    torch.manual_seed(int(fx['unet_seed']))
+    net = E.event.UNet_2heads(6, 2, 2)                 # built on the CPU under the fixture's seed, then moved
+    for p in net.parameters():
+        p.requires_grad_(False)
+    net = net.to(DEV).eval()
+    slam = types.SimpleNamespace(nice=True, bound=bound, renderer=renderer, event_net=net, H=int(H), W=int(W), fx=fxx,
+                                 fy=fy, cx=cx, cy=cy, low_gpu_mem=False)
+    trk = E.tracker.TrackerIteration(cfg, None, slam)
+    trk.c, trk.decoders = grids, model
+    img = {k: torch.from_numpy(fx[k]).to(DEV) for k in ('gt_depth', 'gt_color', 'pre_gt_color', 'gt_event', 'gt_mask')}
+    return trk, img, DEV
+
+
+def test_event_iteration_matches_reference_fixture(monkeypatch):
+    fx = load("tiny_event_iter")
+    trk, img, DEV = _setup(fx)
+    idx = torch.from_numpy(fx['idx']).to(DEV)
+    monkeypatch.setattr(torch, 'randint', lambda *a, **k: idx)        # the reference's pixel draw (RNG streams differ)
+    ct = torch.from_numpy(fx['camera_tensor']).to(DEV).requires_grad_(True)
+    opt = _RecordingOptimizer(ct)
+    ret = trk.optimize_cam_in_batch(ct, None, img['gt_color'], img['gt_depth'], img['gt_event'], img['gt_mask'],
+                                    int(fx['batch_size']), opt, 0, 0, img['pre_gt_color'], rgbd=True, event=True,
+                                    scale_factor=float(fx['scale_factor']))
+    assert len(ret) == 10 and opt.steps == 1
+    loss_rgbd, loss_event, loss_mask, gt_event, full_event, gts, preds, terms, gt_mask, p_event = ret
+    assert np.array_equal(gt_event.cpu().numpy(), fx['gt_event_s'])
+    assert np.array_equal(gt_mask.cpu().numpy(), fx['gt_mask_s'])
+    assert rel_err(full_event.detach().cpu().numpy(), fx['full_event']) <= 1e-4
+    assert rel_err(p_event.detach().cpu().numpy(), fx['event_prob'][0, 1]) <= 1e-4
+    assert rel_err(preds[0].detach().cpu().numpy(), fx['pred_event_blur']) <= 1e-4
+    assert rel_err(gts[0].cpu().numpy(), fx['gt_event_blur']) <= 1e-5
+    assert abs(loss_rgbd - float(fx['loss_rgbd'])) <= 1e-4 * abs(float(fx['loss_rgbd']))
+    assert abs(loss_event - float(fx['loss_event'])) <= 1e-4 * abs(float(fx['loss_event']))
+    assert abs(loss_mask - float(fx['loss_mask'])) <= 1e-4 * abs(float(fx['loss_mask']))
+    assert abs(terms[1] - float(fx['loss_terms'][1])) <= 1e-4 * float(fx['loss_terms'][1])
+    assert rel_err(opt.grad.cpu().numpy(), fx['g_total']) <= 1e-3
+    assert ct.grad is None                                            # the iteration ends with zero_grad (:236)
+
+    # event term alone (rgbd=False): its own pose gradient, 100x smaller than the RGB-D one
+    opt2 = _RecordingOptimizer(ct)
+    ret = trk.optimize_cam_in_batch(ct, None, img['gt_color'], img['gt_depth'], img['gt_event'], img['gt_mask'],
+                                    int(fx['batch_size']), opt2, 0, 0, img['pre_gt_color'], rgbd=False, event=True,
+                                    scale_factor=float(fx['scale_factor']))
+    assert ret[0] is None and abs(ret[1] - float(fx['loss_event'])) <= 1e-4 * abs(float(fx['loss_event']))
+    assert rel_err(opt2.grad.cpu().numpy(), fx['g_event']) <= 1e-3
+
+    # RGB-D alone with the dynamic-object mask (:180-182)
+    opt3 = _RecordingOptimizer(ct)
+    ret = trk.optimize_cam_in_batch(ct, None, img['gt_color'], img['gt_depth'], None, None, int(fx['batch_size']), opt3,
+                                    0, 0, None, rgbd=True, event=False)
+    assert ret[1] is None and ret[2] is None and ret[4] is None
+    assert abs(ret[0] - float(fx['loss_rgbd'])) <= 1e-4 * abs(float(fx['loss_rgbd']))
+    assert rel_err(opt3.grad.cpu().numpy(), fx['g_rgbd']) <= 1e-3
+
+
+def test_event_iteration_switches(monkeypatch):
+    """activate_events off: the event loss is reported but not back-propagated (:231); blur off: 7-tuple."""
+    fx = load("tiny_event_iter")
+    trk, img, DEV = _setup(fx, blur=False, activate=False)
+    idx = torch.from_numpy(fx['idx']).to(DEV)
+    monkeypatch.setattr(torch, 'randint', lambda *a, **k: idx)
+    ct = torch.from_numpy(fx['camera_tensor']).to(DEV).requires_grad_(True)
+    opt = _RecordingOptimizer(ct)
+    ret = trk.optimize_cam_in_batch(ct, None, img['gt_color'], img['gt_depth'], img['gt_event'], img['gt_mask'],
+                                    int(fx['batch_size']), opt, 0, 0, img['pre_gt_color'], rgbd=True, event=True,
+                                    scale_factor=float(fx['scale_factor']))
+    assert len(ret) == 7
+    l2 = float(((fx['gt_event_s'].astype(np.float64) - fx['full_event']) ** 2).sum()) * float(fx['balancer'])
+    assert abs(ret[1] - l2) <= 1e-4 * l2
+    assert rel_err(opt.grad.cpu().numpy(), fx['g_rgbd']) <= 1e-3
+    trk.event_net = None
+    with pytest.raises(RuntimeError):
+        trk.optimize_cam_in_batch(ct, None, img['gt_color'], img['gt_depth'], img['gt_event'], img['gt_mask'],
+                                  int(fx['batch_size']), opt, 0, 0, img['pre_gt_color'], rgbd=True, event=True)
