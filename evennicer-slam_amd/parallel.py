@@ -139,3 +139,59 @@ class ShardedRenderer:
         finally:
             self.renderer.depth_max_override = prev
         return out, slice(lo, hi)
+
+    def render_img_rescale(self, c, decoders, c2w, device, stage, gt_depth=None, scale_factor=0.1):
+        """`Renderer.render_img_rescale` (Renderer.py:258-319) with every chunk's rays split over the ranks: each rank
+        renders its block (with gradient), the blocks are all-gathered into the full images, identical on every
+        rank, so a replicated consumer (the event U-Net and its loss, Tracker.py:150-232) runs unchanged.  In the
+        backward pass a rank keeps the gradient rows of its own block; `allreduce_gradients([camera_tensor])` then
+        sums the ranks' pose gradients."""
+        from .common import get_rays_rescale
+        from .event import resize_bilinear
+        r = self.renderer
+        H, W = r.H, r.W
+        new_H, new_W = int(H * scale_factor), int(W * scale_factor)
+        rays_o, rays_d = get_rays_rescale(H, W, new_H, new_W, r.fx, r.fy, r.cx, r.cy, c2w, device)
+        rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+        gd = resize_bilinear(gt_depth[None].float(), (new_H, new_W)).reshape(-1) if gt_depth is not None else None
+        depths, uncs, colors = [], [], []
+        step = r.ray_batch_size
+        for i in range(0, rays_d.shape[0], step):                      # the reference's chunks (per-chunk depth maxima)
+            g = gd[i:i + step] if gd is not None else None
+            (d, u, col), sl = self.render_batch_ray(c, decoders, rays_d[i:i + step], rays_o[i:i + step], device, stage,
+                                                    gt_depth=g)
+            n = min(step, rays_d.shape[0] - i)
+            packed = torch.cat([d.double()[:, None], u.double()[:, None], col.double()], dim=1)     # one collective per chunk
+            full = gather_blocks(packed, n, self.rank, self.world, self.group)
+            depths.append(full[:, 0])
+            uncs.append(full[:, 1])
+            colors.append(full[:, 2:5].to(col.dtype))
+        depth, unc, color = torch.cat(depths), torch.cat(uncs), torch.cat(colors)
+        return depth.reshape(new_H, new_W), unc.reshape(new_H, new_W), color.reshape(new_H, new_W, 3)
+
+
+class _GatherBlocks(torch.autograd.Function):
+    """All-gather of the ranks' row blocks (`shard_range` split of n rows) into the full [n, C] tensor.  Backward:
+    every rank holds the same gradient of the replicated consumer, so it keeps the rows of its own block."""
+
+    @staticmethod
+    def forward(ctx, block, n, rank, world, group):
+        sizes = [shard_range(n, k, world) for k in range(world)]
+        width = max(hi - lo for lo, hi in sizes)
+        pad = torch.zeros((width,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+        pad[:block.shape[0]] = block.detach()
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        ctx.own = sizes[rank]
+        return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        lo, hi = ctx.own
+        return g[lo:hi], None, None, None, None
+
+
+def gather_blocks(block, n, rank, world, group=None):
+    if world == 1:
+        return block
+    return _GatherBlocks.apply(block, n, rank, world, group)

@@ -130,3 +130,79 @@ def test_block_sparse_bucket_sums_only_touched_blocks():
         assert np.array_equal(o['other'], np.full((3, 2), 3.0, dtype=np.float32))
         # blocks 1 and 4 (whole) + the partial block of 1 voxel + the 6 floats of `other`
         assert o['nbytes'] == 4 * (4 * 2 * 64 + 4 * 1 + 6)
+
+
+def _img_inputs():
+    g = torch.Generator().manual_seed(11)
+    H, W = 48, 64
+    depth_img = torch.rand(H, W, generator=g) * 1.4 + 0.2
+    depth_img[20:24, :] = 0.0
+    th = 0.3
+    c2w = torch.tensor([[np.cos(th), 0, np.sin(th), 0.1], [0, 1, 0, -0.05], [-np.sin(th), 0, np.cos(th), 0.2]],
+                       dtype=torch.float32)
+    wts = torch.rand(12, 16, 3, generator=g)
+    return depth_img, c2w, wts
+
+
+def _img_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from evennicer_slam_amd.parallel import ShardedRenderer, allreduce_gradients
+        params, grids, bound, s = tiny_scene()
+        depth_img, c2w, wts = _img_inputs()
+        c2w.requires_grad_(True)
+        inner = _OracleRenderer(params, bound)
+        inner.H, inner.W, inner.fx, inner.fy, inner.cx, inner.cy, inner.ray_batch_size = 48, 64, 50.0, 50.0, 31.5, 23.5, 80
+        sr = ShardedRenderer(inner)
+        depth, unc, color = sr.render_img_rescale(grids, None, c2w, 'cpu', 'color', gt_depth=depth_img, scale_factor=0.25)
+        loss = (color * wts).sum() + 0.1 * depth.sum()              # a replicated consumer of the full image
+        loss.backward()
+        own = c2w.grad.clone()
+        allreduce_gradients([c2w])
+        q.put({'rank': rank, 'color': color.detach().numpy(), 'depth': depth.detach().numpy(), 'own': own.numpy(),
+               'g': c2w.grad.numpy().copy()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_row_sharded_image_render_matches_unsharded():
+    """render_img_rescale sharded over 2 ranks (3 chunks of 80/80/32 rays, each split 40+40 / 16+16): gathered image
+    and summed pose gradient equal the unsharded chunk loop (Renderer.py:296-318)."""
+    from oracle import render_oracle as R
+    from evennicer_slam_amd.common import get_rays_rescale
+    from oracle.event_oracle import resize_bilinear
+    world, port = 2, 33500 + (os.getpid() % 2000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_img_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    params, grids, bound, s = tiny_scene()
+    depth_img, c2w, wts = _img_inputs()
+    c2w.requires_grad_(True)
+    ro, rd = get_rays_rescale(48, 64, 12, 16, 50.0, 50.0, 31.5, 23.5, c2w, 'cpu')
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    gd = torch.from_numpy(resize_bilinear(depth_img.numpy()[None], (12, 16)).reshape(-1))
+    ds, cs = [], []
+    for i in range(0, 192, 80):
+        d, v, col = R.render_batch_ray(params, grids, rd[i:i + 80], ro[i:i + 80], 'color', bound, gt_depth=gd[i:i + 80])
+        ds.append(d.double())
+        cs.append(col)
+    depth, color = torch.cat(ds).reshape(12, 16), torch.cat(cs).reshape(12, 16, 3)
+    ((color * wts).sum() + 0.1 * depth.sum()).backward()
+    want = c2w.grad.numpy()
+    for o in outs:
+        # (CPU GEMMs round differently for different batch sizes: tolerance instead of bit equality)
+        assert np.abs(o['color'] - color.detach().numpy()).max() <= 1e-5
+        assert np.abs(o['depth'] - depth.detach().numpy()).max() <= 1e-5
+        assert np.abs(o['g'] - want).max() <= 1e-5 * np.abs(want).max()
+    assert np.abs(outs[0]['own'] + outs[1]['own'] - want).max() <= 1e-5 * np.abs(want).max()
+    assert np.array_equal(outs[0]['color'], outs[1]['color'])                   # replicas see the identical image
+    assert np.abs(outs[0]['own'] - want).max() > 1e-3 * np.abs(want).max()      # each rank really holds only a part
