@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("ENSLAM_LIB") or os.path.join(os.path.dirname(os.path.
 STAGE = {'coarse': 0, 'middle': 1, 'fine': 2, 'color': 3}
 MLP_COARSE, MLP_MIDDLE, MLP_FINE, MLP_COLOR = 0, 1, 2, 3
 MLP_NAMES = ('coarse_decoder', 'middle_decoder', 'fine_decoder', 'color_decoder')
+MAX_SMALL_TENSORS = 72      # ENS_ADAM_MAX_TENSORS: dense tensors per adam_tensors / bucket launch
 GRID_NAMES = ('grid_coarse', 'grid_middle', 'grid_fine', 'grid_color')
 # grids / decoders read by each stage (NICE.forward, decoder.py:312-342); fine reads grid_middle twice
 STAGE_KINDS = {'coarse': (0,), 'middle': (1,), 'fine': (1, 2), 'color': (1, 2, 3)}
@@ -64,6 +65,10 @@ _SIGS = {
     "enslam_adam_tensors": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                            POINTER(c_int64), c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, c_void_p]),
+    "enslam_bucket_pack": (ctypes.c_int, [c_int32, POINTER(c_void_p), c_int32, POINTER(c_int64), POINTER(c_int32), c_void_p,
+                                          c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64), c_int64, c_void_p, c_void_p]),
+    "enslam_bucket_unpack": (ctypes.c_int, [c_int32, POINTER(c_void_p), c_int32, POINTER(c_int64), POINTER(c_int32), c_void_p,
+                                            c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64), c_int64, c_void_p, c_void_p]),
     "enslam_step_prepare": (ctypes.c_int, [c_int32, POINTER(c_int32), POINTER(MlpParams), POINTER(c_void_p),
                                            c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),
                                            POINTER(c_void_p), c_int32, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),

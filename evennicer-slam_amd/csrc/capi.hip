@@ -372,6 +372,57 @@ int enslam_adam_tensors(int32_t n, float* const* param, const float* const* grad
     return ens_launch_adam_tensors(job, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
 
+static int bucket_job(int32_t n_grids, float* const* grid_grad, int32_t channels, const int64_t* n_voxels,
+                      const int32_t* layout, const uint8_t* flags, const int32_t* pos, int32_t n_small,
+                      float* const* small, const int64_t* small_numel, int64_t small_base, float* bucket, BucketJob& job) {
+    if (n_grids < 0 || n_grids > 4 || n_small < 0 || n_small > ENS_ADAM_MAX_TENSORS) return ENSLAM_EUNSUPPORTED;
+    if (!bucket || channels < 1 || small_base < 0) return ENSLAM_EINVAL;
+    if (n_grids > 0 && (!grid_grad || !n_voxels || !layout || !flags || !pos)) return ENSLAM_EINVAL;
+    if (n_small > 0 && (!small || !small_numel)) return ENSLAM_EINVAL;
+    job.n_grids = n_grids; job.C = channels; job.flags = flags; job.pos = pos; job.bucket = bucket; job.n_small = n_small;
+    int64_t blocks = 0;
+    for (int g = 0; g < 4; ++g) { job.grid[g] = nullptr; job.V[g] = 0; job.layout[g] = 0; }
+    for (int g = 0; g < n_grids; ++g) {
+        if (!grid_grad[g] || n_voxels[g] < 0 || (layout[g] != 0 && layout[g] != 1)) return ENSLAM_EINVAL;
+        job.grid[g] = grid_grad[g]; job.V[g] = n_voxels[g]; job.layout[g] = layout[g];
+        job.blk_begin[g] = (int)blocks;
+        blocks += (n_voxels[g] + 63) / 64;
+        if (blocks > 0x3fffffff) return ENSLAM_EUNSUPPORTED;
+    }
+    for (int g = n_grids; g <= 4; ++g) job.blk_begin[g] = (int)blocks;
+    int64_t sblocks = 0, off = small_base;
+    for (int i = 0; i < n_small; ++i) {
+        if (!small[i] || small_numel[i] < 0 || small_numel[i] > 0x7fffffff) return ENSLAM_EINVAL;
+        job.small[i] = small[i]; job.numel[i] = (int)small_numel[i];
+        job.small_off[i] = off; off += small_numel[i];
+        job.small_blk_begin[i] = (int)sblocks;
+        sblocks += (small_numel[i] + 1023) / 1024;
+        if (sblocks > 0x3fffffff) return ENSLAM_EUNSUPPORTED;
+    }
+    job.small_blk_begin[n_small] = (int)sblocks;
+    return ENSLAM_OK;
+}
+int enslam_bucket_pack(int32_t n_grids, const float* const* grid_grad, int32_t channels, const int64_t* n_voxels,
+                       const int32_t* layout, const uint8_t* flags, const int32_t* pos, int32_t n_small,
+                       const float* const* small, const int64_t* small_numel, int64_t small_base, float* bucket,
+                       void* stream) {
+    BucketJob job;
+    const int rc = bucket_job(n_grids, const_cast<float* const*>(grid_grad), channels, n_voxels, layout, flags, pos, n_small,
+                              const_cast<float* const*>(small), small_numel, small_base, bucket, job);
+    if (rc != ENSLAM_OK) return rc;
+    return ens_launch_bucket(job, false, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+int enslam_bucket_unpack(int32_t n_grids, float* const* grid_grad, int32_t channels, const int64_t* n_voxels,
+                         const int32_t* layout, const uint8_t* flags, const int32_t* pos, int32_t n_small,
+                         float* const* small, const int64_t* small_numel, int64_t small_base, const float* bucket,
+                         void* stream) {
+    BucketJob job;
+    const int rc = bucket_job(n_grids, grid_grad, channels, n_voxels, layout, flags, pos, n_small, small, small_numel,
+                              small_base, const_cast<float*>(bucket), job);
+    if (rc != ENSLAM_OK) return rc;
+    return ens_launch_bucket(job, true, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+
 int enslam_mark_blocks(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                        const double* z_vals, const enslam_scene* scene, uint8_t* const* flags, void* stream) {
     if (n_rays < 0 || n_samples < 1 || stage < 0 || stage > 3) return ENSLAM_EINVAL;

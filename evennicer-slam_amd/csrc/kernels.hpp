@@ -44,6 +44,24 @@ struct AdamTensorsJob {          // torch.optim.Adam over a list of small dense 
     const double* lr;            // device scalar
     const int* step;             // device scalar (already incremented)
 };
+// Gradient bucket of the ray-sharded step (parallel.py): the touched 64-voxel blocks of up to 4 feature-grid gradients
+// followed by up to ENS_ADAM_MAX_TENSORS small dense tensors, packed into / unpacked from one flat all-reduce buffer.
+struct BucketJob {
+    float* grid[4];              // gradient of grid g: [C, V] (layout 0, the reference's [1,C,D,H,W]) or [V, C] (layout 1)
+    int64_t V[4];
+    int layout[4];
+    int blk_begin[5];            // block range of each grid inside flags / pos (ceil(V / 64) blocks per grid)
+    int n_grids, C;
+    const uint8_t* flags;        // [blk_begin[n_grids]] union over ranks of the touched blocks
+    const int* pos;              // inclusive prefix sum of flags: a flagged block b owns bucket slot pos[b] - 1 (C * 64 floats)
+    float* small[ENS_ADAM_MAX_TENSORS];
+    int numel[ENS_ADAM_MAX_TENSORS];
+    int small_blk_begin[ENS_ADAM_MAX_TENSORS + 1];      // 1024 elements per workgroup
+    int64_t small_off[ENS_ADAM_MAX_TENSORS];            // float offset of each small tensor in the bucket
+    int n_small;
+    float* bucket;
+};
+int ens_launch_bucket(const BucketJob& job, bool unpack, hipStream_t st);
 struct ConvJob {                 // up to 4 grids converted in one launch
     const float* src[4];
     float* dst[4];

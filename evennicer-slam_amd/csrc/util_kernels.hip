@@ -629,6 +629,64 @@ int ens_launch_adam(const AdamJob& job, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ------------------------------------------------------------------------------------------------
+// gradient bucket pack / unpack (ray-sharded step).  One workgroup per 64-voxel block of every grid (unflagged blocks
+// leave at once), then one per 1024 elements of the small tensors.  A block slot holds the block in the gradient's own
+// layout: [C][64] for channel-major grids (256-byte row segments), [64][C] for voxel-major ones (one contiguous run).
+// Voxels past the end of the grid (partial last block) travel as zeros.
+// ------------------------------------------------------------------------------------------------
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void bucket_kernel(BucketJob job) {
+    const int nb = job.blk_begin[job.n_grids];
+    const int b = (int)blockIdx.x;
+    if (b < nb) {
+        if (!job.flags[b]) return;
+        int g = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (k < job.n_grids && b >= job.blk_begin[k]) g = k;
+        const int C = job.C;
+        const int64_t V = job.V[g], v0 = (int64_t)(b - job.blk_begin[g]) * 64;
+        float* __restrict__ G = job.grid[g];
+        float* __restrict__ S = job.bucket + (int64_t)(job.pos[b] - 1) * C * 64;
+        if (job.layout[g] == 0) {
+            const int v = threadIdx.x & 63;
+            const bool in = v0 + v < V;
+            for (int c = threadIdx.x >> 6; c < C; c += 4) {
+                if (UNPACK) { if (in) G[(int64_t)c * V + v0 + v] = S[c * 64 + v]; }
+                else S[c * 64 + v] = in ? G[(int64_t)c * V + v0 + v] : 0.f;
+            }
+        } else {
+            const int64_t n_in = (V - v0 < 64 ? V - v0 : 64) * C;
+            for (int e = threadIdx.x; e < C * 64; e += 256) {
+                if (UNPACK) { if (e < n_in) G[v0 * C + e] = S[e]; }
+                else S[e] = e < n_in ? G[v0 * C + e] : 0.f;
+            }
+        }
+        return;
+    }
+    const int sb = b - nb;
+    int lo = 0, hi = job.n_small;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (sb >= job.small_blk_begin[mid]) lo = mid; else hi = mid;
+    }
+    float* __restrict__ T = job.small[lo];
+    float* __restrict__ S = job.bucket + job.small_off[lo];
+    const int n = job.numel[lo], e0 = (sb - job.small_blk_begin[lo]) * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j * 256 + threadIdx.x;
+        if (e >= n) continue;
+        if (UNPACK) T[e] = S[e]; else S[e] = T[e];
+    }
+}
+int ens_launch_bucket(const BucketJob& job, bool unpack, hipStream_t st) {
+    const int64_t blocks = (int64_t)job.blk_begin[job.n_grids] + (job.n_small > 0 ? job.small_blk_begin[job.n_small] : 0);
+    if (blocks <= 0) return 0;
+    if (unpack) bucket_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(job);
+    else bucket_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(job);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 int ens_launch_adam_tensors(const AdamTensorsJob& job, hipStream_t st) {
     if (job.n <= 0 || job.block_begin[job.n] <= 0) return 0;
     adam_tensors_kernel<<<dim3(job.block_begin[job.n]), dim3(256), 0, st>>>(job);

@@ -162,6 +162,25 @@ int enslam_adam_tensors(int32_t n, float *const *param, const float *const *grad
                         float *const *exp_avg_sq, const int64_t *numel, const double *lr, const int32_t *step,
                         double beta1, double beta2, double eps, void *stream);
 
+/* Gradient bucket of the ray-sharded step (new functionality, SURVEY.md 8e: the reference has no multi-GPU path; the
+ * tensors are the leaf gradients of Mapper.py:573-575).  Packs into / unpacks from one flat all-reduce buffer:
+ *   - of up to 4 feature-grid gradients with `channels` channels each -- layout[g] 0: [channels, n_voxels[g]] (the
+ *     reference's [1,C,D,H,W]), 1: voxel-major [n_voxels[g], channels] -- only the 64-voxel blocks whose flag is set.
+ *     flags (uint8) and pos (int32, the INCLUSIVE prefix sum of flags) run over the blocks of all grids concatenated,
+ *     ceil(n_voxels[g] / 64) per grid; flagged block b occupies bucket floats [(pos[b]-1) * channels * 64, +channels*64)
+ *     in the gradient's own layout ([channels][64] or [64][channels]); voxels past the end of a grid travel as zeros;
+ *   - then n_small (<= 72) dense tensors, concatenated from float offset small_base on.
+ * The flags must be the union over ranks (so every rank lays the bucket out identically); unpack writes only the
+ * flagged blocks and the small tensors. */
+int enslam_bucket_pack(int32_t n_grids, const float *const *grid_grad, int32_t channels, const int64_t *n_voxels,
+                       const int32_t *layout, const uint8_t *flags, const int32_t *pos, int32_t n_small,
+                       const float *const *small, const int64_t *small_numel, int64_t small_base, float *bucket,
+                       void *stream);
+int enslam_bucket_unpack(int32_t n_grids, float *const *grid_grad, int32_t channels, const int64_t *n_voxels,
+                         const int32_t *layout, const uint8_t *flags, const int32_t *pos, int32_t n_small,
+                         float *const *small, const int64_t *small_numel, int64_t small_base, const float *bucket,
+                         void *stream);
+
 /* The small independent jobs around a render call in ONE launch each (they are 4-6 us kernels when issued separately):
  * enslam_step_prepare = enslam_pack_mlp_multi (n_dec decoders) + enslam_grids_convert_sparse to voxel-major (n_conv
  *   grids) + enslam_zero_blocks (n_zero accumulators and the flat range); any of the three parts may be empty.

@@ -1,0 +1,146 @@
+"""-m gpu: the gradient bucket of the ray-sharded step (enslam_bucket_pack / _unpack through the C ABI, and
+parallel.allreduce_gradients on HIP tensors over a 2-rank gloo group sharing the one GPU)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _arrs(items, ctype):
+    return (ctype * max(len(items), 1))(*items)
+
+
+def test_bucket_pack_unpack_roundtrip_and_layout():
+    from evennicer_slam_amd import _lib as L
+    from evennicer_slam_amd.functional import _ptr, _stream
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(0)
+    C = 32
+    shapes = [(5, 7, 11), (4, 8, 8), (3, 5, 13)]                    # 385 (partial last block), 256, 195 voxels
+    Vs = [a * b * c for a, b, c in shapes]
+    grads = [torch.randn(1, C, *shapes[0], generator=g).to(dev), torch.randn(Vs[1], C, generator=g).to(dev),
+             torch.randn(1, C, *shapes[2], generator=g).to(dev)]
+    layout = [0, 1, 0]
+    nblk = [(v + 63) // 64 for v in Vs]
+    flags = (torch.rand(sum(nblk), generator=g) < 0.5).to(torch.uint8)
+    flags[nblk[0] - 1] = 1                                           # the partial block of grid 0 travels
+    flags[sum(nblk) - 1] = 1                                         # ... and of grid 2
+    flags = flags.to(dev)
+    pos = torch.cumsum(flags, 0, dtype=torch.int32)
+    n_slots = int(pos[-1])
+    small = [torch.randn(n, generator=g).to(dev) for n in [1, 3, 1024, 1025, 4096 * 3 + 5] + [7] * 80]   # 85 tensors: two launches
+    n_small = sum(t.numel() for t in small)
+    bucket = torch.full((n_slots * C * 64 + n_small,), float('nan'), device=dev)
+    lib = L.lib()
+
+    def run(fn, grid_tensors, small_tensors, buf):
+        base, first = n_slots * C * 64, True
+        for lo in range(0, len(small_tensors), 72):
+            part = small_tensors[lo:lo + 72]
+            L.check(fn(3 if first else 0, _arrs([t.data_ptr() for t in grid_tensors], ctypes.c_void_p), C,
+                       _arrs(Vs, ctypes.c_int64), _arrs(layout, ctypes.c_int32), _ptr(flags), _ptr(pos), len(part),
+                       _arrs([t.data_ptr() for t in part], ctypes.c_void_p), _arrs([t.numel() for t in part], ctypes.c_int64),
+                       base, _ptr(buf), _stream()), "bucket")
+            base += sum(t.numel() for t in part)
+            first = False
+
+    run(lib.enslam_bucket_pack, grads, small, bucket)
+    torch.cuda.synchronize()
+    # expected bucket, block by block
+    want = []
+    fl = flags.cpu().numpy()
+    b0 = 0
+    for gi, (gr, V, lay) in enumerate(zip(grads, Vs, layout)):
+        a = gr.cpu().numpy()
+        a = a.reshape(C, V) if lay == 0 else a                       # [C,V] | [V,C]
+        for b in range(nblk[gi]):
+            if not fl[b0 + b]:
+                continue
+            lo, hi = b * 64, min(V, b * 64 + 64)
+            slot = np.zeros((C, 64), np.float32) if lay == 0 else np.zeros((64, C), np.float32)
+            if lay == 0:
+                slot[:, :hi - lo] = a[:, lo:hi]
+            else:
+                slot[:hi - lo] = a[lo:hi]
+            want.append(slot.reshape(-1))
+        b0 += nblk[gi]
+    want += [t.cpu().numpy() for t in small]
+    assert np.array_equal(bucket.cpu().numpy(), np.concatenate(want))
+    # unpack 2 x bucket into zeroed copies: flagged blocks and small tensors doubled, everything else untouched (zero)
+    outs = [torch.zeros_like(t) for t in grads]
+    souts = [torch.full_like(t, 5.0) for t in small]
+    run(lib.enslam_bucket_unpack, outs, souts, bucket * 2)
+    torch.cuda.synchronize()
+    b0 = 0
+    for gi, (gr, o, V, lay) in enumerate(zip(grads, outs, Vs, layout)):
+        vmask = np.repeat(fl[b0:b0 + nblk[gi]], 64)[:V].astype(bool)
+        a, r = gr.cpu().numpy(), o.cpu().numpy()
+        if lay == 0:
+            assert np.array_equal(r.reshape(C, V), a.reshape(C, V) * 2 * vmask[None, :])
+        else:
+            assert np.array_equal(r, a * 2 * vmask[:, None])
+        b0 += nblk[gi]
+    for t, o in zip(small, souts):
+        assert torch.equal(o, t * 2)
+    # argument errors come back as status codes
+    assert lib.enslam_bucket_pack(5, None, C, None, None, None, None, 0, None, None, 0, _ptr(bucket), _stream()) != 0
+    assert lib.enslam_bucket_pack(0, None, C, None, None, None, None, 0, None, None, 0, None, _stream()) != 0
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from evennicer_slam_amd.parallel import allreduce_gradients
+        from evennicer_slam_amd.functional import VoxelMajorGrid
+        dev = 'cuda:0'
+        g = torch.Generator().manual_seed(5 + rank)
+        grid = torch.zeros(1, 32, 5, 7, 11, device=dev).requires_grad_(True)       # 385 voxels
+        V = 385
+        grad = torch.zeros(32, V)
+        for b in ([1, 4] if rank == 0 else [4, 6]):                                # rank 1 touches the partial block
+            lo, hi = b * 64, min(V, b * 64 + 64)
+            grad[:, lo:hi] = torch.randn(32, hi - lo, generator=g)
+        grid.grad = grad.view(1, 32, 5, 7, 11).to(dev)
+        vm_grad = torch.zeros(256, 32)
+        vm_grad[64 * (rank + 1):64 * (rank + 2)] = torch.randn(64, 32, generator=g)
+        vmg = VoxelMajorGrid((4, 8, 8), torch.zeros(256, 32, device=dev), vm_grad.to(dev))
+        other = torch.zeros(3, 2, device=dev).requires_grad_(True)
+        other.grad = torch.full((3, 2), float(rank + 1), device=dev)
+        unused = torch.zeros(4, device=dev).requires_grad_(True)                   # grad None on both ranks
+        nbytes = allreduce_gradients([grid, vmg, other, unused])
+        torch.cuda.synchronize()
+        q.put({'rank': rank, 'nbytes': nbytes, 'grid': grid.grad.cpu().numpy(), 'own': grad.numpy(),
+               'vm': vmg.grad_vm.cpu().numpy(), 'own_vm': vm_grad.numpy(), 'other': other.grad.cpu().numpy(),
+               'unused': unused.grad.cpu().numpy()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_of_hip_gradients():
+    import torch.multiprocessing as mp
+    world, port = 2, 35500 + (os.getpid() % 2000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=600) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = (outs[0]['own'] + outs[1]['own']).reshape(1, 32, 5, 7, 11)
+    want_vm = outs[0]['own_vm'] + outs[1]['own_vm']
+    for o in outs:
+        assert np.array_equal(o['grid'], want)
+        assert np.array_equal(o['vm'], want_vm)
+        assert np.array_equal(o['other'], np.full((3, 2), 3.0, dtype=np.float32))
+        assert np.array_equal(o['unused'], np.zeros(4, np.float32))
+        # grid: blocks 1, 4, 6 (partial, always sent); voxel-major grid: blocks 1, 2; small: 6 + 4 floats
+        assert o['nbytes'] == 4 * (32 * 64 * (3 + 2) + 10)
