@@ -171,6 +171,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
+    # rehearsal of the communication path on ONE rank with real RCCL (collectives of a 1-rank group): not a measurement
+    force_comm = world == 1 and os.environ.get('ENSLAM_BENCH_FORCE_COMM') == '1'
+    if force_comm:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29777')
+        dist.init_process_group(backend, rank=0, world_size=1, **({'device_id': dev} if backend == 'nccl' else {}))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
@@ -198,13 +204,14 @@ def main():
     for k in kinds:
         leaves += list(getattr(model, E._lib.MLP_NAMES[k]).parameters())
 
-    dmax_static = PAR.global_depth_max(gd) if (world > 1 and stage != 'coarse') else None
+    comm_on = world > 1 or force_comm
+    dmax_static = PAR.global_depth_max(gd, force=force_comm) if (comm_on and stage != 'coarse') else None
     if dmax_static is not None:
         renderer.depth_max_override = dmax_static
 
     def pre():          # batch-global sampler maxima over all shards (tiny MAX all-reduce), kept outside the graph
         if dmax_static is not None:
-            dmax_static.copy_(PAR.global_depth_max(gd))
+            dmax_static.copy_(PAR.global_depth_max(gd, force=force_comm))
 
     seed_grad, comm = {}, {'bytes': 0}
 
@@ -227,8 +234,8 @@ def main():
         return loss
 
     def post():         # one bucketed RCCL all-reduce of the leaf gradients
-        if world > 1:
-            comm['bytes'] = PAR.allreduce_gradients(leaves, block_flags=EF.last_block_flags())
+        if comm_on:
+            comm['bytes'] = PAR.allreduce_gradients(leaves, block_flags=EF.last_block_flags(), force=force_comm)
 
     def step():
         pre()
@@ -290,14 +297,41 @@ def main():
         if gstep is None:
             elapsed, loss = timed(step, args.steps)
         else:
+            phases = [0.0, 0.0, 0.0] if os.environ.get('ENSLAM_BENCH_PHASES') == '1' else None
+
             def graph_step():
-                pre()
-                out = gstep.replay()
-                post()
+                if phases is None:
+                    pre()
+                    out = gstep.replay()
+                    post()
+                    return out
+                # diagnostic: host-synchronised time of the three phases (changes the timing; not a measurement)
+                for i, fn in enumerate((pre, gstep.replay, post)):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    r = fn()
+                    torch.cuda.synchronize()
+                    phases[i] += time.perf_counter() - t0
+                    if i == 1:
+                        out = r
                 return out
 
             mode = 'hipgraph'
-            elapsed, loss = timed(graph_step, args.steps)
+            if comm_on:
+                # Replays and eager collectives interleave on one stream; if that ever behaves badly on a node (it did
+                # when two ranks of a rehearsal shared one GPU), fall back to the Python-driven step.  Both modes do
+                # the same work; the choice is made on max-over-ranks times, so every rank takes the same branch.
+                trial = min(10, args.steps)
+                tg, _l = timed(graph_step, trial)
+                te, _l = timed(step, trial)
+                del _l
+                if rank == 0 and os.environ.get('ENSLAM_BENCH_PHASES'):
+                    print(f"[bench] trial: graph {tg / trial * 1e3:.3f} ms/step, eager {te / trial * 1e3:.3f} ms/step", file=sys.stderr)
+                if te < tg:
+                    mode = 'eager'
+                    for t in leaves:
+                        t.grad = None
+            elapsed, loss = timed(graph_step if mode == 'hipgraph' else step, args.steps)
 
     S = 48 if stage != 'coarse' else 32
     n_points = args.rays * S
@@ -330,9 +364,12 @@ def main():
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc, rays_cpu, stage)
+    if rank == 0 and not args.eager and mode == 'hipgraph' and gstep is not None and phases is not None:
+        print("[bench] phases ms/step: depth-max all-reduce %.3f, graph replay %.3f, gradient all-reduce %.3f"
+              % tuple(p / args.steps * 1e3 for p in phases), file=sys.stderr)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_comm:
         dist.destroy_process_group()
 
 

@@ -17,10 +17,11 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def global_depth_max(gt_depth_local, group=None):
-    """float32 [2] {max, fl32(max*1.2)} of gt_depth over all ranks' shards (one tiny MAX all-reduce)."""
+def global_depth_max(gt_depth_local, group=None, force=False):
+    """float32 [2] {max, fl32(max*1.2)} of gt_depth over all ranks' shards (one tiny MAX all-reduce).
+    force: issue the collective even in a 1-rank group (rehearsals)."""
     m = gt_depth_local.detach().float().max().reshape(1)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
     return torch.cat([m, m * 1.2]).contiguous()
 
@@ -52,7 +53,7 @@ def _block_views(g):
     return main, tail
 
 
-def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=None):
+def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=None, force=False):
     """Sum `.grad` of the given leaf tensors over ranks through one flat bucket (one SUM collective per step).
     Leaves whose grad is None on this rank contribute zeros, so every rank issues the same collectives.
 
@@ -60,10 +61,10 @@ def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=Non
     compact_grids the bucket carries, per grid, only the union over ranks of those blocks: one small MAX
     all-reduce of the block flags (block_flags: {id(tensor): uint8 flags}, normally functional.last_block_flags();
     derived from the gradients when absent), a gather of the flagged blocks, the SUM all-reduce, a scatter back.
-    Returns the bucket size in bytes."""
+    Returns the bucket size in bytes.  force: run the whole sequence even in a 1-rank group (rehearsals)."""
     from .functional import VoxelMajorGrid
     tensors = [t for t in tensors if t is not None and (isinstance(t, VoxelMajorGrid) or t.requires_grad)]
-    if not tensors or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not tensors or not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return 0
     for t in tensors:
         if not isinstance(t, VoxelMajorGrid) and t.grad is None:
