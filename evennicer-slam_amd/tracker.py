@@ -119,6 +119,98 @@ class TrackerIteration(object):
         _, _, color = self.renderer._render_chunks(self.c, self.decoders, rays_o, rays_d, self.device, 'color', gd)
         return color.reshape(new_H, new_W, 3)
 
+    def _bound_on(self, device):
+        """the scene bound on the rays' device (copied once: a host-to-device copy cannot be captured in a hipGraph)"""
+        b = getattr(self, '_bound_dev', None)
+        if b is None or b.device != device:
+            b = self._bound_dev = self.bound.to(device)
+        return b
+
+    def prepare_event_frame(self, gt_event, gt_mask, pre_gt_color, scale_factor):
+        """The per-frame part of the event term (Tracker.py:129-137,146): ground-truth events, event mask and the
+        previous colour image at the event resolution.  Constant over the camera iterations of a frame."""
+        from . import event as EV
+        g = gt_event.permute(2, 0, 1)
+        _, h, w = g.shape
+        size = (int(scale_factor * h), int(scale_factor * w))
+        if size[0] <= 0 or size[1] <= 0:
+            raise AssertionError('Scale is too small, resized images would have no pixels')
+        return (EV.resize_nearest(g, size).permute(1, 2, 0), EV.resize_nearest(gt_mask[None, :, :], size).permute(1, 2, 0),
+                EV.resize_nearest(pre_gt_color.permute(2, 0, 1), size).permute(1, 2, 0))
+
+    def _rgbd_loss(self, camera_tensor, gt_color, gt_depth, batch_size, static_shapes):
+        """RGB-D term of one iteration (Tracker.py:160-195).  static_shapes: no boolean indexing (hipGraph capture) --
+        rays the reference drops are rendered but carry no loss, and the sampler's batch maxima are taken over the
+        kept rays, so the kept rays get exactly the samples of the reference's filtered batch."""
+        from .losses import tracker_loss
+        device = self.device
+        H, W, fx, fy, cx, cy = self.H, self.W, self.fx, self.fy, self.cx, self.cy
+        Wedge, Hedge = self.ignore_edge_W, self.ignore_edge_H
+        ro, rd, b_depth, b_color = get_samples_from_camera_tensor(Hedge, H - Hedge, Wedge, W - Wedge, batch_size, H, W,
+                                                                  fx, fy, cx, cy, camera_tensor, gt_depth, gt_color, device)
+        inside = None
+        if self.nice:                                                                               # :164-174
+            with torch.no_grad():
+                t = (self._bound_on(ro.device).unsqueeze(0) - ro.detach().unsqueeze(-1)) / rd.detach().unsqueeze(-1)
+                t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
+                inside = t >= b_depth
+            if not static_shapes:
+                rd, ro, b_depth, b_color = rd[inside], ro[inside], b_depth[inside], b_color[inside]
+                inside = None
+        prev = self.renderer.depth_max_override
+        if inside is not None:
+            m = torch.where(inside, b_depth.float(), b_depth.new_zeros(()).float()).max().reshape(1)
+            self.renderer.depth_max_override = torch.cat([m, m * 1.2]).contiguous()
+        try:
+            depth, uncertainty, color = self.renderer.render_batch_ray(self.c, self.decoders, rd, ro, device, stage='color',
+                                                                       gt_depth=b_depth)
+        finally:
+            self.renderer.depth_max_override = prev
+        uncertainty = uncertainty.detach()
+        keep = inside
+        if self.handle_dynamic:                                                                     # :180-182
+            with torch.no_grad():
+                tmp = torch.abs(b_depth - depth) / torch.sqrt(uncertainty + 1e-10)
+                if inside is None:
+                    med = tmp.median()
+                else:               # median (lower middle, like torch.median) over the kept rays, without a dynamic shape
+                    srt = torch.sort(torch.where(inside, tmp, torch.full_like(tmp, float('inf')))).values
+                    med = srt.gather(0, ((inside.sum() - 1) // 2).clamp(min=0).reshape(1))[0]
+                dyn = tmp < 10 * med
+                keep = dyn if keep is None else (keep & dyn)
+        gd_loss = b_depth if keep is None else torch.where(keep, b_depth, torch.zeros_like(b_depth))   # the loss keeps gt_depth > 0
+        return tracker_loss(depth, uncertainty, color, gd_loss, b_color, self.w_color_loss,
+                            use_color=self.use_color_in_tracking)                                   # :187-195
+
+    def iteration_losses(self, camera_tensor, gt_color, gt_depth, frame, batch_size, rgbd=True, event=True,
+                         scale_factor=0.1, static_shapes=False):
+        """Loss tensors of one camera iteration, nothing synchronised: dict with `total` (what is back-propagated;
+        None when nothing is), `rgbd`, `event` (balanced), `mask`, `full_event`, `event_mask`, `gts_blurred`,
+        `preds_blurred`, `terms`.  `frame` = prepare_event_frame(...) (needed when event)."""
+        from . import event as EV
+        out = dict(total=None, rgbd=None, event=None, mask=None, full_event=None, event_mask=None, gts_blurred=[],
+                   preds_blurred=[], terms=[])
+        if event:
+            if self.event_net is None:
+                raise RuntimeError("event=True needs slam.event_net")
+            gt_event, gt_mask, full_color_previous = frame
+            if self.low_gpu_mem and not static_shapes:
+                torch.cuda.empty_cache()
+            full_color_current = self._render_rescaled(camera_tensor, gt_depth, scale_factor)      # :150
+            out['full_event'], out['event_mask'] = EV.inference_event(
+                net=self.event_net, img1=full_color_previous, img2=full_color_current, device=self.device, scale_factor=1.0,
+                out_threshold=0.5)                                                                  # :153
+        if rgbd:
+            out['rgbd'] = out['total'] = self._rgbd_loss(camera_tensor, gt_color, gt_depth, batch_size, static_shapes)
+        if event:
+            loss_event, out['gts_blurred'], out['preds_blurred'], out['terms'] = EV.event_loss(     # :206-221
+                gt_event, out['full_event'], self.blur, self.kernel_sizes, self.unblurred_weight, self.kernel_weights)
+            out['mask'] = torch.nn.functional.cross_entropy(out['event_mask'], gt_mask.permute(2, 0, 1).long())   # :224-225
+            out['event'] = loss_event * self.cfg['event']['balancer']                               # :228-229
+            if self.activate_events:
+                out['total'] = out['event'] if out['total'] is None else out['total'] + out['event'].to(out['total'].dtype)
+        return out
+
     def optimize_cam_in_batch(self, camera_tensor, pre_c2w, gt_color, gt_depth, gt_event, gt_mask, batch_size, optimizer,
                               idx, iter, pre_gt_color, rgbd=True, event=True, scale_factor=0.1):
         """One camera iteration (Tracker.py:104-245): sample pixels, render, RGB-D loss and/or event loss, backward,
@@ -127,72 +219,60 @@ class TrackerIteration(object):
         blur on : (loss_rgbd, loss_event, loss_mask, gt_event, full_event, gts_blurred, preds_blurred, term_values,
                    gt_mask, P(event)[h,w]).  With `event=False` the event entries are None (the reference raises a
         NameError on its undefined lists in that case when blur is on)."""
-        from . import event as EV
-        from .losses import tracker_loss
-        device = self.device
-        H, W, fx, fy, cx, cy = self.H, self.W, self.fx, self.fy, self.cx, self.cy
         optimizer.zero_grad()
-        full_event = event_mask = None
-        gts_event_list, preds_event_list, losses_event_list = [], [], []
+        frame = None
         if event:
-            if self.event_net is None:
-                raise RuntimeError("event=True needs slam.event_net")
-            g = gt_event.permute(2, 0, 1)
-            _, h, w = g.shape
-            size = (int(scale_factor * h), int(scale_factor * w))
-            if size[0] <= 0 or size[1] <= 0:
-                raise AssertionError('Scale is too small, resized images would have no pixels')
-            gt_event = EV.resize_nearest(g, size).permute(1, 2, 0)                                  # :133-134
-            gt_mask = EV.resize_nearest(gt_mask[None, :, :], size).permute(1, 2, 0)                 # :137
-            full_color_previous = EV.resize_nearest(pre_gt_color.permute(2, 0, 1), size).permute(1, 2, 0)   # :146
-            if self.low_gpu_mem:
-                torch.cuda.empty_cache()
-            full_color_current = self._render_rescaled(camera_tensor, gt_depth, scale_factor)      # :150
-            full_event, event_mask = EV.inference_event(net=self.event_net, img1=full_color_previous,
-                                                        img2=full_color_current, device=device, scale_factor=1.0,
-                                                        out_threshold=0.5)                           # :153
-        total = None
-        loss_rgbd = None
-        if rgbd:
-            Wedge, Hedge = self.ignore_edge_W, self.ignore_edge_H
-            ro, rd, b_depth, b_color = get_samples_from_camera_tensor(Hedge, H - Hedge, Wedge, W - Wedge, batch_size, H, W,
-                                                                      fx, fy, cx, cy, camera_tensor, gt_depth, gt_color, device)
-            if self.nice:                                                                           # :164-174
-                with torch.no_grad():
-                    t = (self.bound.unsqueeze(0).to(device) - ro.detach().unsqueeze(-1)) / rd.detach().unsqueeze(-1)
-                    t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
-                    inside = t >= b_depth
-                rd, ro, b_depth, b_color = rd[inside], ro[inside], b_depth[inside], b_color[inside]
-            depth, uncertainty, color = self.renderer.render_batch_ray(self.c, self.decoders, rd, ro, device, stage='color',
-                                                                       gt_depth=b_depth)
-            uncertainty = uncertainty.detach()
-            gd_loss = b_depth
-            if self.handle_dynamic:                                                                 # :180-182
-                with torch.no_grad():
-                    tmp = torch.abs(b_depth - depth) / torch.sqrt(uncertainty + 1e-10)
-                    keep = tmp < 10 * tmp.median()
-                    gd_loss = torch.where(keep, b_depth, torch.zeros_like(b_depth))                 # the loss keeps gt_depth > 0
-            loss_rgbd = tracker_loss(depth, uncertainty, color, gd_loss, b_color, self.w_color_loss,
-                                     use_color=self.use_color_in_tracking)                           # :187-195
-            total = loss_rgbd
-        loss_event = loss_mask = None
-        if event:
-            loss_event, gts_event_list, preds_event_list, terms = EV.event_loss(                    # :206-221
-                gt_event, full_event, self.blur, self.kernel_sizes, self.unblurred_weight, self.kernel_weights)
-            losses_event_list = terms
-            loss_mask = torch.nn.functional.cross_entropy(event_mask, gt_mask.permute(2, 0, 1).long())      # :224-225
-            loss_event = loss_event * self.cfg['event']['balancer']                                 # :228-229
-            if self.activate_events:
-                total = loss_event if total is None else total + loss_event.to(total.dtype)
-        if total is not None and total.requires_grad:
-            total.backward()                                                                        # :197-199,231-232
+            frame = self.prepare_event_frame(gt_event, gt_mask, pre_gt_color, scale_factor)
+            gt_event, gt_mask = frame[0], frame[1]
+        o = self.iteration_losses(camera_tensor, gt_color, gt_depth, frame, batch_size, rgbd, event, scale_factor)
+        if o['total'] is not None and o['total'].requires_grad:
+            o['total'].backward()                                                                   # :197-199,231-232
         optimizer.step()
         optimizer.zero_grad()
         item = lambda x: None if x is None else float(x.item())
-        loss_rgbd_item, loss_event_item, loss_mask_item = item(loss_rgbd), item(loss_event), item(loss_mask)
-        p_event = event_mask[0][1] if event_mask is not None else None
+        loss_rgbd_item, loss_event_item, loss_mask_item = item(o['rgbd']), item(o['event']), item(o['mask'])
+        p_event = o['event_mask'][0][1] if o['event_mask'] is not None else None
         if event and not self.blur:
-            return loss_rgbd_item, loss_event_item, loss_mask_item, gt_event, full_event, gt_mask, p_event
-        losses_event_list = [float(x.item()) if torch.is_tensor(x) else float(x) for x in losses_event_list]
-        return (loss_rgbd_item, loss_event_item, loss_mask_item, gt_event, full_event, gts_event_list, preds_event_list,
-                losses_event_list, gt_mask, p_event)
+            return loss_rgbd_item, loss_event_item, loss_mask_item, gt_event, o['full_event'], gt_mask, p_event
+        terms = [float(x.item()) if torch.is_tensor(x) else float(x) for x in o['terms']]
+        return (loss_rgbd_item, loss_event_item, loss_mask_item, gt_event, o['full_event'], o['gts_blurred'],
+                o['preds_blurred'], terms, gt_mask, p_event)
+
+
+class GraphedCameraIteration(object):
+    """The camera iterations of one frame as replays of ONE hipGraph (zero_grad -> losses -> backward -> optimiser
+    step), using the static-shape formulation of `TrackerIteration.iteration_losses`.  `optimizer` must be capturable
+    (`mapper.FusedAdam`).  Per frame: `set_frame(images...)` copies the images into the graph's input buffers and
+    prepares the event-resolution ground truth; per iteration: `step()` returns the (device) loss tensors."""
+
+    def __init__(self, trk, camera_tensor, optimizer, gt_color, gt_depth, gt_event=None, gt_mask=None, pre_gt_color=None,
+                 batch_size=200, rgbd=True, event=True, scale_factor=0.1, warmup=3):
+        from .graph import GraphedStep
+        self.trk, self.event, self.scale_factor = trk, event, scale_factor
+        self.gt_color, self.gt_depth = gt_color.clone(), gt_depth.clone()
+        self.frame = None
+        if event:
+            self.frame = tuple(t.clone() for t in trk.prepare_event_frame(gt_event, gt_mask, pre_gt_color, scale_factor))
+
+        def it():
+            optimizer.zero_grad()
+            o = trk.iteration_losses(camera_tensor, self.gt_color, self.gt_depth, self.frame, batch_size, rgbd, event,
+                                     scale_factor, static_shapes=True)
+            if 'one' not in self.__dict__:
+                self.one = torch.ones_like(o['total'])
+            o['total'].backward(gradient=self.one)
+            optimizer.step()
+            z = o['total'].new_zeros(())
+            return tuple(z if o[k] is None else o[k].detach() for k in ('rgbd', 'event', 'mask'))
+
+        self.graph = GraphedStep(it, warmup=warmup)
+
+    def set_frame(self, gt_color, gt_depth, gt_event=None, gt_mask=None, pre_gt_color=None):
+        self.gt_color.copy_(gt_color)
+        self.gt_depth.copy_(gt_depth)
+        if self.event:
+            for dst, src in zip(self.frame, self.trk.prepare_event_frame(gt_event, gt_mask, pre_gt_color, self.scale_factor)):
+                dst.copy_(src)
+
+    def step(self):
+        return self.graph.replay()

@@ -113,3 +113,43 @@ def test_event_iteration_switches(monkeypatch):
     with pytest.raises(RuntimeError):
         trk.optimize_cam_in_batch(ct, None, img['gt_color'], img['gt_depth'], img['gt_event'], img['gt_mask'],
                                   int(fx['batch_size']), opt, 0, 0, img['pre_gt_color'], rgbd=True, event=True)
+
+
+def test_static_shape_and_graphed_iteration_match_fixture(monkeypatch):
+    """The capture-friendly formulation (no boolean indexing: dropped rays rendered without loss, sampler maxima over
+    the kept rays, masked median) and its hipGraph replay reproduce the reference fixture."""
+    import gc
+    from evennicer_slam_amd.mapper import FusedAdam
+    fx = load("tiny_event_iter")
+    trk, img, DEV = _setup(fx)
+    idx = torch.from_numpy(fx['idx']).to(DEV)
+    monkeypatch.setattr(torch, 'randint', lambda *a, **k: idx)
+    sf = float(fx['scale_factor'])
+    ct = torch.from_numpy(fx['camera_tensor']).to(DEV).requires_grad_(True)
+    frame = trk.prepare_event_frame(img['gt_event'], img['gt_mask'], img['pre_gt_color'], sf)
+    o = trk.iteration_losses(ct, img['gt_color'], img['gt_depth'], frame, int(fx['batch_size']), True, True, sf,
+                             static_shapes=True)
+    assert abs(o['rgbd'].item() - float(fx['loss_rgbd'])) <= 1e-4 * abs(float(fx['loss_rgbd']))
+    assert abs(o['event'].item() - float(fx['loss_event'])) <= 1e-4 * abs(float(fx['loss_event']))
+    o['total'].backward()
+    assert rel_err(ct.grad.cpu().numpy(), fx['g_total']) <= 1e-3
+    del o
+    ct.grad = None
+    gc.collect()
+    opt = FusedAdam([ct], lr=0.0)                       # lr 0: the replays leave the camera where the fixture has it
+    git = E_tracker().GraphedCameraIteration(trk, ct, opt, img['gt_color'], img['gt_depth'], img['gt_event'], img['gt_mask'],
+                                             img['pre_gt_color'], batch_size=int(fx['batch_size']), rgbd=True, event=True,
+                                             scale_factor=sf)
+    for _ in range(2):
+        git.set_frame(img['gt_color'], img['gt_depth'], img['gt_event'], img['gt_mask'], img['pre_gt_color'])
+        l_rgbd, l_event, l_mask = git.step()
+        assert abs(l_rgbd.item() - float(fx['loss_rgbd'])) <= 1e-4 * abs(float(fx['loss_rgbd']))
+        assert abs(l_event.item() - float(fx['loss_event'])) <= 1e-4 * abs(float(fx['loss_event']))
+        assert abs(l_mask.item() - float(fx['loss_mask'])) <= 1e-4 * abs(float(fx['loss_mask']))
+        assert rel_err(ct.grad.cpu().numpy(), fx['g_total']) <= 1e-3
+    assert np.array_equal(ct.detach().cpu().numpy(), fx['camera_tensor'])
+
+
+def E_tracker():
+    import evennicer_slam_amd as E
+    return E.tracker

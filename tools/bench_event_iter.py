@@ -70,3 +70,20 @@ rays = int(H * SF) * int(W * SF)
 print(f"config 3, room0, eager: full iteration (200-ray RGB-D + {rays}-ray event render + U-Net + losses + Adam) {t_full * 1e3:.2f} ms; "
       f"RGB-D part alone {t_rgbd * 1e3:.2f} ms; event render path alone (fwd+bwd to the pose) {t_path * 1e3:.2f} ms "
       f"({rays / t_path / 1e6:.2f} M rays/s); U-Net fwd+bwd alone {t_unet * 1e3:.2f} ms; losses rgbd {r[0]:.2f} event {r[1]:.2f} mask {r[2]:.3f}")
+git = None
+if os.environ.get('GRAPH', '1') == '1':
+    import gc
+    for f in (full,):
+        f()
+    gc.collect()
+    git = E.tracker.GraphedCameraIteration(trk, ct, opt, color_img, depth_img, gt_event, gt_mask, pre_color, batch_size=200,
+                                           rgbd=True, event=True, scale_factor=SF)
+    git_ev = E.tracker.GraphedCameraIteration(trk, ct, opt, color_img, depth_img, gt_event, gt_mask, pre_color, batch_size=200,
+                                              rgbd=False, event=True, scale_factor=SF)
+if git is not None:
+    for _i in range(3): git.step(); git_ev.step()
+    tg, tge = timed(git.step, n * 3), timed(git_ev.step, n * 3)
+    lr_, le_, lm_ = git.step()
+    tf = timed(lambda: git.set_frame(color_img, depth_img, gt_event, gt_mask, pre_color), 20)
+    print(f"config 3, one hipGraph per iteration (static-shape formulation): RGB-D + event {tg * 1e3:.2f} ms, event only "
+          f"(frames without RGB-D) {tge * 1e3:.2f} ms, per-frame set_frame {tf * 1e3:.2f} ms; losses rgbd {lr_.item():.2f} event {le_.item():.2f}")
