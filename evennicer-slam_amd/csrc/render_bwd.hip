@@ -155,6 +155,12 @@ ENS_DEV void stage_tile(float* sacc, int ld, int col0, int nc, int t, const f32x
         }
     }
 }
+// per-lane bias partials of own_layer_a: lane (p,q) holds feature 16rt+p summed over its samples 4q..4q+3
+ENS_DEV void stage_bias_lane(float* sbias, int rt, float v, int n_valid, int p, int q) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (q == 0 && 16 * rt + p < n_valid) sbias[16 * rt + p] = v;
+}
 ENS_DEV void stage_bias(float* sbias, int rt, const f32x4& acc, int n_valid, int p, int q) {
     if (p == 0) {
 #pragma unroll
@@ -424,13 +430,15 @@ ENS_DEV void own_outer_a(f32x4 (&acc)[NJ], const unsigned (&fb)[4], int ytile0, 
         }
     }
 }
-// One layer's owned weight-gradient tiles in one pass over the slots: dWc (NA tiles), dW (NB tiles) and the bias row.
+// One layer's owned weight-gradient tiles in one pass over the slots: dWc (NA tiles), dW (NB tiles) and the bias row
+// (per-lane partial sums on the VALU -- a 16-MFMA tile per layer for one row was 20 % of the dW waves' MFMA time;
+// stage_bias_lane reduces them over q once, at the flush).
 // Per slot all operand fragments are read first, then the MFMAs of the NA+NB+1 independent accumulators interleave,
 // so no MFMA waits on its own predecessor and one LDS round trip feeds 4*(NA+NB+1) MFMAs (three separate passes with
 // one or two accumulators each ran at about half the MFMA rate).
 template <int NA, int NB>
 ENS_DEV void own_layer_a(f32x4 (&accA)[NA], int yA, int xA, int ncA, int ntA, f32x4 (&accB)[NB], int yB, int xB, int ncB,
-                         int ntB, f32x4& accBias, int ybias, const unsigned (&fb)[4], int wave) {
+                         int ntB, float& accBias, int ybias, const unsigned (&fb)[4], int wave) {
     // operand fragments of the next slot are requested before the current slot's MFMAs are issued (two register sets),
     // so the LDS round trip of slot s+1 runs under the MFMAs of slot s
     constexpr bool PIPE = (NA + NB) <= 4;
@@ -470,8 +478,8 @@ ENS_DEV void own_layer_a(f32x4 (&accA)[NA], int yA, int xA, int ncA, int ntA, f3
             for (int j = 0; j < NA; ++j) accA[j] = MFMA16(aA[set][j][s], bA[set][j][s], accA[j]);
 #pragma unroll
             for (int j = 0; j < NB; ++j) accB[j] = MFMA16(aB[set][j][s], bB[set][j][s], accB[j]);
-            accBias = MFMA16(ab[set][s], 1.f, accBias);
         }
+        accBias += (ab[set][0] + ab[set][1]) + (ab[set][2] + ab[set][3]);     // bias row: feature p, samples 4q..4q+3 (VALU)
     }
 }
 ENS_DEV void own_bias_a(f32x4& acc, const unsigned (&fb)[4], int ytile) {
@@ -864,11 +872,12 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         }
     };
 
-    f32x4 aWc[5][CT / 2], aW0[3], aW1[1], aW2[1], aW3[4], aW4[1], aB[5], aBT[2];
+    f32x4 aWc[5][CT / 2], aW0[3], aW1[1], aW2[1], aW3[4], aW4[1], aBT[2];
+    float aB[5];
     float aWo[NE][8], aBo[NE];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        aB[i] = splat4(0.f);
+        aB[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < CT / 2; ++j) aWc[i][j] = splat4(0.f);
     }
@@ -1125,7 +1134,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             for (int i = 0; i < 5; ++i) {
 #pragma unroll
                 for (int j = 0; j < CT / 2; ++j) stage_tile(sacc + L.oWc(i), CT * 16, 0, CT, wave + 4 * j, aWc[i][j], 32, CT * 16, p, q);
-                stage_bias(sacc + (wave < 2 ? L.ob(i) : L.obc(i)), wave & 1, aB[i], 32, p, q);
+                stage_bias_lane(sacc + (wave < 2 ? L.ob(i) : L.obc(i)), wave & 1, aB[i], 32, p, q);
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) stage_tile(sacc + L.oW(0), 96, 0, 6, wave + 4 * j, aW0[j], 32, 96, p, q);
@@ -1173,10 +1182,11 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
     float* gpk = A.gpacked[kind];
     float* slots = smem + 2 * RB;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)smem;
-    f32x4 aWc[5][CT / 2], aW0[3], aW1[1], aW2[1], aW3[4], aW4[1], aB[5], aBT[2];
+    f32x4 aWc[5][CT / 2], aW0[3], aW1[1], aW2[1], aW3[4], aW4[1], aBT[2];
+    float aB[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        aB[i] = splat4(0.f);
+        aB[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < CT / 2; ++j) aWc[i][j] = splat4(0.f);
     }
@@ -1258,7 +1268,7 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
     for (int i = 0; i < 5; ++i) {
 #pragma unroll
         for (int j = 0; j < CT / 2; ++j) stage_tile(sacc + L.oWc(i), CT * 16, 0, CT, ow + 4 * j, aWc[i][j], 32, CT * 16, p, q);
-        stage_bias(sacc + (ow < 2 ? L.ob(i) : L.obc(i)), ow & 1, aB[i], 32, p, q);
+        stage_bias_lane(sacc + (ow < 2 ? L.ob(i) : L.obc(i)), ow & 1, aB[i], 32, p, q);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) stage_tile(sacc + L.oW(0), 96, 0, 6, ow + 4 * j, aW0[j], 32, 96, p, q);
