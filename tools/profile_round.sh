@@ -11,23 +11,5 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUS
   tag=$(echo $c | cut -d' ' -f1)
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o p -- python3 $R/bench.py --steps 10 --warmup 3 --eager > $O/pmc_$tag.log 2>&1
 done
-python3 - <<PY
-import csv, glob, json, collections
-O = "$O"
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(O + "/pmc_*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
-        acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {}
-for k, cs in acc.items():
-    if not any(s in k for s in ("decoder_bwd", "render_fwd", "grid_bwd", "convert_kernel", "composite", "sample_kernel")): continue
-    d = {c: sum(v) / len(v) for c, v in cs.items()}
-    d["dispatches"] = max(len(v) for v in cs.values())
-    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        d["bytes_per_launch"] = int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
-    out[k] = d
-json.dump(out, open(O + "/pmc_summary.json", "w"), indent=1)
-print(json.dumps({k: v.get("bytes_per_launch") for k, v in out.items()}, indent=1))
-PY
+python3 $R/tools/pmc_summary.py $O $O/pmc_summary.json > $O/pmc_summary.txt
 tail -1 $O/graph.log | cut -c1-200
