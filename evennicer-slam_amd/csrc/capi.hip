@@ -231,12 +231,12 @@ int enslam_step_prepare(int32_t n_dec, const int32_t* kinds, const enslam_mlp_pa
         if (!make_conv_job(n_conv, src, dst, n_voxels, need, valid, true, cj)) return ENSLAM_EINVAL;
     }
     if (n_zero > 0 && !make_conv_job(n_zero, nullptr, zero_dst, zero_voxels, zero_need, nullptr, false, zj)) return ENSLAM_EINVAL;
-    return ens_launch_step(pj, false, cj, true, zj, flat, n_flat, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+    return ens_launch_step(pj, false, cj, true, zj, flat, n_flat, nullptr, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
 
-int enslam_step_finish(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
-                       const uint8_t* const* need, int32_t n_dec, const int32_t* kinds, const float* const* packed_grads,
-                       const enslam_mlp_params* grads, void* stream) {
+static int step_finish_impl(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                            const uint8_t* const* need, int32_t n_dec, const int32_t* kinds, const float* const* packed_grads,
+                            const enslam_mlp_params* grads, const RayGradArgs* rg, void* stream) {
     if (n_dec < 0 || n_dec > 4 || n_conv < 0 || n_conv > 4) return ENSLAM_EINVAL;
     PackJob pj;
     clear_job(pj);
@@ -257,7 +257,29 @@ int enslam_step_finish(int32_t n_conv, const float* const* src, float* const* ds
             if (!need[i]) return ENSLAM_EINVAL;
         if (!make_conv_job(n_conv, src, dst, n_voxels, need, nullptr, true, cj)) return ENSLAM_EINVAL;
     }
-    return ens_launch_step(pj, true, cj, false, zj, nullptr, 0, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+    return ens_launch_step(pj, true, cj, false, zj, nullptr, 0, rg, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+int enslam_step_finish(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                       const uint8_t* const* need, int32_t n_dec, const int32_t* kinds, const float* const* packed_grads,
+                       const enslam_mlp_params* grads, void* stream) {
+    return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, nullptr, stream);
+}
+int enslam_step_finish_rays(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                            const uint8_t* const* need, int32_t n_dec, const int32_t* kinds, const float* const* packed_grads,
+                            const enslam_mlp_params* grads, int32_t stage, int32_t n_rays, int32_t n_samples,
+                            const float* rays_o, const float* rays_d, const double* z_vals, const enslam_scene* scene,
+                            float* dgrid_ws, float* g_rays_o, float* g_rays_d, void* stream) {
+    if (n_rays < 0) return ENSLAM_EINVAL;
+    if (n_rays == 0 || stage == ENSLAM_STAGE_COARSE)
+        return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, nullptr, stream);
+    if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
+    DevScene d;
+    if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
+    if (!rays_o || !rays_d || !z_vals || !dgrid_ws || !g_rays_o || !g_rays_d) return ENSLAM_EINVAL;
+    RayGradArgs rg;
+    if (!ens_ray_grad_args(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, dgrid_ws, g_rays_o, g_rays_d, rg))
+        return ENSLAM_EINVAL;
+    return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, &rg, stream);
 }
 
 int enslam_grids_convert(int32_t n, const float* const* src, float* const* dst, const int64_t* n_voxels,

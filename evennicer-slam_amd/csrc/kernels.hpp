@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "common.hpp"
+#include "raygrad.hpp"
 
 // one segment of a decoder re-layout: dst[r*dst_ld + c] = T ? src[c*src_ld + r] : src[r*src_ld + c]
 struct PackSeg {
@@ -83,7 +84,9 @@ int ens_launch_tracker_loss(int n, const double* depth, const double* unc, const
 int ens_launch_pose_rays(int n, const float* ct, const float* pi, const float* pj, float fx, float fy, float cx, float cy,
                          const float* g_ro, const float* g_rd, float* ro, float* rd, float* g_ct, hipStream_t st);
 int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_vm, const ConvJob& zj, float* flat,
-                    int64_t n_flat, hipStream_t st);
+                    int64_t n_flat, const RayGradArgs* rg, hipStream_t st);
+bool ens_ray_grad_args(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z, const DevScene& sc,
+                       float* dgrid_ws, float* g_ro, float* g_rd, RayGradArgs& A);
 int ens_launch_adam(const AdamJob& job, hipStream_t st);
 int ens_launch_adam_tensors(const AdamTensorsJob& job, hipStream_t st);
 int ens_launch_zero_blocks(const ConvJob& job, float* flat, int64_t n_flat, hipStream_t st);

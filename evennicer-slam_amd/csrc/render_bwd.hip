@@ -221,48 +221,7 @@ ENS_DEV unsigned pos_bits(const f32x4& v) {
 // ------------------------------------------------------------------------------------------------
 // Per-tile geometry shared by the decoder roles
 // ------------------------------------------------------------------------------------------------
-struct TileGeo {
-    double pw[3];
-    float zf;
-    int64_t sidx;
-    int ray;
-};
 
-ENS_DEV TileGeo tile_geo(int64_t tile, int ntl, int S, const float* ro, const float* rd, const double* z, int p) {
-    TileGeo g;
-    g.ray = __builtin_amdgcn_readfirstlane((int)(tile / ntl));            // tile is wave-uniform
-    const int tl = __builtin_amdgcn_readfirstlane((int)(tile - (int64_t)g.ray * ntl));
-    g.sidx = (int64_t)g.ray * S + 16 * tl + p;
-    const double zz = z[g.sidx];
-    g.zf = (float)zz;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) g.pw[a] = (double)ro[g.ray * 3 + a] + (double)rd[g.ray * 3 + a] * zz;
-    return g;
-}
-
-// Coordinate gradient through the trilinear weights (ATen grid_sampler_3d_backward, gix/giy/giz) for the lane's
-// 8 channels; partial over channels -> caller reduces over the 4 q lanes.
-ENS_DEV void coord_grad_partial(const Vox& v, const DevGrid& g, int q, const f32x4& d0, const f32x4& d1, float& gx,
-                                float& gy, float& gz) {
-    gx = gy = gz = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-        int x = v.ix + dx, y = v.iy + dy, z = v.iz + dz;
-        const bool ok = (x < g.W) && (y < g.H) && (z < g.D);
-        x = min(x, g.W - 1); y = min(y, g.H - 1); z = min(z, g.D - 1);
-        const float* src = g.data + (((int64_t)z * g.H + y) * g.W + x) * 32 + 4 * q;
-        const f32x4 a = ld4(src), b = ld4(src + 16);
-        float dot = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dot = fmaf(a[r], d0[r], fmaf(b[r], d1[r], dot));
-        dot = ok ? dot : 0.f;
-        const float wx = dx ? v.fx : (1.f - v.fx), wy = dy ? v.fy : (1.f - v.fy), wz = dz ? v.fz : (1.f - v.fz);
-        gx += (dx ? dot : -dot) * wy * wz;
-        gy += (dy ? dot : -dot) * wx * wz;
-        gz += (dz ? dot : -dot) * wx * wy;
-    }
-}
 
 // Scatter the tile's feature gradient (deposited as [sample][32] floats in `dep`) into the voxel-major grid
 // gradient: 4 wave instructions per flush, each 2 x-adjacent corners x 32 channels = 256 contiguous bytes.
@@ -348,19 +307,6 @@ ENS_DEV void scatter_tile_rec(const float* dep, const f32x4& rec, const DevGrid&
     if (open) flush();
 }
 
-// reduce the per-sample position gradient over the tile and add it to the ray gradients
-ENS_DEV void add_ray_grad(float dpx, float dpy, float dpz, float zf, int ray, float* g_ro, float* g_rd, int lane) {
-    float v[6] = {dpx, dpy, dpz, dpx * zf, dpy * zf, dpz * zf};
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { atomicAdd(g_ro + ray * 3 + a, v[a]); atomicAdd(g_rd + ray * 3 + a, v[3 + a]); }
-    }
-}
 
 struct BwdArgs {
     int n_rays, ntl;
@@ -1287,34 +1233,10 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
     }
 }
 
-// Ray-gradient side of the backward for the saved-activation path: one wave per (16-sample tile, decoder slot).  Low
-// register count -> many waves per SIMD hide the latency of the fp64 geometry and of the corner re-gather.
-__global__ __launch_bounds__(64) void grid_bwd_kernel(BwdArgs A, int n_slots) {
-    const int lane = threadIdx.x, p = lane & 15, q = lane >> 4;
-    const int64_t unit = blockIdx.x;
-    const int64_t tile = unit / n_slots;
-    const int slot_idx = A.role_kind[unit - tile * n_slots] - 1;
-    const int kind = slot_idx + 1;
-    const DevGrid grid = A.sc.grid[kind];
-    const float* dgw = A.dgrid_ws + (tile * ACT_SLOTS + slot_idx) * DG_STRIDE;
-    const f32x4 dc0 = ld4(dgw + lane * 4), dc1 = ld4(dgw + 256 + lane * 4);
-    const f32x4 dpe = ld4(dgw + DG_DPE + lane * 4);
-    bool nz = false;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) nz = nz || dc0[r] != 0.f || dc1[r] != 0.f || dpe[r] != 0.f;
-    if (!__any(nz)) return;
-    const int S = 16 * A.ntl;
-    const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
-    const Vox v = make_vox(G.pw, A.sc.lo, A.sc.hi, grid);
-    float gx, gy, gz;
-    coord_grad_partial(v, grid, q, dc0, dc1, gx, gy, gz);
-    gx += __shfl_xor(gx, 16); gx += __shfl_xor(gx, 32);
-    gy += __shfl_xor(gy, 16); gy += __shfl_xor(gy, 32);
-    gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
-    float dpx = gx * v.gx + dpe[0], dpy = gy * v.gy + dpe[1], dpz = gz * v.gz + dpe[2];
-    if (q != 0) { dpx = dpy = dpz = 0.f; }
-    add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
-}
+// Ray-gradient side of the backward for the saved-activation path: one wave per (16-sample tile, decoder slot)
+// (ray_grad_unit, raygrad.hpp).  Normally this work rides in the finish launch (step_kernel); the stand-alone kernel
+// serves enslam_ray_grad_bwd.
+__global__ __launch_bounds__(64) void grid_bwd_kernel(RayGradArgs A) { ray_grad_unit(A, (int64_t)blockIdx.x, (int)threadIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // MLP_no_xyz (coarse) backward role
@@ -1695,21 +1617,20 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
 }
 
 // Second kernel of the saved-activation backward: ray gradients from the decoder kernel's hand-off buffer.
+bool ens_ray_grad_args(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z, const DevScene& sc,
+                       float* dgrid_ws, float* g_ro, float* g_rd, RayGradArgs& A) {
+    if (n_rays <= 0 || stage == 0 || !dgrid_ws || !g_ro || !g_rd) return false;
+    A.n_rays = n_rays; A.ntl = ntl; A.n_slots = stage;       // middle | middle+fine | middle+fine+color
+    A.ro = ro; A.rd = rd; A.z = z; A.dgrid_ws = dgrid_ws; A.g_ro = g_ro; A.g_rd = g_rd;
+    for (int a = 0; a < 3; ++a) { A.lo[a] = sc.lo[a]; A.hi[a] = sc.hi[a]; }
+    for (int k = 0; k < 4; ++k) A.grid[k] = sc.grid[k];
+    return true;
+}
 int ens_launch_ray_grad_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
                             const DevScene& sc, float* dgrid_ws, float* g_ro, float* g_rd, hipStream_t st) {
     if (n_rays <= 0 || stage == 0) return 0;
-    if (!dgrid_ws || !g_ro || !g_rd) return -1;
-    BwdArgs A;
-    A.act_ws = nullptr;
-    A.act_light = 0;
-    A.dgrid_ws = dgrid_ws;
-    A.n_rays = n_rays; A.ntl = ntl; A.ro = ro; A.rd = rd; A.z = z; A.d_raw = nullptr; A.sc = sc;
-    A.g_ro = g_ro; A.g_rd = g_rd;
-    for (int k = 0; k < 4; ++k) { A.ggrid[k] = DevGrid{nullptr, 0, 0, 0}; A.gpacked[k] = nullptr; A.role_kind[k] = -1; }
-    const int n2 = stage;                                   // middle | middle+fine | middle+fine+color
-    for (int i = 0; i < n2; ++i) A.role_kind[i] = i + 1;
-    A.n_roles = n2;
-    const int64_t n_tiles = (int64_t)n_rays * ntl;
-    grid_bwd_kernel<<<dim3((unsigned)(n_tiles * n2)), dim3(64), 0, st>>>(A, n2);
+    RayGradArgs A;
+    if (!ens_ray_grad_args(stage, ntl, n_rays, ro, rd, z, sc, dgrid_ws, g_ro, g_rd, A)) return -1;
+    grid_bwd_kernel<<<dim3((unsigned)((int64_t)n_rays * ntl * A.n_slots)), dim3(64), 0, st>>>(A);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -576,11 +576,16 @@ __global__ __launch_bounds__(256) void pack_kernel(PackJob job, float* __restric
 // convert the touched blocks to voxel-major, clear the gradient accumulators.  After the backward: transposed-back
 // grid gradients and unpacked decoder gradients.
 __global__ __launch_bounds__(256) void step_kernel(PackJob pj, int unpack, ConvJob cj, int to_vm, ConvJob zj,
-                                                   float* __restrict__ flat, int64_t n_flat, int nb_pack, int nb_conv) {
+                                                   float* __restrict__ flat, int64_t n_flat, int nb_pack, int nb_conv,
+                                                   int nb_zero, RayGradArgs rg) {
     const int b = blockIdx.x;
     if (b < nb_pack) pack_body(pj, nullptr, unpack, b >> 2, b & 3, 4);
     else if (b < nb_pack + nb_conv) convert_body(cj, to_vm, b - nb_pack);
-    else zero_body(zj, flat, n_flat, b - nb_pack - nb_conv);
+    else if (b < nb_pack + nb_conv + nb_zero) zero_body(zj, flat, n_flat, b - nb_pack - nb_conv);
+    else {                                  // ray gradients: one wave per (tile, decoder slot), four per workgroup
+        const int64_t unit = (int64_t)(b - nb_pack - nb_conv - nb_zero) * 4 + (threadIdx.x >> 6);
+        if (unit < (int64_t)rg.n_rays * rg.ntl * rg.n_slots) ray_grad_unit(rg, unit, (int)(threadIdx.x & 63));
+    }
 }
 
 }  // namespace
@@ -606,13 +611,17 @@ int ens_launch_convert(const ConvJob& job, bool to_vm, hipStream_t st) {
 }
 
 int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_vm, const ConvJob& zj, float* flat,
-                    int64_t n_flat, hipStream_t st) {
+                    int64_t n_flat, const RayGradArgs* rg, hipStream_t st) {
     const int nb_pack = pj.n * 4, nb_conv = cj.n > 0 ? cj.block_begin[cj.n] : 0;
     const int64_t nb_zero = (zj.n > 0 ? zj.block_begin[zj.n] : 0) + (flat != nullptr && n_flat > 0 ? (n_flat + 2047) / 2048 : 0);
-    const int64_t nb = (int64_t)nb_pack + nb_conv + nb_zero;
+    RayGradArgs r;
+    if (rg != nullptr) r = *rg; else { r.n_rays = 0; r.ntl = 0; r.n_slots = 0; }
+    const int64_t nb_ray = ((int64_t)r.n_rays * r.ntl * r.n_slots + 3) / 4;
+    const int64_t nb = (int64_t)nb_pack + nb_conv + nb_zero + nb_ray;
     if (nb <= 0) return 0;
+    if (nb > 0x7fffffff) return -1;
     step_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(pj, unpack ? 1 : 0, cj, to_vm ? 1 : 0, zj, flat, flat ? n_flat : 0,
-                                                          nb_pack, nb_conv);
+                                                          nb_pack, nb_conv, (int)nb_zero, r);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

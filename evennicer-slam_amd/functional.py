@@ -595,9 +595,8 @@ class _RenderFn(torch.autograd.Function):
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
-        if dgw is not None and plan.stage != 'coarse':      # saved-activation path: ray gradients in their own kernel
-            L.check(lib.enslam_ray_grad_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                            _ptr(dgw), p_ro, p_rd, st), "enslam_ray_grad_bwd")
+        # saved-activation path: the ray gradients (corner re-gather from the hand-off in dgw) ride in the finish launch
+        ray_pending = dgw is not None and plan.stage != 'coarse'
         out = [None, g_ro if needs[1] else None, g_rd if needs[2] else None, None, None]
         # ONE launch: grid gradients back to the callers' [1,32,D,H,W] layout + decoder gradients unpacked into views of
         # one flat buffer shaped like the parameters
@@ -627,7 +626,11 @@ class _RenderFn(torch.autograd.Function):
                 views_by_kind[k] = views
                 kind_arr[j], pk_arr[j] = k, g_packed[k]
                 structs[j] = _fill_params_struct(k, views)
-        if nc or npk:
+        if ray_pending:
+            L.check(lib.enslam_step_finish_rays(nc, srcs, dsts, vs, need_ptrs, npk, kind_arr, pk_arr, structs, L.STAGE[plan.stage],
+                                                N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc), _ptr(dgw), p_ro, p_rd, st),
+                    "enslam_step_finish_rays")
+        elif nc or npk:
             L.check(lib.enslam_step_finish(nc, srcs, dsts, vs, need_ptrs, npk, kind_arr, pk_arr, structs, st), "enslam_step_finish")
         for k in plan.kinds:
             out += views_by_kind.get(k, [None] * plan.n_params[k])

@@ -193,6 +193,14 @@ int enslam_step_prepare(int32_t n_dec, const int32_t *kinds, const enslam_mlp_pa
 int enslam_step_finish(int32_t n_conv, const float *const *src, float *const *dst, const int64_t *n_voxels,
                        const uint8_t *const *need, int32_t n_dec, const int32_t *kinds,
                        const float *const *packed_grads, const enslam_mlp_params *grads, void *stream);
+/* enslam_step_finish with enslam_ray_grad_bwd riding in the same launch (both depend only on enslam_decoder_bwd):
+ * one dependent launch fewer per step.  stage COARSE or n_rays == 0: plain enslam_step_finish. */
+int enslam_step_finish_rays(int32_t n_conv, const float *const *src, float *const *dst, const int64_t *n_voxels,
+                            const uint8_t *const *need, int32_t n_dec, const int32_t *kinds,
+                            const float *const *packed_grads, const enslam_mlp_params *grads, int32_t stage,
+                            int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                            const double *z_vals, const enslam_scene *scene, float *dgrid_ws, float *g_rays_o,
+                            float *g_rays_d, void *stream);
 
 /* Sample distances along rays (mark_scene / mark_flags non-NULL: also does enslam_mark_blocks' work for stage mark_stage
  * on the samples it has just placed -- one launch less per render call).
