@@ -153,6 +153,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--torch-loss', action='store_true', help='compute the mapper loss with torch ops instead of the fused HIP loss')
+    ap.add_argument('--separate-loss', action='store_true', help='render_batch_ray, then losses.rgbd_loss as its own launches')
     ap.add_argument('--eager', action='store_true', help='time the plain Python-driven step instead of hipGraph replays')
     args = ap.parse_args()
 
@@ -223,11 +224,14 @@ def main():
             t.grad = None
         ro.grad = None
         rd.grad = None
-        depth, var, color = renderer.render_batch_ray(grids, model, rd, ro, dev, stage, gt_depth=gd)
-        if args.torch_loss:
-            loss = mapper_loss(depth, color, gd, gc, stage)
-        else:
-            loss = E.losses.rgbd_loss(depth, color if stage == 'color' else None, gd, gc, 0.2)
+        if args.torch_loss or args.separate_loss or stage == 'coarse':
+            depth, var, color = renderer.render_batch_ray(grids, model, rd, ro, dev, stage, gt_depth=gd)
+            if args.torch_loss:
+                loss = mapper_loss(depth, color, gd, gc, stage)
+            else:
+                loss = E.losses.rgbd_loss(depth, color if stage == 'color' else None, gd, gc, 0.2)
+        else:               # the same render and loss with the loss folded into the compositing launches
+            loss, depth, var, color = renderer.render_batch_ray_rgbd_loss(grids, model, rd, ro, dev, stage, gd, gc, 0.2)
         if 'one' not in seed_grad:              # d(loss)/d(loss) = 1, allocated once (backward() would fill one per step)
             seed_grad['one'] = torch.ones_like(loss)
         loss.backward(gradient=seed_grad['one'])
@@ -344,7 +348,8 @@ def main():
                    "rays_per_gpu": args.rays, "samples_per_ray": S,
                    "parallelism": "1 GPU" if world == 1 else f"ray-sharded dp{world}, one bucketed RCCL all-reduce of leaf grads "
                                                             f"(touched 64-voxel blocks only: {comm['bytes'] / 1e6:.1f} MB per step)"},
-        "loss": float(loss.item()), "mode": mode, "loss_impl": "torch" if args.torch_loss else "fused HIP (losses.rgbd_loss)",
+        "loss": float(loss.item()), "mode": mode, "loss_impl": "torch" if args.torch_loss else ("fused HIP (losses.rgbd_loss)" if args.separate_loss or stage == 'coarse'
+                                                                  else "fused into the compositing launches (render_batch_ray_rgbd_loss)"),
         "eager_rays_per_s": world * args.rays * eager_steps / eager_elapsed,
     }
     if events:

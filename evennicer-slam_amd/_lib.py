@@ -97,6 +97,11 @@ _SIGS = {
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Grid),
                                          POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                                          c_void_p]),
+    "enslam_render_loss_fwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene), c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, ctypes.c_float,
+                                              c_void_p, c_void_p]),
+    "enslam_composite_loss_bwd": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 ctypes.c_float, c_void_p, c_void_p, c_void_p]),
     "enslam_composite_fwd": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p]),
     "enslam_composite_bwd": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -498,6 +498,36 @@ int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
                                  rgb, raw_out, stage == ENSLAM_STAGE_COARSE ? nullptr : act_ws, act_light != 0, (hipStream_t)stream);
 }
 
+int enslam_render_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                           const double* z_vals, const enslam_scene* scene, double* depth, double* var, float* rgb,
+                           float* raw_out, float* act_ws, int32_t act_light, const float* gt_depth, const float* gt_color,
+                           float w_color, double* loss, void* stream) {
+    if (n_rays < 0) return ENSLAM_EINVAL;
+    if (n_rays == 0) return ENSLAM_OK;
+    if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
+    DevScene d;
+    if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
+    if (!rays_o || !rays_d || !z_vals || !depth || !var || !rgb || !raw_out || !gt_depth || !loss) return ENSLAM_EINVAL;
+    if (act_ws != nullptr)
+        for (int k = 1; k < 4; ++k)
+            if (d.grid[k].data && (int64_t)d.grid[k].D * d.grid[k].H * d.grid[k].W >= ACT_MAX_VOXELS) return ENSLAM_EUNSUPPORTED;
+    const LossSpec ls{gt_depth, gt_color, w_color, loss, nullptr};
+    const int rc = ens_launch_render_fwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, nullptr, 0, 1, d, depth, var, rgb,
+                                         raw_out, stage == ENSLAM_STAGE_COARSE ? nullptr : act_ws, act_light != 0,
+                                         (hipStream_t)stream, &ls);
+    return rc == 0 ? ENSLAM_OK : (rc == -1 ? ENSLAM_EUNSUPPORTED : ENSLAM_ELAUNCH);
+}
+int enslam_composite_loss_bwd(int32_t n_rays, int32_t n_samples, const float* raw, const double* z_vals,
+                              const double* depth, const float* rgb, const float* gt_depth, const float* gt_color,
+                              float w_color, const double* g_loss, float* d_raw, void* stream) {
+    if (n_rays < 0 || n_samples < 1 || n_samples > 64) return ENSLAM_EINVAL;
+    if (n_rays == 0) return ENSLAM_OK;
+    if (!raw || !z_vals || !depth || !gt_depth || !g_loss || !d_raw || (gt_color && !rgb)) return ENSLAM_EINVAL;
+    const LossSpec ls{gt_depth, gt_color, w_color, nullptr, g_loss};
+    return ens_launch_composite_bwd(n_rays, n_samples, raw, z_vals, depth, nullptr, nullptr, nullptr, d_raw,
+                                    (hipStream_t)stream, &ls, rgb) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+
 size_t enslam_grid_handoff_floats(int32_t stage, int32_t n_rays, int32_t n_samples) {
     if (stage == ENSLAM_STAGE_COARSE || n_rays <= 0 || n_samples <= 0) return 0;
     return (size_t)n_rays * (size_t)(n_samples / 16) * ACT_SLOTS * DG_STRIDE;

@@ -5,6 +5,15 @@
 #include "common.hpp"
 #include "raygrad.hpp"
 
+// Mapper RGB-D loss (Mapper.py:553-562) fused into the compositing launches: gd != null switches it on
+struct LossSpec {
+    const float* gd;             // gt depth [N] (term only where > 0)
+    const float* gc;             // gt colour [N,3] or null (depth term only)
+    float w;                     // colour weight
+    double* loss;                // forward: += sum of the rays' terms (zero on entry)
+    const double* g_loss;        // backward: d(total)/d(loss), device scalar
+};
+
 // one segment of a decoder re-layout: dst[r*dst_ld + c] = T ? src[c*src_ld + r] : src[r*src_ld + c]
 struct PackSeg {
     float* src;                              // caller tensor (input of pack, output of unpack)
@@ -108,12 +117,13 @@ int ens_launch_voxel_index(int64_t n, const double* pts, const double* bound, in
                            int* iz, float* fx, float* fy, float* fz, hipStream_t st);
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
-                          double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st);
+                          double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st,
+                          const LossSpec* ls = nullptr);
 int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* z, double* depth, double* var,
-                             float* rgb, float* weights, hipStream_t st);
+                             float* rgb, float* weights, hipStream_t st, const LossSpec* ls = nullptr);
 int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* z, const double* depth,
                              const double* g_depth, const double* g_var, const float* g_rgb, float* d_raw,
-                             hipStream_t st);
+                             hipStream_t st, const LossSpec* ls = nullptr, const float* rgb = nullptr);
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
                            const DevScene& sc, const float* d_raw, const float* act_ws, int act_light, float* dgrid_ws,
                            const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(int S, const float* _
                                                            const double* __restrict__ g_depth,
                                                            const double* __restrict__ g_var,
                                                            const float* __restrict__ g_rgb,
-                                                           float* __restrict__ d_raw) {
+                                                           float* __restrict__ d_raw, LossSpec ls,
+                                                           const float* __restrict__ rgb) {
     const int lane = threadIdx.x;
     const int64_t ray = blockIdx.x, sidx = ray * S + lane;
     const bool valid = lane < S;
@@ -58,9 +59,24 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(int S, const float* _
     T = lane == 0 ? 1.f : T;
     const float w = alpha * T;
     const double dep = depth[ray];
-    const double gD = g_depth ? g_depth[ray] : 0.0, gV = g_var ? g_var[ray] : 0.0;
+    double gD = g_depth ? g_depth[ray] : 0.0;
+    const double gV = g_var ? g_var[ray] : 0.0;
     float gc[3] = {0.f, 0.f, 0.f};
     if (g_rgb) { gc[0] = g_rgb[ray * 3]; gc[1] = g_rgb[ray * 3 + 1]; gc[2] = g_rgb[ray * 3 + 2]; }
+    if (ls.gd != nullptr) {                          // gradients of the fused mapper loss instead of incoming ones
+        const double g = ls.g_loss[0];
+        const float t = ls.gd[ray];
+        const double diff = (double)t - dep;
+        gD = t > 0.f ? (diff > 0.0 ? -g : (diff < 0.0 ? g : 0.0)) : 0.0;
+        if (ls.gc != nullptr) {
+            const float gw = (float)g * ls.w;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float d = ls.gc[ray * 3 + a] - rgb[ray * 3 + a];
+                gc[a] = -gw * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            }
+        }
+    }
     const double tmp = zk - dep;
     // var depends on depth through tmp:  d var / d depth = -2 sum_k w_k tmp_k
     const double gDt = gD - 2.0 * gV * wave_sum((double)w * tmp);
@@ -1474,9 +1490,11 @@ extern "C" int enslam_debug_set_stamp_buffer(void* p) {
 
 int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* z, const double* depth,
                              const double* g_depth, const double* g_var, const float* g_rgb, float* d_raw,
-                             hipStream_t st) {
+                             hipStream_t st, const LossSpec* ls, const float* rgb) {
     if (n_rays <= 0) return 0;
-    composite_bwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(S, raw, z, depth, g_depth, g_var, g_rgb, d_raw);
+    LossSpec l{nullptr, nullptr, 0.f, nullptr, nullptr};
+    if (ls != nullptr) l = *ls;
+    composite_bwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(S, raw, z, depth, g_depth, g_var, g_rgb, d_raw, l, rgb);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -533,13 +533,19 @@ extern "C" int enslam_debug_set_stamp_buffer_fwd(void* p) {
 namespace {
 #endif
 
-// raw2outputs_nerf_color on its own (common.py:256-297, occupancy branch): one wave per ray.
-__global__ __launch_bounds__(64) void composite_fwd_kernel(int S, const float* __restrict__ raw,
+// raw2outputs_nerf_color on its own (common.py:256-297, occupancy branch): one wave per ray; blockDim.x / 64 rays per
+// workgroup (16 when the mapper loss is fused in: its terms are summed in LDS first, one fp64 atomic per workgroup --
+// one per ray, all on one address, tripled the kernel's time).
+__global__ __launch_bounds__(1024) void composite_fwd_kernel(int n_rays, int S, const float* __restrict__ raw,
                                                            const double* __restrict__ z_vals,
                                                            double* __restrict__ depth, double* __restrict__ var,
-                                                           float* __restrict__ rgb, float* __restrict__ weights) {
-    const int lane = threadIdx.x;
-    const int64_t ray = blockIdx.x, sidx = ray * S + lane;
+                                                           float* __restrict__ rgb, float* __restrict__ weights,
+                                                           LossSpec ls) {
+    __shared__ double red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ray_raw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const bool rvalid = ray_raw < n_rays;
+    const int64_t ray = rvalid ? ray_raw : n_rays - 1, sidx = ray * S + lane;
     const bool valid = lane < S;
     const f32x4 rw = valid ? *reinterpret_cast<const f32x4*>(raw + sidx * 4) : splat4(0.f);
     const double zk = valid ? z_vals[sidx] : 0.0;
@@ -558,13 +564,29 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(int S, const float* _
     const double dep = wave_sum((double)w * zk);
     const double tmp = zk - dep;
     const double vr = wave_sum(((double)w * tmp) * tmp);
-    if (weights != nullptr && valid) weights[sidx] = w;
-    if (lane == 0) {
+    if (weights != nullptr && valid && rvalid) weights[sidx] = w;
+    double term = 0.0;
+    if (lane == 0 && rvalid) {
         depth[ray] = dep;
         var[ray] = vr;
         rgb[ray * 3 + 0] = cr;
         rgb[ray * 3 + 1] = cg;
         rgb[ray * 3 + 2] = cb;
+        if (ls.gd != nullptr) {                      // this ray's term of the mapper loss
+            const float g = ls.gd[ray];
+            term = g > 0.f ? fabs((double)g - dep) : 0.0;
+            if (ls.gc != nullptr)
+                term += (double)(ls.w * ((fabsf(ls.gc[ray * 3] - cr) + fabsf(ls.gc[ray * 3 + 1] - cg)) + fabsf(ls.gc[ray * 3 + 2] - cb)));
+        }
+    }
+    if (ls.gd != nullptr) {                          // (uniform over the launch)
+        if (lane == 0) red[wave] = term;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+            atomicAdd(ls.loss, t);
+        }
     }
 }
 
@@ -586,15 +608,19 @@ int launch_stage(int ntl, int64_t n_units, const float* ro, const float* rd, con
 }  // namespace
 
 int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* z, double* depth, double* var,
-                             float* rgb, float* weights, hipStream_t st) {
+                             float* rgb, float* weights, hipStream_t st, const LossSpec* ls) {
     if (n_rays <= 0) return 0;
-    composite_fwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(S, raw, z, depth, var, rgb, weights);
+    LossSpec l{nullptr, nullptr, 0.f, nullptr, nullptr};
+    if (ls != nullptr) l = *ls;
+    if (l.gd != nullptr) composite_fwd_kernel<<<dim3((n_rays + 15) / 16), dim3(1024), 0, st>>>(n_rays, S, raw, z, depth, var, rgb, weights, l);
+    else composite_fwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(n_rays, S, raw, z, depth, var, rgb, weights, l);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
-                          double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st) {
+                          double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st,
+                          const LossSpec* ls) {
     // Ray mode with raw requested and a moderate ray count: tile-per-wave decoders + separate compositing (more
     // waves in flight).  Large batches (full-image renders) already fill the chip with one wave per ray.
     int tpr = 0;
@@ -607,6 +633,7 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
         n_units *= ntl;
         ntl = 1;
     }
+    if (ls != nullptr && tpr == 0) return -1;                 // the fused loss rides in the separate compositing launch
     int rc;
     if (tpr > 0 && stage >= 1 && stage <= 3) {
         static bool attr_set = false;
@@ -622,7 +649,7 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
         else if (stage == 2) render_fwd_ring_kernel<2><<<grid, block, fwd_ring_lds_bytes(2), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
         else render_fwd_ring_kernel<3><<<grid, block, fwd_ring_lds_bytes(3), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
         if (hipGetLastError() != hipSuccess) return -2;
-        return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st);
+        return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st, ls);
     }
     switch (stage) {
         case 0: rc = launch_stage<0>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, act_light, sc, depth, var, rgb, raw, st); break;
@@ -632,5 +659,5 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
         default: return -1;
     }
     if (rc != 0 || tpr == 0) return rc;
-    return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st);
+    return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st, ls);
 }

@@ -386,6 +386,7 @@ class RenderPlan:
         self.decoders = decoders                # dict kind -> module
         self.n_params = {k: (12 if k == L.MLP_COARSE else 23) for k in kinds}
         self.vm = {}                            # kind -> VoxelMajorGrid for grids passed in the device layout
+        self.loss = None                        # (gt_depth [N] f32, gt_color [N,3] f32 | None, w_color): fused mapper loss
 
 
 class _Accumulators:
@@ -431,7 +432,8 @@ class _Accumulators:
 
 class _RenderFn(torch.autograd.Function):
     """inputs: plan, rays_o, rays_d, gt_depth|None, t_rand|None, then for each kind in plan.kinds: grid,
-    then for each kind: its parameters.  Outputs depth f64 [N], var f64 [N], rgb f32 [N,3]."""
+    then for each kind: its parameters.  Outputs depth f64 [N], var f64 [N], rgb f32 [N,3]; with plan.loss the
+    fused mapper loss (f64 scalar) comes first and is the only differentiable output."""
 
     @staticmethod
     def forward(ctx, plan, rays_o, rays_d, gt_depth, t_rand, *tensors):
@@ -457,7 +459,7 @@ class _RenderFn(torch.autograd.Function):
         static = [(i, k) for i, k in enumerate(plan.kinds) if k not in vmg and not ctx.needs_input_grad[5 + i]]
         dense = [(i, k) for i, k in enumerate(plan.kinds) if k not in vmg and ctx.needs_input_grad[5 + i]]
         nblk = [(dims[k][0] * dims[k][1] * dims[k][2] + 63) // 64 for _, k in dense]
-        arena = _ZeroArena(dev, 2 * sum(nblk) + 4 * sum(lib.enslam_packed_floats(k) for k in plan.kinds) + 256)
+        arena = _ZeroArena(dev, 2 * sum(nblk) + 4 * sum(lib.enslam_packed_floats(k) for k in plan.kinds) + 256 + 32)
         flags = [None] * nk
         grids_vm, packed = {k: vmg[k].vm for k in vmg}, {}
         _last_flags.clear()
@@ -518,19 +520,36 @@ class _RenderFn(torch.autograd.Function):
             n_act = lib.enslam_activation_floats(L.STAGE[plan.stage], N, S, act_light)
             if 0 < n_act * 4 <= ACT_WORKSPACE_LIMIT_BYTES and max(d[0] * d[1] * d[2] for d in dims.values()) < (1 << 29):
                 act = torch.empty(n_act, dtype=torch.float32, device=dev)
-        L.check(lib.enslam_render_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                      _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, st),
-                "enslam_render_fwd")
+        loss = None
+        if plan.loss is None:
+            L.check(lib.enslam_render_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
+                                          _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, st),
+                    "enslam_render_fwd")
+        else:
+            lgd, lgc, lw = plan.loss
+            loss = arena.take(1, torch.float64)
+            L.check(lib.enslam_render_loss_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
+                                               _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, _ptr(lgd),
+                                               _ptr(lgc), ctypes.c_float(lw), _ptr(loss), st), "enslam_render_loss_fwd")
         ctx.plan, ctx.S, ctx.dims, ctx.act_light, ctx.accum = plan, S, dims, act_light, accum
         ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act, flags)
+        ctx.rgb = rgb if plan.loss is not None else None
         ctx.grid_shapes = [tuple(g.shape) for g in grids]
         ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
+        if loss is not None:
+            ctx.mark_non_differentiable(depth, var, rgb)
+            return loss[0], depth, var, rgb
         return depth, var, rgb
 
     @staticmethod
-    def backward(ctx, g_depth, g_var, g_rgb):
+    def backward(ctx, *gouts):
         lib = L.lib()
         plan, S = ctx.plan, ctx.S
+        g_loss = None
+        if plan.loss is not None:
+            g_loss, g_depth, g_var, g_rgb = gouts[0], None, None, None
+        else:
+            g_depth, g_var, g_rgb = gouts
         ro, rd, z, raw, depth, grids_vm, packed, act, flags = ctx.keep
         N, dev, st = ro.shape[0], ro.device, _stream()
         nk = len(plan.kinds)
@@ -544,7 +563,8 @@ class _RenderFn(torch.autograd.Function):
             return g.detach().to(dtype).expand(shape).contiguous()
 
         gD, gV, gC = prep(g_depth, torch.float64, (N,)), prep(g_var, torch.float64, (N,)), prep(g_rgb, torch.float32, (N, 3))
-        if gD is None and gV is None and gC is None:
+        gL = prep(g_loss, torch.float64, (1,))
+        if gD is None and gV is None and gC is None and gL is None:
             return (None,) * len(needs)
         sc = _scene_struct(plan.stage, plan.bound6, plan.coarse_bound6, grids_vm, ctx.dims, packed)
         gg = (L.Grid * 4)()
@@ -580,8 +600,13 @@ class _RenderFn(torch.autograd.Function):
             g_rd = zbuf[r0 + 3 * N:r0 + 6 * N].view(N, 3)
             p_ro, p_rd = _ptr(g_ro), _ptr(g_rd)
         d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
-        L.check(lib.enslam_composite_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
-                                         _ptr(d_raw), st), "enslam_composite_bwd")
+        if gL is not None:
+            lgd, lgc, lw = plan.loss
+            L.check(lib.enslam_composite_loss_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(ctx.rgb), _ptr(lgd), _ptr(lgc),
+                                                  ctypes.c_float(lw), _ptr(gL), _ptr(d_raw), st), "enslam_composite_loss_bwd")
+        else:
+            L.check(lib.enslam_composite_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
+                                             _ptr(d_raw), st), "enslam_composite_bwd")
         dgw = None
         if act is not None and need_rays:
             dgw = torch.empty(lib.enslam_grid_handoff_floats(L.STAGE[plan.stage], N, S), dtype=torch.float32, device=dev)

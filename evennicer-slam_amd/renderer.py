@@ -53,6 +53,21 @@ class Renderer(object):
 
     def render_batch_ray(self, c, decoders, rays_d, rays_o, device, stage, gt_depth=None):
         """(depth f64 [N], uncertainty f64 [N], color f32 [N,3]) -- note rays_d comes before rays_o."""
+        return self._render(c, decoders, rays_d, rays_o, device, stage, gt_depth, None)
+
+    def render_batch_ray_rgbd_loss(self, c, decoders, rays_d, rays_o, device, stage, gt_depth, gt_color, w_color=0.2):
+        """`render_batch_ray` and the mapper's loss on its outputs (Mapper.py:548-562:
+        sum_{gt_depth>0} |gt_depth - depth| + [stage == 'color'] w_color * sum |gt_color - color|) with the loss folded
+        into the compositing launches, forward and backward.  Returns (loss f64 scalar, depth, uncertainty, color); only
+        the loss carries gradient.  Same numbers as `losses.rgbd_loss(*render_batch_ray(...))` up to the summation
+        order of the loss value."""
+        if gt_depth is None or stage == 'coarse':
+            raise ValueError("render_batch_ray_rgbd_loss needs gt_depth and a depth-guided stage (middle, fine, color)")
+        gd = gt_depth.detach().contiguous().float().reshape(-1)
+        gc = gt_color.detach().contiguous().float().reshape(-1, 3) if (stage == 'color' and gt_color is not None) else None
+        return self._render(c, decoders, rays_d, rays_o, device, stage, gt_depth, (gd, gc, float(w_color)))
+
+    def _render(self, c, decoders, rays_d, rays_o, device, stage, gt_depth, loss):
         if self.N_importance > 0:
             raise NotImplementedError("hierarchical sampling (N_importance > 0) is not exercised by the NICE "
                                       "configuration and is not built on the HIP path")
@@ -78,6 +93,7 @@ class Renderer(object):
         decs = {k: getattr(decoders, L.MLP_NAMES[k]) for k in kinds}
         plan = EF.RenderPlan(stage, self.bound, self._coarse_bound(decoders), n_lin, n_surf, self.lindisp, t_lin,
                              t_surf, kinds, decs, depth_max=self.depth_max_override if gt_depth is not None else None)
+        plan.loss = loss
         grids = []
         for k in kinds:
             g = c[L.GRID_NAMES[k]]
@@ -91,8 +107,7 @@ class Renderer(object):
         if N == 0:
             z = rays_o.new_zeros((0,))
             return z.double(), z.double(), rays_o.new_zeros((0, 3))
-        depth, var, color = EF.render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params)
-        return depth, var, color
+        return EF.render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params)
 
     def _render_chunks(self, c, decoders, rays_o, rays_d, device, stage, gt_depth):
         depth_l, var_l, col_l = [], [], []

@@ -263,6 +263,21 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
                       const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o, float *g_rays_d,
                       float *d_raw, const float *act_ws, int32_t act_light, float *dgrid_ws, void *stream);
 
+/* The mapper's RGB-D loss (Mapper.py:553-562:  sum_{gt_depth>0} |gt_depth - depth| + w_color * sum |gt_color - color|)
+ * fused into the compositing launches of the render (two dependent launches fewer per optimisation step).
+ * enslam_render_loss_fwd   : enslam_render_fwd that also ADDS the loss of this batch into loss[0] (float64, zero on
+ *   entry; one atomic per ray, so the last bits depend on the order).  gt_color NULL: depth term only.  Needs raw_out;
+ *   ray counts above the tile-mode limit (full-image renders) return ENSLAM_EUNSUPPORTED.
+ * enslam_composite_loss_bwd: enslam_composite_bwd with d(depth), d(rgb) derived from that loss and the device scalar
+ *   g_loss = d(total)/d(loss) instead of read from memory; follow with enslam_decoder_bwd. */
+int enslam_render_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                           const double *z_vals, const enslam_scene *scene, double *depth, double *var, float *rgb,
+                           float *raw_out, float *act_ws, int32_t act_light, const float *gt_depth,
+                           const float *gt_color, float w_color, double *loss, void *stream);
+int enslam_composite_loss_bwd(int32_t n_rays, int32_t n_samples, const float *raw, const double *z_vals,
+                              const double *depth, const float *rgb, const float *gt_depth, const float *gt_color,
+                              float w_color, const double *g_loss, float *d_raw, void *stream);
+
 /* The two halves of enslam_render_bwd, callable on their own.
  * enslam_composite_bwd: backward of raw2outputs_nerf_color (common.py:284-296): d(depth,var,rgb) -> d_raw [N*S,4].
  * enslam_decoder_bwd  : everything upstream of raw (decoders, gather, points), consuming d_raw.  With act_ws and

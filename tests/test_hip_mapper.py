@@ -113,3 +113,44 @@ def test_fused_adam_matches_torch_adam():
     assert opt.step_t.item() == 8
     for t, u in zip(a, b):
         assert float((t - u).abs().max()) <= 2e-6 * max(1.0, float(u.abs().max()))
+
+
+def test_render_with_fused_loss_matches_separate_loss():
+    """Renderer.render_batch_ray_rgbd_loss (loss folded into the compositing launches) against render_batch_ray +
+    losses.rgbd_loss: outputs, loss and every gradient, for the three depth-guided stages."""
+    import evennicer_slam_amd as E
+    from tests.hip_util import DEV, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    names = ['grid_middle', 'grid_fine', 'grid_color']
+    for stage in ('middle', 'fine', 'color'):
+        res = []
+        for fused in (False, True):
+            g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+            ro = rays['rays_o'].detach().clone().requires_grad_(True)
+            rd = rays['rays_d'].detach().clone().requires_grad_(True)
+            for p in model.parameters():
+                p.grad = None
+            if fused:
+                loss, depth, var, color = renderer.render_batch_ray_rgbd_loss(g, model, rd, ro, DEV, stage, rays['gt_depth'],
+                                                                              rays['gt_color'], 0.2)
+                assert not depth.requires_grad and not color.requires_grad
+            else:
+                depth, var, color = renderer.render_batch_ray(g, model, rd, ro, DEV, stage, gt_depth=rays['gt_depth'])
+                loss = E.losses.rgbd_loss(depth, color if stage == 'color' else None, rays['gt_depth'], rays['gt_color'], 0.2)
+            (loss * 1.5).backward()
+            grads = [g[k].grad for k in names] + [ro.grad, rd.grad] + [p.grad for p in model.parameters()]
+            res.append((loss.item(), depth.detach().clone(), color.detach().clone(),
+                        [None if t is None else t.detach().clone() for t in grads]))
+        (l0, d0, c0, g0), (l1, d1, c1, g1) = res
+        assert abs(l0 - l1) <= 1e-12 * abs(l0)
+        assert torch.equal(d0, d1) and torch.equal(c0, c1)
+        n_checked = 0
+        for a, b in zip(g0, g1):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30)
+                n_checked += 1
+        assert n_checked >= 4
+    with pytest.raises(ValueError):
+        renderer.render_batch_ray_rgbd_loss(grids, model, rays['rays_d'], rays['rays_o'], DEV, 'coarse', rays['gt_depth'],
+                                            rays['gt_color'])
