@@ -135,6 +135,16 @@ ENS_DEV void axis_coord(double pw, double lo, double hi, int size, int& i0, floa
     gmul = g * (float)(2.0 / (hi - lo));          // chain through the float64 normalisation
 }
 
+// The two halves of axis_coord for callers that look one point up in several grids over the SAME bound (middle, fine
+// and colour grids): the float64 normalisation (a division) once, the per-grid unnormalise / clip / floor per grid.
+ENS_DEV float axis_norm(double pw, double lo, double hi) { return (float)(((pw - lo) / (hi - lo)) * 2.0 - 1.0); }
+ENS_DEV int axis_cell(float pn, int size) {
+    float c = ((pn + 1.f) / 2.f) * (float)(size - 1);
+    const float mx = (float)(size - 1);
+    c = c <= 0.f ? 0.f : (c >= mx ? mx : c);
+    return (int)floorf(c);
+}
+
 ENS_DEV Vox make_vox(const double pw[3], const double* lo, const double* hi, const DevGrid& g) {
     Vox v;
     axis_coord(pw[0], lo[0], hi[0], g.W, v.ix, v.fx, v.gx);

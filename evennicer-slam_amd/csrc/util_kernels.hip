@@ -55,12 +55,17 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
     }
     const double lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
     double far_bb = INFINITY;
+    {   // the six face distances are ray-uniform: lanes 0..5 divide once each (float64 divisions are the long pole of
+        // this kernel), the others pick the results up
+        const int ax = lane < 6 ? (lane >> 1) : 0;
+        const double face = (lane & 1) ? (ax == 0 ? hi0 : (ax == 1 ? hi1 : hi2)) : (ax == 0 ? lo0 : (ax == 1 ? lo1 : lo2));
+        const double tq = (face - (double)ro[ray * 3 + ax]) / (double)rd[ray * 3 + ax];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double o = (double)ro[ray * 3 + a], d = (double)rd[ray * 3 + a];
-        const double t0 = (lo[a] - o) / d, t1 = (hi[a] - o) / d;
-        const double tm = t0 > t1 ? t0 : t1;            // torch.max over the two faces
-        far_bb = tm < far_bb ? tm : far_bb;            // torch.min over axes
+        for (int a = 0; a < 3; ++a) {
+            const double t0 = __shfl(tq, 2 * a), t1 = __shfl(tq, 2 * a + 1);
+            const double tm = t0 > t1 ? t0 : t1;        // torch.max over the two faces
+            far_bb = tm < far_bb ? tm : far_bb;        // torch.min over axes
+        }
     }
     far_bb += 0.01;
     const bool guided = gd != nullptr;
@@ -114,15 +119,27 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
             double pw[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) pw[a] = (double)ro[ray * 3 + a] + (double)rd[ray * 3 + a] * z;
+            float pn[3] = {0.f, 0.f, 0.f};               // normalised coordinates over Renderer.bound, shared by grids 1..3
+            if (mk.kmask & 14) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) pn[a] = axis_norm(pw[a], mk.sc.lo[a], mk.sc.hi[a]);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!((mk.kmask >> k) & 1) || mk.flags[k] == nullptr) continue;
-                const Vox v = make_vox(pw, k == 0 ? mk.sc.clo : mk.sc.lo, k == 0 ? mk.sc.chi : mk.sc.hi, mk.sc.grid[k]);
+                const DevGrid& g = mk.sc.grid[k];
+                int ix, iy, iz;
+                if (k == 0) {
+                    ix = axis_cell(axis_norm(pw[0], mk.sc.clo[0], mk.sc.chi[0]), g.W);
+                    iy = axis_cell(axis_norm(pw[1], mk.sc.clo[1], mk.sc.chi[1]), g.H);
+                    iz = axis_cell(axis_norm(pw[2], mk.sc.clo[2], mk.sc.chi[2]), g.D);
+                } else {
+                    ix = axis_cell(pn[0], g.W); iy = axis_cell(pn[1], g.H); iz = axis_cell(pn[2], g.D);
+                }
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    int64_t idx; float w;
-                    corner(v, mk.sc.grid[k], c, idx, w);
-                    mk.flags[k][idx >> 6] = 1;
+                for (int c = 0; c < 8; ++c) {            // the 8 corners, clamped like corner()
+                    const int x = min(ix + (c & 1), g.W - 1), y = min(iy + ((c >> 1) & 1), g.H - 1), zc = min(iz + (c >> 2), g.D - 1);
+                    mk.flags[k][(((int64_t)zc * g.H + y) * g.W + x) >> 6] = 1;
                 }
             }
         }
