@@ -20,6 +20,6 @@ for line in out.splitlines():
         cur[k.strip()] = v.strip()
 for r in rows:
     name = subprocess.run(["c++filt", r["name"]], capture_output=True, text=True).stdout.strip()
-    name = re.sub(r"\(.*", "", name).replace("(anonymous namespace)::", "")
+    name = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
     print(f"{name:55s} VGPR {r.get('VGPRs','?'):>4} AGPR {r.get('AGPRs','?'):>4} scratch {r.get('ScratchSize [bytes/lane]','?'):>5} "
           f"occ {r.get('Occupancy [waves/SIMD]','?'):>2} spillV {r.get('VGPRs Spill','?'):>3} LDS {r.get('LDS Size [bytes/block]','?')}")
