@@ -58,8 +58,7 @@ def run_glue(FREEZE):
 
     def it():
         dec_opt.zero_grad()
-        depth, var, color = renderer.render_batch_ray(c, model, rd, ro, dev, 'color', gt_depth=gd)
-        loss = E.losses.rgbd_loss(depth, color, gd, gc, 0.2)
+        loss, depth, var, color = renderer.render_batch_ray_rgbd_loss(c, model, rd, ro, dev, 'color', gd, gc, 0.2)
         if 'one' not in one: one['one'] = torch.ones_like(loss)
         loss.backward(gradient=one['one'])
         dec_opt.step()
