@@ -34,8 +34,10 @@ PEAK_HBM = 8.0e12
 SCENES = {      # mapping.bound of the reference configs (configs/Replica/room0.yaml:3, office0.yaml:3, rpg/recording4.yaml:4)
     'room0': [[-2.9, 8.9], [-3.2, 5.5], [-3.5, 3.3]],
     'office0': [[-5.5, 5.9], [-6.7, 5.4], [-4.7, 5.3]],
+    'recording4': [[-7.0, 9.4], [-6.5, 3.6], [-9.2, 9.5]],
 }
 CAM = dict(H=680, W=1200, fx=600.0, fy=600.0, cx=599.5, cy=339.5)       # configs/Replica/replica.yaml:37-43
+CAM_RPG = dict(H=260, W=346, fx=196.71854278974607, fy=196.68898128242577, cx=172.5, cy=129.5)     # configs/rpg/rpg.yaml:62-68
 GRID_LEN = {'coarse': 2, 'middle': 0.32, 'fine': 0.16, 'color': 0.16, 'bound_divisible': 0.32}
 
 
@@ -55,12 +57,18 @@ def build_scene_cpu(scene='room0', seed=0):
     model = E.get_model(cfg)
     bound = E.scene.scene_bound(SCENES[scene], 1.0, GRID_LEN['bound_divisible'])
     grids = E.scene.grid_init(bound, GRID_LEN)
-    depth_img = torch.rand(CAM['H'], CAM['W']) * 3.0 + 0.5
-    depth_img[300:340, :] = 0.0                                   # 5.9 % pixels without depth
-    color_img = torch.rand(CAM['H'], CAM['W'], 3)
+    cam = scene_cam(scene)
+    depth_img = torch.rand(cam['H'], cam['W']) * 3.0 + 0.5
+    z0 = int(cam['H'] * 300 / 680)
+    depth_img[z0:z0 + max(1, int(cam['H'] * 40 / 680)), :] = 0.0   # 5.9 % pixels without depth
+    color_img = torch.rand(cam['H'], cam['W'], 3)
     c2w = torch.eye(4)[:3].clone()
     c2w[:, 3] = torch.tensor([3.0, 1.0, 0.0]) if scene == 'room0' else torch.tensor([0.0, 0.0, 0.0])
-    return dict(cfg=cfg, model=model, bound=bound, grids=grids, depth_img=depth_img, color_img=color_img, c2w=c2w)
+    return dict(cfg=cfg, model=model, bound=bound, grids=grids, depth_img=depth_img, color_img=color_img, c2w=c2w, cam=cam)
+
+
+def scene_cam(scene):
+    return CAM_RPG if scene == 'recording4' else CAM
 
 
 def attach_bounds(model, bound):
@@ -73,8 +81,9 @@ def attach_bounds(model, bound):
 def make_rays(sc, n_rays, seed):
     from evennicer_slam_amd.common import get_samples
     torch.manual_seed(seed)
-    ro, rd, gd, gc = get_samples(0, CAM['H'], 0, CAM['W'], n_rays, CAM['H'], CAM['W'], CAM['fx'], CAM['fy'],
-                                 CAM['cx'], CAM['cy'], sc['c2w'], sc['depth_img'], sc['color_img'], 'cpu')
+    cam = sc.get('cam', CAM)
+    ro, rd, gd, gc = get_samples(0, cam['H'], 0, cam['W'], n_rays, cam['H'], cam['W'], cam['fx'], cam['fy'],
+                                 cam['cx'], cam['cy'], sc['c2w'], sc['depth_img'], sc['color_img'], 'cpu')
     return ro.float().contiguous(), rd.float().contiguous(), gd.float().contiguous(), gc.float().contiguous()
 
 
@@ -197,7 +206,7 @@ def main():
     ro, rd, gd, gc = [t.to(dev) for t in rays_cpu]
     ro.requires_grad_(True)
     rd.requires_grad_(True)
-    slam = types.SimpleNamespace(nice=True, bound=sc['bound'], **CAM)
+    slam = types.SimpleNamespace(nice=True, bound=sc['bound'], **sc['cam'])
     renderer = E.Renderer(sc['cfg'], None, slam)
     stage = args.stage
     kinds = EF.stage_kinds(stage)
@@ -343,7 +352,7 @@ def main():
         "metric": "rendered rays/sec (fwd+bwd)", "value": world * args.rays * args.steps / elapsed, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"Replica {args.scene} full 4-level grid, stage {stage}, {args.rays} rays x {S} samples "
+        "config": {"workload": f"{'RPG' if args.scene == 'recording4' else 'Replica'} {args.scene} full 4-level grid, stage {stage}, {args.rays} rays x {S} samples "
                                f"per GPU, render_batch_ray + mapper loss + backward (grads: grids, all decoder params, rays)",
                    "rays_per_gpu": args.rays, "samples_per_ray": S,
                    "parallelism": "1 GPU" if world == 1 else f"ray-sharded dp{world}, one bucketed RCCL all-reduce of leaf grads "
