@@ -221,7 +221,7 @@ def main():
 
     def pre():          # batch-global sampler maxima over all shards (tiny MAX all-reduce), kept outside the graph
         if dmax_static is not None:
-            dmax_static.copy_(PAR.global_depth_max(gd, force=force_comm))
+            PAR.global_depth_max(gd, force=force_comm, out=dmax_static)
 
     seed_grad, comm = {}, {'bytes': 0}
 

@@ -17,13 +17,18 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def global_depth_max(gt_depth_local, group=None, force=False):
+def global_depth_max(gt_depth_local, group=None, force=False, out=None):
     """float32 [2] {max, fl32(max*1.2)} of gt_depth over all ranks' shards (one tiny MAX all-reduce).
-    force: issue the collective even in a 1-rank group (rehearsals)."""
-    m = gt_depth_local.detach().float().max().reshape(1)
+    force: issue the collective even in a 1-rank group (rehearsals).  out: a float32 [2] tensor to fill in place (the
+    renderer's static `depth_max_override` of a captured step): three launches and the collective, no temporaries."""
+    if out is None:
+        out = torch.empty(2, dtype=torch.float32, device=gt_depth_local.device)
+    g = gt_depth_local.detach()
+    torch.amax(g if g.dtype == torch.float32 else g.float(), dim=0, keepdim=True, out=out[0:1])
     if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
-    return torch.cat([m, m * 1.2]).contiguous()
+        dist.all_reduce(out[0:1], op=dist.ReduceOp.MAX, group=group)
+    torch.mul(out[0:1], 1.2, out=out[1:2])
+    return out
 
 
 def block_flags_of(grads):
