@@ -136,10 +136,14 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
                 } else {
                     ix = axis_cell(pn[0], g.W); iy = axis_cell(pn[1], g.H); iz = axis_cell(pn[2], g.D);
                 }
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {            // the 8 corners, clamped like corner()
-                    const int x = min(ix + (c & 1), g.W - 1), y = min(iy + ((c >> 1) & 1), g.H - 1), zc = min(iz + (c >> 2), g.D - 1);
-                    mk.flags[k][(((int64_t)zc * g.H + y) * g.W + x) >> 6] = 1;
+                const int dx = (ix + 1 < g.W) ? 1 : 0;         // the 8 corners, clamped like corner(): four x-pairs of
+#pragma unroll                                               // adjacent linear indices -> mostly ONE block per pair
+                for (int c = 0; c < 4; ++c) {
+                    const int y = min(iy + (c & 1), g.H - 1), zc = min(iz + (c >> 1), g.D - 1);
+                    const int64_t idx = ((int64_t)zc * g.H + y) * g.W + ix;
+                    uint8_t* f = mk.flags[k];
+                    f[idx >> 6] = 1;
+                    if (((idx + dx) >> 6) != (idx >> 6)) f[(idx + dx) >> 6] = 1;
                 }
             }
         }
