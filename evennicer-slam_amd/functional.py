@@ -310,6 +310,43 @@ def clear_caches():
     _pack_caches.clear()
 
 
+def refresh_in_place(c, decoders, stage='color'):
+    """Bring the cached device-side forms of a map up to date IN PLACE after its tensors were updated in place
+    (`Tracker.update_para_from_mapping` copying the mapper's state into the tracker's tensors, an optimiser step):
+    the voxel-major copies of dense no-gradient grids and the packed decoders are rewritten inside their existing
+    buffers.  A captured step (graph.GraphedStep, tracker.GraphedCameraIteration) that was recorded while those caches
+    were warm contains no conversion / packing launch and reads exactly these buffers, so this call is what makes it
+    see the new map.  Must not run between a forward and its backward.  Returns the number of buffers rewritten."""
+    lib = L.lib()
+    n = 0
+    for k in stage_kinds(stage):
+        g = c[L.GRID_NAMES[k]]
+        if isinstance(g, VoxelMajorGrid):
+            continue                                    # already the kernels' layout: nothing cached
+        e = _grid_cache.items.get(id(g))
+        if e is not None and e[0]() is g and len(e) == 3 and e[1] != g._version:
+            src = g.detach()
+            src = src if src.is_contiguous() else src.contiguous()
+            L.check(lib.enslam_grid_to_voxel_major(_ptr(src), _ptr(e[2]), e[2].shape[0], _stream()), "grid_to_voxel_major")
+            _grid_cache.items[id(g)] = (e[0], g._version, e[2])
+            n += 1
+        dec = getattr(decoders, L.MLP_NAMES[k])
+        cache = _pack_caches.get(dec)
+        if cache is None or cache.packed is None:
+            continue
+        ps = decoder_params(dec, k)
+        key = tuple((id(p), p.data_ptr(), p._version) for p in ps)
+        if key != cache.key:
+            where = tuple(q[:2] for q in key)
+            if where != getattr(cache, 'where', None) or getattr(cache, 'struct', None) is None:
+                _check_params(k, ps)
+                cache.where, cache.struct = where, _fill_params_struct(k, ps)
+            L.check(lib.enslam_pack_mlp(k, ctypes.byref(cache.struct), _ptr(cache.packed), _stream()), "enslam_pack_mlp")
+            cache.key = key
+            n += 1
+    return n
+
+
 def _scene_struct(stage, bound, coarse_bound, grids_vm, grid_dims, packed):
     """enslam_scene for a stage. grids_vm / packed: dict kind -> tensor."""
     sc = L.Scene()

@@ -274,5 +274,11 @@ class GraphedCameraIteration(object):
             for dst, src in zip(self.frame, self.trk.prepare_event_frame(gt_event, gt_mask, pre_gt_color, self.scale_factor)):
                 dst.copy_(src)
 
+    def refresh_map(self):
+        """Call after the tracker's map (`trk.c` tensors, `trk.decoders` parameters) was updated in place: the captured
+        iteration reads the cached voxel-major grids and packed decoders, which this rewrites in place."""
+        from .functional import refresh_in_place
+        return refresh_in_place(self.trk.c, self.trk.decoders, 'color')
+
     def step(self):
         return self.graph.replay()

@@ -149,6 +149,20 @@ def test_static_shape_and_graphed_iteration_match_fixture(monkeypatch):
         assert rel_err(ct.grad.cpu().numpy(), fx['g_total']) <= 1e-3
     assert np.array_equal(ct.detach().cpu().numpy(), fx['camera_tensor'])
 
+    # the map changes in place (Tracker.update_para_from_mapping): the captured iteration follows after refresh_map()
+    with torch.no_grad():
+        trk.c['grid_color'].mul_(1.25)
+        trk.c['grid_fine'].add_(0.01)
+        trk.decoders.color_decoder.output_linear.weight.mul_(0.9)
+    stale = [t.item() for t in git.step()]
+    assert git.refresh_map() >= 3
+    l_rgbd, l_event, l_mask = git.step()
+    o = trk.iteration_losses(ct, img['gt_color'], img['gt_depth'], frame, int(fx['batch_size']), True, True, sf,
+                             static_shapes=True)
+    assert abs(l_rgbd.item() - o['rgbd'].item()) <= 1e-6 * abs(o['rgbd'].item())
+    assert abs(l_event.item() - o['event'].item()) <= 1e-5 * abs(o['event'].item())
+    assert abs(stale[0] - o['rgbd'].item()) > 1e-4 * abs(o['rgbd'].item())      # (before the refresh it rendered the old map)
+
 
 def E_tracker():
     import evennicer_slam_amd as E
