@@ -140,3 +140,27 @@ def get_tensor_from_camera(RT, Tquad=False):
         quad = -quad
     out = torch.cat([T, quad]) if Tquad else torch.cat([quad, T])
     return out.float().to(dev)
+
+
+def sample_pdf(bins, weights, N_samples, det=False, device='cuda:0'):
+    """Inverse-CDF ("hierarchical", NeRF sec. 5.2) samples of the piecewise-constant density `weights` over `bins`
+    (src/common.py:19-63): bins [B, M], weights [B, M-1] -> samples [B, N_samples].  det: evenly spaced quantiles,
+    else one torch.rand draw.  Plain torch ops on the inputs' device: only iMAP / N_importance > 0 use it, which no
+    shipped NICE configuration does; the HIP renderer itself raises for N_importance > 0."""
+    w = weights + 1e-5
+    cdf = torch.cumsum(w / w.sum(-1, keepdim=True), -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    lead = list(cdf.shape[:-1])
+    if det:
+        u = torch.linspace(0., 1., steps=N_samples).expand(lead + [N_samples])
+    else:
+        u = torch.rand(lead + [N_samples])
+    u = u.to(device).contiguous()
+    hi = torch.searchsorted(cdf, u, right=True)
+    lo = (hi - 1).clamp(min=0)
+    hi = hi.clamp(max=cdf.shape[-1] - 1)
+    c0, c1 = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+    b0, b1 = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+    denom = c1 - c0
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    return b0 + (u - c0) / denom * (b1 - b0)

@@ -122,3 +122,17 @@ def test_shard_ranges_cover_batch():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_sample_pdf_matches_reference_fixture():
+    """common.sample_pdf (src/common.py:19-63) against outputs of the reference's function (tests/golden/sample_pdf.npz)."""
+    import numpy as np
+    import torch
+    from evennicer_slam_amd.common import sample_pdf
+    from tests.util import load
+    fx = load("sample_pdf")
+    for case in range(3):
+        bins, w, n = torch.from_numpy(fx[f'c{case}_bins']), torch.from_numpy(fx[f'c{case}_w']), int(fx[f'c{case}_n'])
+        assert np.array_equal(sample_pdf(bins, w, n, det=True, device='cpu').numpy(), fx[f'c{case}_det'])
+        torch.manual_seed(100 + case)
+        assert np.array_equal(sample_pdf(bins, w, n, det=False, device='cpu').numpy(), fx[f'c{case}_rand'])
