@@ -215,12 +215,29 @@ def main():
         leaves += list(getattr(model, E._lib.MLP_NAMES[k]).parameters())
 
     comm_on = world > 1 or force_comm
-    dmax_static = PAR.global_depth_max(gd, force=force_comm) if (comm_on and stage != 'coarse') else None
-    if dmax_static is not None:
+    # Ray sharding hands every rank the WHOLE batch (parallel.ShardedRenderer): each rank holds all ranks' rays, so the
+    # batch maxima of gt_depth and the union of the touched 64-voxel blocks are computed locally -- one marking launch
+    # over all rays before the local step -- and the gradient SUM is the only collective of a step.
+    # ENSLAM_BENCH_EXCHANGE_FLAGS=1: the ranks only know their own rays (MAX all-reduces of the depth maximum and of the
+    # block flags instead).
+    whole_batch = comm_on and stage != 'coarse' and os.environ.get('ENSLAM_BENCH_EXCHANGE_FLAGS') != '1'
+    ro_all = rd_all = gd_all = None
+    if whole_batch:
+        others = [make_rays(sc, args.rays, seed=1000 + r) for r in range(world)]
+        ro_all, rd_all, gd_all = [torch.cat([o[i] for o in others]).to(dev) for i in range(3)]
+    dmax_static = None
+    if comm_on and stage != 'coarse':
+        dmax_static = PAR.global_depth_max(gd_all if whole_batch else gd, force=force_comm and not whole_batch)
         renderer.depth_max_override = dmax_static
+    prep = {'flags': None, 'prepared': None}
 
-    def pre():          # batch-global sampler maxima over all shards (tiny MAX all-reduce), kept outside the graph
-        if dmax_static is not None:
+    def pre():          # what precedes the local step, outside the graph
+        if whole_batch:
+            torch.amax(gd_all, dim=0, keepdim=True, out=dmax_static[0:1])
+            torch.mul(dmax_static[0:1], 1.2, out=dmax_static[1:2])
+            prep['flags'] = PAR.batch_block_flags(renderer, grids, model, ro_all, rd_all, gd_all, stage, out=prep['flags'])
+            prep['prepared'] = PAR.PreparedFlags([prep['flags'][id(t)] for t in leaves if t.dim() == 5])
+        elif dmax_static is not None:       # batch-global sampler maxima over all shards (tiny MAX all-reduce)
             PAR.global_depth_max(gd, force=force_comm, out=dmax_static)
 
     seed_grad, comm = {}, {'bytes': 0}
@@ -247,7 +264,10 @@ def main():
         return loss
 
     def post():         # one bucketed RCCL all-reduce of the leaf gradients
-        if comm_on:
+        if comm_on and whole_batch:
+            comm['bytes'] = PAR.allreduce_gradients(leaves, block_flags=prep['flags'], force=force_comm,
+                                                    prepared=prep['prepared'])
+        elif comm_on:
             comm['bytes'] = PAR.allreduce_gradients(leaves, block_flags=EF.last_block_flags(), force=force_comm)
 
     def step():

@@ -58,7 +58,7 @@ def _block_views(g):
     return main, tail
 
 
-def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=None, force=False):
+def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=None, force=False, prepared=None):
     """Sum `.grad` of the given leaf tensors over ranks through one flat bucket (one SUM collective per step).
     Leaves whose grad is None on this rank contribute zeros, so every rank issues the same collectives.
 
@@ -66,7 +66,9 @@ def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=Non
     compact_grids the bucket carries, per grid, only the union over ranks of those blocks: one small MAX
     all-reduce of the block flags (block_flags: {id(tensor): uint8 flags}, normally functional.last_block_flags();
     derived from the gradients when absent), a gather of the flagged blocks, the SUM all-reduce, a scatter back.
-    Returns the bucket size in bytes.  force: run the whole sequence even in a 1-rank group (rehearsals)."""
+    Returns the bucket size in bytes.  force: run the whole sequence even in a 1-rank group (rehearsals).
+    prepared: a PreparedFlags made before the local step from flags that are already the union over ranks (HIP
+    tensors): no flag collective and no host wait here."""
     from .functional import VoxelMajorGrid
     tensors = [t for t in tensors if t is not None and (isinstance(t, VoxelMajorGrid) or t.requires_grad)]
     if not tensors or not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
@@ -76,7 +78,7 @@ def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=Non
             t.grad = torch.zeros_like(t)
     first = tensors[0].grad_vm if isinstance(tensors[0], VoxelMajorGrid) else tensors[0]
     if first.is_cuda:
-        return _allreduce_hip(tensors, group, compact_grids, block_flags)
+        return _allreduce_hip(tensors, group, compact_grids, block_flags, prepared)
     if any(isinstance(t, VoxelMajorGrid) for t in tensors):
         raise TypeError("VoxelMajorGrid gradients live on a HIP device")
     grid_ids = [i for i, t in enumerate(tensors) if compact_grids and t.dim() == 5 and t.shape[0] == 1]
@@ -123,7 +125,7 @@ def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=Non
     return bucket.numel() * 4
 
 
-def _allreduce_hip(tensors, group, compact_grids, block_flags):
+def _allreduce_hip(tensors, group, compact_grids, block_flags, prepared=None):
     """Device tensors: the bucket is packed and unpacked by one HIP launch each (`enslam_bucket_pack/_unpack`) instead
     of ~100 index_select / copy launches.  Per step: flag MAX all-reduce, prefix sum, ONE host read (the bucket
     size, which the collective needs on the host), pack, SUM all-reduce, unpack."""
@@ -166,7 +168,9 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags):
         if g.dtype != torch.float32:
             raise TypeError(f"gradient bucket carries float32 tensors, got {g.dtype}")
     n_slots, allf, pos = 0, None, None
-    if grid_items:
+    if grid_items and prepared is not None and prepared.matches([it[3] for it in grid_items]):
+        allf, pos, n_slots = prepared.allf, prepared.pos, prepared.n_slots()      # made while the local step ran
+    elif grid_items:
         allf = torch.cat([it[3] for it in grid_items]) if len(grid_items) > 1 else grid_items[0][3].clone()
         dist.all_reduce(allf, op=dist.ReduceOp.MAX, group=group)          # union of the touched blocks
         pos = torch.cumsum(allf, 0, dtype=torch.int32)
@@ -194,6 +198,72 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags):
     dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     run(lib.enslam_bucket_unpack, "enslam_bucket_unpack")
     return bucket.numel() * 4
+
+
+class PreparedFlags:
+    """Bucket layout of a step whose touched-block flags are known BEFORE its local step runs and are already the union
+    over ranks -- the case of ray sharding, where every rank holds the whole batch (ShardedRenderer) and can mark the
+    blocks of all rays itself (`batch_block_flags`).  Construction enqueues the prefix sum and an asynchronous read of
+    the bucket size; `allreduce_gradients(..., prepared=this)` after the backward then needs neither the flag
+    collective nor a host wait (the read finished while the step was running).
+
+    flag_list: the uint8 flag tensors of the grids, in the order the grids appear in the tensors later handed to
+    allreduce_gradients (the same objects as in its block_flags dict)."""
+
+    def __init__(self, flag_list):
+        self.ids = [(f.data_ptr(), f.numel()) for f in flag_list]
+        self.allf = torch.cat([f.reshape(-1) for f in flag_list]) if len(flag_list) > 1 else flag_list[0].reshape(-1).clone()
+        self.pos = torch.cumsum(self.allf, 0, dtype=torch.int32)
+        self.count = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self.count.copy_(self.pos[-1:], non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def matches(self, flag_list):
+        return [(f.data_ptr(), f.numel()) for f in flag_list] == self.ids
+
+    def n_slots(self):
+        self.event.synchronize()
+        return int(self.count[0])
+
+
+def batch_block_flags(renderer, c, decoders, rays_o, rays_d, gt_depth, stage, out=None):
+    """{id(grid tensor): uint8 flags} of the 64-voxel blocks the samples of a ray batch touch in the dense grids of
+    `stage` -- the sampler's block marking on its own (one launch), for batches that are not rendered here: the other
+    ranks' blocks of a sharded batch.  The batch maxima of gt_depth are taken over the rays given, i.e. pass the whole
+    batch.  Deterministic sampling only (perturb == 0).  out: flags dict of an earlier call to refill."""
+    import ctypes
+    from . import _lib as L
+    from . import functional as EF
+    if renderer.perturb > 0.:
+        raise ValueError("batch_block_flags: perturbed sampling draws its own random numbers per call")
+    lib = L.lib()
+    dev = rays_o.device
+    N = rays_o.shape[0]
+    guided = gt_depth is not None and stage != 'coarse'
+    n_lin, n_surf = renderer.N_samples, (renderer.N_surface if guided else 0)
+    t_lin, t_surf = renderer._t_vals(dev, n_lin, renderer.N_surface)
+    kinds = [k for k in EF.stage_kinds(stage) if not isinstance(c[L.GRID_NAMES[k]], EF.VoxelMajorGrid)]
+    grids = {k: c[L.GRID_NAMES[k]] for k in kinds}
+    if out is None:
+        out = {id(g): torch.empty((g.shape[2] * g.shape[3] * g.shape[4] + 63) // 64, dtype=torch.uint8, device=dev)
+               for g in grids.values()}
+    msc = L.Scene()
+    msc.bound, msc.coarse_bound = EF.bound6(renderer.bound), EF.bound6(renderer._coarse_bound(decoders))
+    fptr = (ctypes.c_void_p * 4)()
+    for k, g in grids.items():
+        f = out[id(g)]
+        f.zero_()
+        msc.grids[k].D, msc.grids[k].H, msc.grids[k].W = (int(x) for x in g.shape[2:])
+        fptr[k] = f.data_ptr()
+    ro, rd = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
+    gd = gt_depth.detach().contiguous().float().reshape(-1) if guided else None
+    z = torch.empty((N, n_lin + n_surf), dtype=torch.float64, device=dev)
+    scratch = torch.empty(2, dtype=torch.float32, device=dev)
+    L.check(lib.enslam_sample_rays(N, n_lin, n_surf, EF._ptr(ro), EF._ptr(rd), EF._ptr(gd), msc.bound, EF._ptr(t_lin),
+                                   EF._ptr(t_surf), int(bool(renderer.lindisp)), None, EF._ptr(scratch), 0, EF._ptr(z), L.STAGE[stage],
+                                   ctypes.byref(msc), fptr, EF._stream()), "enslam_sample_rays")
+    return out
 
 
 class ShardedRenderer:

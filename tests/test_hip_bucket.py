@@ -144,3 +144,65 @@ def test_two_rank_allreduce_of_hip_gradients():
         assert np.array_equal(o['unused'], np.zeros(4, np.float32))
         # grid: blocks 1, 4, 6 (partial, always sent); voxel-major grid: blocks 1, 2; small: 6 + 4 floats
         assert o['nbytes'] == 4 * (32 * 64 * (3 + 2) + 10)
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import evennicer_slam_amd as E
+        from evennicer_slam_amd import parallel as PAR
+        from tests.hip_util import DEV, tiny_on_gpu
+        from tests.util import GRID_KEYS
+        s, bound, model, grids, rays, renderer = tiny_on_gpu()
+        g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+        ro, rd, gd, gc = rays['rays_o'], rays['rays_d'], rays['gt_depth'], rays['gt_color']
+        leaves = [g[k] for k in ('grid_middle', 'grid_fine', 'grid_color')] + list(model.color_decoder.parameters())
+        # every rank holds the whole batch: union of the touched blocks and the bucket layout before the local step
+        flags = PAR.batch_block_flags(renderer, g, model, ro, rd, gd, 'color')
+        prepared = PAR.PreparedFlags([flags[id(t)] for t in leaves if t.dim() == 5])
+        sr = PAR.ShardedRenderer(renderer)
+        (depth, var, color), sl = sr.render_batch_ray(g, model, rd, ro, DEV, 'color', gt_depth=gd)
+        E.losses.rgbd_loss(depth, color, gd[sl], gc[sl], 0.2).backward()
+        own_flags = E.functional.last_block_flags()
+        covered = all(bool((flags[id(t)] >= own_flags[id(t)]).all()) for t in leaves if t.dim() == 5)
+        nbytes = PAR.allreduce_gradients(leaves, block_flags=flags, prepared=prepared)
+        torch.cuda.synchronize()
+        q.put({'rank': rank, 'nbytes': nbytes, 'covered': covered, 'slice': (sl.start, sl.stop),
+               'grads': [t.grad.cpu().numpy() for t in leaves]})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_step_with_local_union_flags_matches_unsharded():
+    """Ray-sharded step on HIP tensors, 2 ranks: the union of touched blocks marked locally over the whole batch
+    (batch_block_flags), bucket layout prepared before the step (PreparedFlags), ONE collective -- the summed gradients
+    equal the unsharded step's."""
+    import torch.multiprocessing as mp
+    import evennicer_slam_amd as E
+    from tests.hip_util import DEV, tiny_on_gpu
+    world, port = 2, 37500 + (os.getpid() % 2000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=600) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+    leaves = [g[k] for k in ('grid_middle', 'grid_fine', 'grid_color')] + list(model.color_decoder.parameters())
+    depth, var, color = renderer.render_batch_ray(g, model, rays['rays_d'], rays['rays_o'], DEV, 'color', gt_depth=rays['gt_depth'])
+    E.losses.rgbd_loss(depth, color, rays['gt_depth'], rays['gt_color'], 0.2).backward()
+    want = [t.grad.cpu().numpy() for t in leaves]
+    assert outs[0]['slice'] == (0, 32) and outs[1]['slice'] == (32, 64)
+    for o in outs:
+        assert o['covered'] and o['nbytes'] > 0
+        for a, b in zip(o['grads'], want):
+            assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-30)
+    for a, b in zip(outs[0]['grads'], outs[1]['grads']):
+        assert np.array_equal(a, b)                         # replicas hold identical sums
