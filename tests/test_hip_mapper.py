@@ -154,3 +154,40 @@ def test_render_with_fused_loss_matches_separate_loss():
     with pytest.raises(ValueError):
         renderer.render_batch_ray_rgbd_loss(grids, model, rays['rays_d'], rays['rays_o'], DEV, 'coarse', rays['gt_depth'],
                                             rays['gt_color'])
+
+
+def test_coarse_grid_in_device_layout_matches_dense_path():
+    """The coarse mapper (Mapper.py:326-328: keys = ['grid_coarse'], stage 'coarse') through MaskedGridOptimizer: same
+    outputs and gradients as the dense leaf, and one Adam step equal to torch.optim.Adam on the dense grid."""
+    import evennicer_slam_amd as E
+    from evennicer_slam_amd.mapper import MaskedGridOptimizer
+    from tests.hip_util import DEV, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    try:
+        dense = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+        d, v, c = renderer.render_batch_ray(dense, model, rays['rays_d'], rays['rays_o'], DEV, 'coarse')
+        w = torch.linspace(0.5, 1.5, d.shape[0], device=DEV, dtype=d.dtype)
+        (d * w).sum().backward()
+        ref = dense['grid_coarse'].grad
+        assert float(ref.abs().max()) > 0
+        work = {k: v.clone() for k, v in grids.items()}
+        opt = MaskedGridOptimizer(work, None, keys=('grid_coarse',))
+        d2, v2, c2 = renderer.render_batch_ray(opt.render_grids(), model, rays['rays_d'], rays['rays_o'], DEV, 'coarse')
+        assert torch.equal(d, d2)
+        (d2 * w).sum().backward()
+        G = opt.grids['grid_coarse']
+        D, H, W = G.dims
+        got = G.grad_vm.reshape(D, H, W, 32).permute(3, 0, 1, 2)[None]
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        # one optimiser step
+        tref = torch.optim.Adam([dense['grid_coarse']], lr=0.01)
+        tref.step()
+        opt.step({'grid_coarse': 0.01})
+        opt.write_back()
+        assert float((work['grid_coarse'] - dense['grid_coarse'].detach()).abs().max()) <= 2e-6
+        assert float(G.grad_vm.abs().max()) == 0.0                       # accumulators cleared by the step
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(True)
