@@ -10,6 +10,8 @@ from .common import get_rays, get_rays_rescale
 
 
 class Renderer(object):
+    FUSED_LOSS_MAX_RAYS = 32768         # the tile-mode limit of enslam_render_fwd (csrc/render_fwd.hip)
+
     def __init__(self, cfg, args, slam, points_batch_size=500000, ray_batch_size=100000):
         self.ray_batch_size = ray_batch_size
         self.points_batch_size = points_batch_size
@@ -65,6 +67,12 @@ class Renderer(object):
             raise ValueError("render_batch_ray_rgbd_loss needs gt_depth and a depth-guided stage (middle, fine, color)")
         gd = gt_depth.detach().contiguous().float().reshape(-1)
         gc = gt_color.detach().contiguous().float().reshape(-1, 3) if (stage == 'color' and gt_color is not None) else None
+        if rays_o.shape[0] > self.FUSED_LOSS_MAX_RAYS:
+            # full-image batches run the one-wave-per-ray forward with compositing inside the kernel: separate loss launches
+            from .losses import rgbd_loss
+            depth, var, color = self._render(c, decoders, rays_d, rays_o, device, stage, gt_depth, None)
+            loss = rgbd_loss(depth, color if gc is not None else None, gd, gc, w_color)
+            return loss, depth.detach(), var.detach(), color.detach()
         return self._render(c, decoders, rays_d, rays_o, device, stage, gt_depth, (gd, gc, float(w_color)))
 
     def _render(self, c, decoders, rays_d, rays_o, device, stage, gt_depth, loss):

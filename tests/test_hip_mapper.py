@@ -191,3 +191,22 @@ def test_coarse_grid_in_device_layout_matches_dense_path():
     finally:
         for p in model.parameters():
             p.requires_grad_(True)
+
+
+def test_fused_loss_falls_back_above_the_tile_mode_limit(monkeypatch):
+    import evennicer_slam_amd as E
+    from tests.hip_util import DEV, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+    monkeypatch.setattr(type(renderer), 'FUSED_LOSS_MAX_RAYS', 8)       # the 64-ray batch now counts as "large"
+    loss, depth, var, color = renderer.render_batch_ray_rgbd_loss(g, model, rays['rays_d'], rays['rays_o'], DEV, 'color',
+                                                                  rays['gt_depth'], rays['gt_color'], 0.2)
+    loss.backward()
+    g2 = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+    monkeypatch.setattr(type(renderer), 'FUSED_LOSS_MAX_RAYS', 32768)
+    loss2, *_ = renderer.render_batch_ray_rgbd_loss(g2, model, rays['rays_d'], rays['rays_o'], DEV, 'color', rays['gt_depth'],
+                                                    rays['gt_color'], 0.2)
+    loss2.backward()
+    assert abs(loss.item() - loss2.item()) <= 1e-12 * abs(loss2.item()) and not depth.requires_grad
+    a, b = g['grid_color'].grad, g2['grid_color'].grad
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
