@@ -394,6 +394,7 @@ def main():
             "kernel": "decoder_bwd_split_kernel", "bound": "mfma", "achieved": flops / avg / 1e12, "peak": PEAK_F32_MFMA / 1e12,
             "unit": "TFLOP/s", "frac": flops / avg / PEAK_F32_MFMA, "traffic": traffic,
             "avg_launch_us": avg * 1e6, "launches": int(len(dur)),
+            "peak_measured": 138.9,     # TFLOP/s, v_mfma_f32_16x16x4_f32 micro-benchmark on the box (profiles/r01_peaks.txt)
             "step_frac": step_flops / PEAK_F32_MFMA / (elapsed / args.steps),
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
