@@ -99,7 +99,7 @@ _SIGS = {
                                          c_void_p]),
     "enslam_render_loss_fwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene), c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, ctypes.c_float,
-                                              c_void_p, c_void_p]),
+                                              c_void_p, c_void_p, c_void_p]),
     "enslam_composite_loss_bwd": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  ctypes.c_float, c_void_p, c_void_p, c_void_p]),
     "enslam_composite_fwd": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -109,6 +109,9 @@ _SIGS = {
     "enslam_decoder_bwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
                                           c_void_p, c_void_p, c_int32, c_void_p, POINTER(Grid), POINTER(c_void_p), c_void_p,
                                           c_void_p, c_void_p]),
+    "enslam_decoder_bwd_scaled": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
+                                                 c_void_p, c_void_p, c_void_p, c_int32, c_void_p, POINTER(Grid), POINTER(c_void_p),
+                                                 c_void_p, c_void_p, c_void_p]),
     "enslam_rgbd_loss_fwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,
                                             c_void_p]),
     "enslam_rgbd_loss_bwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,

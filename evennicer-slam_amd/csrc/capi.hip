@@ -501,7 +501,7 @@ int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
 int enslam_render_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                            const double* z_vals, const enslam_scene* scene, double* depth, double* var, float* rgb,
                            float* raw_out, float* act_ws, int32_t act_light, const float* gt_depth, const float* gt_color,
-                           float w_color, double* loss, void* stream) {
+                           float w_color, double* loss, float* d_raw_unit, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
@@ -511,7 +511,7 @@ int enslam_render_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, con
     if (act_ws != nullptr)
         for (int k = 1; k < 4; ++k)
             if (d.grid[k].data && (int64_t)d.grid[k].D * d.grid[k].H * d.grid[k].W >= ACT_MAX_VOXELS) return ENSLAM_EUNSUPPORTED;
-    const LossSpec ls{gt_depth, gt_color, w_color, loss, nullptr};
+    const LossSpec ls{gt_depth, gt_color, w_color, loss, nullptr, d_raw_unit};
     const int rc = ens_launch_render_fwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, nullptr, 0, 1, d, depth, var, rgb,
                                          raw_out, stage == ENSLAM_STAGE_COARSE ? nullptr : act_ws, act_light != 0,
                                          (hipStream_t)stream, &ls);
@@ -523,7 +523,7 @@ int enslam_composite_loss_bwd(int32_t n_rays, int32_t n_samples, const float* ra
     if (n_rays < 0 || n_samples < 1 || n_samples > 64) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (!raw || !z_vals || !depth || !gt_depth || !g_loss || !d_raw || (gt_color && !rgb)) return ENSLAM_EINVAL;
-    const LossSpec ls{gt_depth, gt_color, w_color, nullptr, g_loss};
+    const LossSpec ls{gt_depth, gt_color, w_color, nullptr, g_loss, nullptr};
     return ens_launch_composite_bwd(n_rays, n_samples, raw, z_vals, depth, nullptr, nullptr, nullptr, d_raw,
                                     (hipStream_t)stream, &ls, rgb) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
@@ -571,6 +571,13 @@ int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const f
                        const double* z_vals, const enslam_scene* scene, const float* d_raw, const float* act_ws,
                        int32_t act_light, float* dgrid_ws, const enslam_grid* grad_grids, float* const* grad_packed,
                        float* g_rays_o, float* g_rays_d, void* stream) {
+    return enslam_decoder_bwd_scaled(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, d_raw, nullptr, act_ws, act_light,
+                                     dgrid_ws, grad_grids, grad_packed, g_rays_o, g_rays_d, stream);
+}
+int enslam_decoder_bwd_scaled(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                              const double* z_vals, const enslam_scene* scene, const float* d_raw, const double* d_raw_scale,
+                              const float* act_ws, int32_t act_light, float* dgrid_ws, const enslam_grid* grad_grids,
+                              float* const* grad_packed, float* g_rays_o, float* g_rays_d, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
@@ -589,7 +596,7 @@ int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const f
             return ENSLAM_EINVAL;
     }
     return ens_launch_decoder_bwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, d_raw, act_ws, act_light != 0, dgrid_ws, gg,
-                                  grad_packed, g_rays_o, g_rays_d, (hipStream_t)stream);
+                                  grad_packed, g_rays_o, g_rays_d, (hipStream_t)stream, d_raw_scale);
 }
 
 int enslam_ray_grad_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,

@@ -12,6 +12,8 @@ struct LossSpec {
     float w;                     // colour weight
     double* loss;                // forward: += sum of the rays' terms (zero on entry)
     const double* g_loss;        // backward: d(total)/d(loss), device scalar
+    float* d_raw_unit;           // forward (optional): d(loss)/d(raw) for g_loss = 1, [N*S,4] -- lets the backward start at the
+                                 // decoders (ens_launch_decoder_bwd's draw_scale = g_loss) without a compositing launch
 };
 
 // one segment of a decoder re-layout: dst[r*dst_ld + c] = T ? src[c*src_ld + r] : src[r*src_ld + c]
@@ -127,4 +129,4 @@ int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* 
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
                            const DevScene& sc, const float* d_raw, const float* act_ws, int act_light, float* dgrid_ws,
                            const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,
-                           hipStream_t st);
+                           hipStream_t st, const double* draw_scale = nullptr);

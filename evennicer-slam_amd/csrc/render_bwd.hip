@@ -330,6 +330,7 @@ struct BwdArgs {
     const float* rd;
     const double* z;
     const float* d_raw;
+    const double* draw_scale;   // null, or a device scalar every d_raw value is multiplied by (unit gradients of a fused loss)
     const float* act_ws;     // forward activations (render_fwd_kernel) or null: recompute
     int act_light;           // act_ws holds the light layout (coordinates | masks | cell records): light kernel only
     float* dgrid_ws;         // decoder -> grid_bwd_kernel hand-off (saved path): [tile][slot][DG_STRIDE]
@@ -342,6 +343,7 @@ struct BwdArgs {
     int role_kind[4];
     int n_roles;
 };
+ENS_DEV float draw_scale_of(const BwdArgs& A) { return A.draw_scale != nullptr ? (float)A.draw_scale[0] : 1.f; }
 
 // ------------------------------------------------------------------------------------------------
 // MLP (middle / fine / color) backward for one workgroup role
@@ -519,7 +521,7 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
         const bool tvalid = tile_raw < n_tiles;
         const int tile = __builtin_amdgcn_readfirstlane((int)(tvalid ? tile_raw : n_tiles - 1));
         const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
-        f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4);
+        f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4) * draw_scale_of(A);
         if (!tvalid) draw = splat4(0.f);
         float dj[NE];                                               // d(loss)/d(output j) of this lane's sample
         if constexpr (NOUT == 4) { dj[0] = draw[0]; dj[1] = draw[1]; dj[2] = draw[2]; } else { dj[0] = draw[3]; }
@@ -881,6 +883,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         const int64_t tr = b + wave;
         return __builtin_amdgcn_readfirstlane((int)(tr < n_tiles ? tr : n_tiles - 1));
     };
+    const float dscale = draw_scale_of(A);
     f32x4 draw_n = splat4(0.f);
     uint2 mw_n = make_uint2(0u, 0u);
     if ((int64_t)wg * 4 < n_tiles) {
@@ -892,7 +895,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         const int64_t tile_raw = base + wave;
         const bool tvalid = tile_raw < n_tiles;
         const int tile = tile_of(base);
-        f32x4 draw = draw_n;
+        f32x4 draw = draw_n * dscale;
         const uint2 mw = mw_n;
         if (base + stride < n_tiles) {
             const int t1 = tile_of(base + stride);
@@ -1291,7 +1294,7 @@ ENS_DEV void feat_role(const BwdArgs& A, int wg, int n_wg, float* smem) {
         const bool tvalid = tile_raw < n_tiles;
         const int tile = __builtin_amdgcn_readfirstlane((int)(tvalid ? tile_raw : n_tiles - 1));
         const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
-        f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4);
+        f32x4 draw = *reinterpret_cast<const f32x4*>(A.d_raw + G.sidx * 4) * draw_scale_of(A);
         if (!tvalid) draw = splat4(0.f);
         f32x4 dout = splat4(0.f);
         if (q == 0) dout[0] = draw[3];
@@ -1492,7 +1495,7 @@ int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* 
                              const double* g_depth, const double* g_var, const float* g_rgb, float* d_raw,
                              hipStream_t st, const LossSpec* ls, const float* rgb) {
     if (n_rays <= 0) return 0;
-    LossSpec l{nullptr, nullptr, 0.f, nullptr, nullptr};
+    LossSpec l{nullptr, nullptr, 0.f, nullptr, nullptr, nullptr};
     if (ls != nullptr) l = *ls;
     composite_bwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(S, raw, z, depth, g_depth, g_var, g_rgb, d_raw, l, rgb);
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -1501,13 +1504,13 @@ int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* 
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
                            const DevScene& sc, const float* d_raw, const float* act_ws, int act_light, float* dgrid_ws,
                            const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,
-                           hipStream_t st) {
+                           hipStream_t st, const double* draw_scale) {
     if (n_rays <= 0) return 0;
     BwdArgs A;
     A.act_light = act_light;
     A.act_ws = stage == 0 ? nullptr : act_ws;
     A.dgrid_ws = dgrid_ws;
-    A.n_rays = n_rays; A.ntl = ntl; A.ro = ro; A.rd = rd; A.z = z; A.d_raw = d_raw; A.sc = sc;
+    A.n_rays = n_rays; A.ntl = ntl; A.ro = ro; A.rd = rd; A.z = z; A.d_raw = d_raw; A.draw_scale = draw_scale; A.sc = sc;
     A.g_ro = (g_ro && g_rd) ? g_ro : nullptr;
     A.g_rd = (g_ro && g_rd) ? g_rd : nullptr;
     // roles and their relative cost (MFMA count per tile: middle/color 270, fine 350)

@@ -580,6 +580,34 @@ __global__ __launch_bounds__(1024) void composite_fwd_kernel(int n_rays, int S, 
                 term += (double)(ls.w * ((fabsf(ls.gc[ray * 3] - cr) + fabsf(ls.gc[ray * 3 + 1] - cg)) + fabsf(ls.gc[ray * 3 + 2] - cb)));
         }
     }
+    if (ls.d_raw_unit != nullptr) {                  // backward of the compositing for d(total)/d(loss) = 1, same arithmetic
+        const float t = ls.gd[ray];                  // as composite_bwd_kernel (render_bwd.hip) with the loss's gradients
+        const double diff = (double)t - dep;
+        const double gD = t > 0.f ? (diff > 0.0 ? -1.0 : (diff < 0.0 ? 1.0 : 0.0)) : 0.0;
+        float gcl[3] = {0.f, 0.f, 0.f};
+        if (ls.gc != nullptr) {
+            const float cc[3] = {cr, cg, cb};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float d = ls.gc[ray * 3 + a] - cc[a];
+                gcl[a] = -ls.w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            }
+        }
+        float gw = (float)(gD * zk);
+        gw += gcl[0] * rw[0] + gcl[1] * rw[1] + gcl[2] * rw[2];
+        gw = valid ? gw : 0.f;
+        const float gww = gw * w;
+        float suf = gww;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float tt = __shfl_down(suf, off);
+            suf = lane + off < 64 ? suf + tt : suf;
+        }
+        suf -= gww;
+        const float ga = gw * T - suf / m;
+        const float gocc = ga * (1.f - alpha) * alpha * 10.f;
+        if (valid && rvalid) *reinterpret_cast<f32x4*>(ls.d_raw_unit + sidx * 4) = f32x4{gcl[0] * w, gcl[1] * w, gcl[2] * w, gocc};
+    }
     if (ls.gd != nullptr) {                          // (uniform over the launch)
         if (lane == 0) red[wave] = term;
         __syncthreads();
@@ -611,7 +639,7 @@ int launch_stage(int ntl, int64_t n_units, const float* ro, const float* rd, con
 int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* z, double* depth, double* var,
                              float* rgb, float* weights, hipStream_t st, const LossSpec* ls) {
     if (n_rays <= 0) return 0;
-    LossSpec l{nullptr, nullptr, 0.f, nullptr, nullptr};
+    LossSpec l{nullptr, nullptr, 0.f, nullptr, nullptr, nullptr};
     if (ls != nullptr) l = *ls;
     if (l.gd != nullptr) composite_fwd_kernel<<<dim3((n_rays + 15) / 16), dim3(1024), 0, st>>>(n_rays, S, raw, z, depth, var, rgb, weights, l);
     else composite_fwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(n_rays, S, raw, z, depth, var, rgb, weights, l);

@@ -565,12 +565,16 @@ class _RenderFn(torch.autograd.Function):
         else:
             lgd, lgc, lw = plan.loss
             loss = arena.take(1, torch.float64)
+            # the compositing launch also leaves d(loss)/d(raw) for a unit loss gradient: the backward starts at the decoders
+            d_raw_unit = torch.empty((N * S, 4), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
             L.check(lib.enslam_render_loss_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                                _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, _ptr(lgd),
-                                               _ptr(lgc), ctypes.c_float(lw), _ptr(loss), st), "enslam_render_loss_fwd")
+                                               _ptr(lgc), ctypes.c_float(lw), _ptr(loss), _ptr(d_raw_unit), st),
+                    "enslam_render_loss_fwd")
         ctx.plan, ctx.S, ctx.dims, ctx.act_light, ctx.accum = plan, S, dims, act_light, accum
         ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act, flags)
         ctx.rgb = rgb if plan.loss is not None else None
+        ctx.d_raw_unit = d_raw_unit if plan.loss is not None else None
         ctx.grid_shapes = [tuple(g.shape) for g in grids]
         ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
         if loss is not None:
@@ -636,12 +640,16 @@ class _RenderFn(torch.autograd.Function):
             g_ro = zbuf[r0:r0 + 3 * N].view(N, 3)
             g_rd = zbuf[r0 + 3 * N:r0 + 6 * N].view(N, 3)
             p_ro, p_rd = _ptr(g_ro), _ptr(g_rd)
-        d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
-        if gL is not None:
+        d_scale = None
+        if gL is not None and ctx.d_raw_unit is not None:
+            d_raw, d_scale = ctx.d_raw_unit, gL             # unit gradients from the forward, scaled inside the decoder backward
+        elif gL is not None:
+            d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
             lgd, lgc, lw = plan.loss
             L.check(lib.enslam_composite_loss_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(ctx.rgb), _ptr(lgd), _ptr(lgc),
                                                   ctypes.c_float(lw), _ptr(gL), _ptr(d_raw), st), "enslam_composite_loss_bwd")
         else:
+            d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
             L.check(lib.enslam_composite_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
                                              _ptr(d_raw), st), "enslam_composite_bwd")
         dgw = None
@@ -651,9 +659,9 @@ class _RenderFn(torch.autograd.Function):
         if ev is not None:                      # bench.py: HIP events around the dominant kernel, on this stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        L.check(lib.enslam_decoder_bwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                       _ptr(d_raw), _ptr(act), ctx.act_light, _ptr(dgw), gg, gpk, p_ro, p_rd, st),
-                "enslam_decoder_bwd")
+        L.check(lib.enslam_decoder_bwd_scaled(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
+                                              _ptr(d_raw), _ptr(d_scale), _ptr(act), ctx.act_light, _ptr(dgw), gg, gpk, p_ro, p_rd,
+                                              st), "enslam_decoder_bwd")
         if ev is not None:
             e1.record()
             ev.append((e0, e1))

@@ -266,14 +266,16 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
 /* The mapper's RGB-D loss (Mapper.py:553-562:  sum_{gt_depth>0} |gt_depth - depth| + w_color * sum |gt_color - color|)
  * fused into the compositing launches of the render (two dependent launches fewer per optimisation step).
  * enslam_render_loss_fwd   : enslam_render_fwd that also ADDS the loss of this batch into loss[0] (float64, zero on
- *   entry; one atomic per ray, so the last bits depend on the order).  gt_color NULL: depth term only.  Needs raw_out;
- *   ray counts above the tile-mode limit (full-image renders) return ENSLAM_EUNSUPPORTED.
+ *   entry; one atomic per 16 rays, so the last bits depend on the order).  gt_color NULL: depth term only.  Needs raw_out;
+ *   ray counts above the tile-mode limit (full-image renders) return ENSLAM_EUNSUPPORTED.  d_raw_unit (optional,
+ *   float32 [N*S,4]): d(loss)/d(raw) for g_loss = 1, so that the backward can start at enslam_decoder_bwd_scaled
+ *   (d_raw = d_raw_unit, d_raw_scale = g_loss) without a compositing launch.
  * enslam_composite_loss_bwd: enslam_composite_bwd with d(depth), d(rgb) derived from that loss and the device scalar
  *   g_loss = d(total)/d(loss) instead of read from memory; follow with enslam_decoder_bwd. */
 int enslam_render_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                            const double *z_vals, const enslam_scene *scene, double *depth, double *var, float *rgb,
                            float *raw_out, float *act_ws, int32_t act_light, const float *gt_depth,
-                           const float *gt_color, float w_color, double *loss, void *stream);
+                           const float *gt_color, float w_color, double *loss, float *d_raw_unit, void *stream);
 int enslam_composite_loss_bwd(int32_t n_rays, int32_t n_samples, const float *raw, const double *z_vals,
                               const double *depth, const float *rgb, const float *gt_depth, const float *gt_color,
                               float w_color, const double *g_loss, float *d_raw, void *stream);
@@ -293,6 +295,12 @@ int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const f
                        const double *z_vals, const enslam_scene *scene, const float *d_raw, const float *act_ws,
                        int32_t act_light, float *dgrid_ws, const enslam_grid *grad_grids, float *const *grad_packed,
                        float *g_rays_o, float *g_rays_d, void *stream);
+/* enslam_decoder_bwd with every d_raw value multiplied by the device scalar *d_raw_scale (NULL: 1). */
+int enslam_decoder_bwd_scaled(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                              const double *z_vals, const enslam_scene *scene, const float *d_raw,
+                              const double *d_raw_scale, const float *act_ws, int32_t act_light, float *dgrid_ws,
+                              const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o,
+                              float *g_rays_d, void *stream);
 int enslam_ray_grad_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                         const double *z_vals, const enslam_scene *scene, float *dgrid_ws, float *g_rays_o,
                         float *g_rays_d, void *stream);
