@@ -78,7 +78,7 @@ _SIGS = {
     "enslam_step_finish_rays": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),
                                                c_int32, POINTER(c_int32), POINTER(c_void_p), POINTER(MlpParams), c_int32, c_int32,
                                                c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene), c_void_p, c_void_p, c_void_p,
-                                               c_void_p]),
+                                               c_void_p, c_void_p, c_void_p]),
     "enslam_ray_grad_bwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene), c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
     "enslam_zero_blocks": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), c_void_p,
@@ -99,9 +99,11 @@ _SIGS = {
                                          c_void_p]),
     "enslam_render_loss_fwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene), c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, ctypes.c_float,
-                                              c_void_p, c_void_p, c_void_p]),
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "enslam_composite_loss_bwd": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                 ctypes.c_float, c_void_p, c_void_p, c_void_p]),
+                                                 ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "enslam_composite_bwd_list": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "enslam_composite_fwd": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p]),
     "enslam_composite_bwd": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -111,7 +113,7 @@ _SIGS = {
                                           c_void_p, c_void_p]),
     "enslam_decoder_bwd_scaled": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
                                                  c_void_p, c_void_p, c_void_p, c_int32, c_void_p, POINTER(Grid), POINTER(c_void_p),
-                                                 c_void_p, c_void_p, c_void_p]),
+                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "enslam_rgbd_loss_fwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,
                                             c_void_p]),
     "enslam_rgbd_loss_bwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,

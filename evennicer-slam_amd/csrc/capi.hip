@@ -234,6 +234,11 @@ int enslam_step_prepare(int32_t n_dec, const int32_t* kinds, const enslam_mlp_pa
     return ens_launch_step(pj, false, cj, true, zj, flat, n_flat, nullptr, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
 
+// optional work list arguments: both given or both NULL
+static bool work_list_of(int32_t* tiles, int32_t* count, WorkList& w) {
+    w.tiles = tiles; w.count = count;
+    return (tiles == nullptr) == (count == nullptr);
+}
 static int step_finish_impl(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
                             const uint8_t* const* need, int32_t n_dec, const int32_t* kinds, const float* const* packed_grads,
                             const enslam_mlp_params* grads, const RayGradArgs* rg, void* stream) {
@@ -268,7 +273,8 @@ int enslam_step_finish_rays(int32_t n_conv, const float* const* src, float* cons
                             const uint8_t* const* need, int32_t n_dec, const int32_t* kinds, const float* const* packed_grads,
                             const enslam_mlp_params* grads, int32_t stage, int32_t n_rays, int32_t n_samples,
                             const float* rays_o, const float* rays_d, const double* z_vals, const enslam_scene* scene,
-                            float* dgrid_ws, float* g_rays_o, float* g_rays_d, void* stream) {
+                            float* dgrid_ws, float* g_rays_o, float* g_rays_d, const int32_t* work_list,
+                            const int32_t* work_count, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0 || stage == ENSLAM_STAGE_COARSE)
         return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, nullptr, stream);
@@ -277,7 +283,10 @@ int enslam_step_finish_rays(int32_t n_conv, const float* const* src, float* cons
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
     if (!rays_o || !rays_d || !z_vals || !dgrid_ws || !g_rays_o || !g_rays_d) return ENSLAM_EINVAL;
     RayGradArgs rg;
-    if (!ens_ray_grad_args(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, dgrid_ws, g_rays_o, g_rays_d, rg))
+    WorkList wl;
+    if (!work_list_of(const_cast<int32_t*>(work_list), const_cast<int32_t*>(work_count), wl)) return ENSLAM_EINVAL;
+    if (!ens_ray_grad_args(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, dgrid_ws, g_rays_o, g_rays_d, rg,
+                           work_list ? &wl : nullptr))
         return ENSLAM_EINVAL;
     return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, &rg, stream);
 }
@@ -501,7 +510,8 @@ int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
 int enslam_render_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                            const double* z_vals, const enslam_scene* scene, double* depth, double* var, float* rgb,
                            float* raw_out, float* act_ws, int32_t act_light, const float* gt_depth, const float* gt_color,
-                           float w_color, double* loss, float* d_raw_unit, void* stream) {
+                           float w_color, double* loss, float* d_raw_unit, int32_t* work_list, int32_t* work_count,
+                           void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
@@ -512,20 +522,25 @@ int enslam_render_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, con
         for (int k = 1; k < 4; ++k)
             if (d.grid[k].data && (int64_t)d.grid[k].D * d.grid[k].H * d.grid[k].W >= ACT_MAX_VOXELS) return ENSLAM_EUNSUPPORTED;
     const LossSpec ls{gt_depth, gt_color, w_color, loss, nullptr, d_raw_unit};
+    WorkList wl;
+    if (!work_list_of(work_list, work_count, wl) || (work_list && !d_raw_unit)) return ENSLAM_EINVAL;
     const int rc = ens_launch_render_fwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, nullptr, 0, 1, d, depth, var, rgb,
                                          raw_out, stage == ENSLAM_STAGE_COARSE ? nullptr : act_ws, act_light != 0,
-                                         (hipStream_t)stream, &ls);
+                                         (hipStream_t)stream, &ls, work_list ? &wl : nullptr);
     return rc == 0 ? ENSLAM_OK : (rc == -1 ? ENSLAM_EUNSUPPORTED : ENSLAM_ELAUNCH);
 }
 int enslam_composite_loss_bwd(int32_t n_rays, int32_t n_samples, const float* raw, const double* z_vals,
                               const double* depth, const float* rgb, const float* gt_depth, const float* gt_color,
-                              float w_color, const double* g_loss, float* d_raw, void* stream) {
+                              float w_color, const double* g_loss, float* d_raw, int32_t* work_list, int32_t* work_count,
+                              void* stream) {
     if (n_rays < 0 || n_samples < 1 || n_samples > 64) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (!raw || !z_vals || !depth || !gt_depth || !g_loss || !d_raw || (gt_color && !rgb)) return ENSLAM_EINVAL;
     const LossSpec ls{gt_depth, gt_color, w_color, nullptr, g_loss, nullptr};
+    WorkList wl;
+    if (!work_list_of(work_list, work_count, wl)) return ENSLAM_EINVAL;
     return ens_launch_composite_bwd(n_rays, n_samples, raw, z_vals, depth, nullptr, nullptr, nullptr, d_raw,
-                                    (hipStream_t)stream, &ls, rgb) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+                                    (hipStream_t)stream, &ls, rgb, work_list ? &wl : nullptr) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
 
 size_t enslam_grid_handoff_floats(int32_t stage, int32_t n_rays, int32_t n_samples) {
@@ -567,17 +582,29 @@ int enslam_composite_bwd(int32_t n_rays, int32_t n_samples, const float* raw, co
                                     (hipStream_t)stream);
 }
 
+int enslam_composite_bwd_list(int32_t n_rays, int32_t n_samples, const float* raw, const double* z_vals,
+                              const double* depth, const double* g_depth, const double* g_var, const float* g_rgb,
+                              float* d_raw, int32_t* work_list, int32_t* work_count, void* stream) {
+    if (n_rays < 0 || n_samples < 1 || n_samples > 64) return ENSLAM_EINVAL;
+    if (n_rays == 0) return ENSLAM_OK;
+    WorkList wl;
+    if (!raw || !z_vals || !depth || !d_raw || !work_list_of(work_list, work_count, wl)) return ENSLAM_EINVAL;
+    return ens_launch_composite_bwd(n_rays, n_samples, raw, z_vals, depth, g_depth, g_var, g_rgb, d_raw, (hipStream_t)stream,
+                                    nullptr, nullptr, work_list ? &wl : nullptr);
+}
+
 int enslam_decoder_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                        const double* z_vals, const enslam_scene* scene, const float* d_raw, const float* act_ws,
                        int32_t act_light, float* dgrid_ws, const enslam_grid* grad_grids, float* const* grad_packed,
                        float* g_rays_o, float* g_rays_d, void* stream) {
     return enslam_decoder_bwd_scaled(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, d_raw, nullptr, act_ws, act_light,
-                                     dgrid_ws, grad_grids, grad_packed, g_rays_o, g_rays_d, stream);
+                                     dgrid_ws, grad_grids, grad_packed, g_rays_o, g_rays_d, nullptr, nullptr, stream);
 }
 int enslam_decoder_bwd_scaled(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                               const double* z_vals, const enslam_scene* scene, const float* d_raw, const double* d_raw_scale,
                               const float* act_ws, int32_t act_light, float* dgrid_ws, const enslam_grid* grad_grids,
-                              float* const* grad_packed, float* g_rays_o, float* g_rays_d, void* stream) {
+                              float* const* grad_packed, float* g_rays_o, float* g_rays_d, const int32_t* work_list,
+                              const int32_t* work_count, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
@@ -595,8 +622,10 @@ int enslam_decoder_bwd_scaled(int32_t stage, int32_t n_rays, int32_t n_samples, 
             (grad_grids[k].D != d.grid[k].D || grad_grids[k].H != d.grid[k].H || grad_grids[k].W != d.grid[k].W))
             return ENSLAM_EINVAL;
     }
+    WorkList wl;
+    if (!work_list_of(const_cast<int32_t*>(work_list), const_cast<int32_t*>(work_count), wl)) return ENSLAM_EINVAL;
     return ens_launch_decoder_bwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, d_raw, act_ws, act_light != 0, dgrid_ws, gg,
-                                  grad_packed, g_rays_o, g_rays_d, (hipStream_t)stream, d_raw_scale);
+                                  grad_packed, g_rays_o, g_rays_d, (hipStream_t)stream, d_raw_scale, work_list ? &wl : nullptr);
 }
 
 int enslam_ray_grad_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,

@@ -198,6 +198,24 @@ ENS_DEV void gather8(const Vox& v, const DevGrid& g, int q, f32x4& c0, f32x4& c1
     }
 }
 
+// Work-list append (see WorkList, kernels.hpp): one wave holds the d_raw of one ray, lane = sample.  Tiles whose 16 lanes carry
+// any non-zero component are appended in order; one atomic per ray.
+ENS_DEV void append_active_tiles(int* tiles, int* count, int64_t ray, int ntl, bool lane_nonzero, int lane) {
+    const unsigned long long b = __ballot(lane_nonzero);
+    int k = 0;
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) k += (tl < ntl && ((b >> (16 * tl)) & 0xFFFFull)) ? 1 : 0;
+    int base = 0;
+    if (lane == 0 && k > 0) base = atomicAdd(count, k);
+    base = __shfl(base, 0);
+    if (lane == 0) {
+        int j = 0;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+            if (tl < ntl && ((b >> (16 * tl)) & 0xFFFFull)) tiles[base + j++] = (int)(ray * ntl + tl);
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // MFMA building blocks
 // ----------------------------------------------------------------------------------------------

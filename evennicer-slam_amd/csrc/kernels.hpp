@@ -15,6 +15,13 @@ struct LossSpec {
     float* d_raw_unit;           // forward (optional): d(loss)/d(raw) for g_loss = 1, [N*S,4] -- lets the backward start at the
                                  // decoders (ens_launch_decoder_bwd's draw_scale = g_loss) without a compositing launch
 };
+// Work list of the saved-activation backward: the 16-sample tiles (ray * ntl + tl) whose d_raw is not all zero, appended
+// ray by ray (a ray's tiles stay adjacent) by the kernel that produces d_raw; count[0] must be zero before that kernel.
+// Behind a converged surface the transmittance underflows to 0 and the far tiles of most rays drop out.
+struct WorkList {
+    int* tiles;                  // [n_rays * ntl]
+    int* count;                  // [1]
+};
 
 // one segment of a decoder re-layout: dst[r*dst_ld + c] = T ? src[c*src_ld + r] : src[r*src_ld + c]
 struct PackSeg {
@@ -97,7 +104,7 @@ int ens_launch_pose_rays(int n, const float* ct, const float* pi, const float* p
 int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_vm, const ConvJob& zj, float* flat,
                     int64_t n_flat, const RayGradArgs* rg, hipStream_t st);
 bool ens_ray_grad_args(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z, const DevScene& sc,
-                       float* dgrid_ws, float* g_ro, float* g_rd, RayGradArgs& A);
+                       float* dgrid_ws, float* g_ro, float* g_rd, RayGradArgs& A, const WorkList* wl = nullptr);
 int ens_launch_adam(const AdamJob& job, hipStream_t st);
 int ens_launch_adam_tensors(const AdamTensorsJob& job, hipStream_t st);
 int ens_launch_zero_blocks(const ConvJob& job, float* flat, int64_t n_flat, hipStream_t st);
@@ -120,13 +127,15 @@ int ens_launch_voxel_index(int64_t n, const double* pts, const double* bound, in
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
                           double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st,
-                          const LossSpec* ls = nullptr);
+                          const LossSpec* ls = nullptr, const WorkList* wl = nullptr);
 int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* z, double* depth, double* var,
-                             float* rgb, float* weights, hipStream_t st, const LossSpec* ls = nullptr);
+                             float* rgb, float* weights, hipStream_t st, const LossSpec* ls = nullptr,
+                             const WorkList* wl = nullptr);
 int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* z, const double* depth,
                              const double* g_depth, const double* g_var, const float* g_rgb, float* d_raw,
-                             hipStream_t st, const LossSpec* ls = nullptr, const float* rgb = nullptr);
+                             hipStream_t st, const LossSpec* ls = nullptr, const float* rgb = nullptr,
+                             const WorkList* wl = nullptr);
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
                            const DevScene& sc, const float* d_raw, const float* act_ws, int act_light, float* dgrid_ws,
                            const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,
-                           hipStream_t st, const double* draw_scale = nullptr);
+                           hipStream_t st, const double* draw_scale = nullptr, const WorkList* wl = nullptr);

@@ -15,6 +15,8 @@ struct RayGradArgs {
     DevGrid grid[4];             // voxel-major values
     float* g_ro;
     float* g_rd;
+    const int* work;             // optional work list of active tiles (null: every tile)
+    const int* n_work;
 };
 
 struct TileGeo {
@@ -77,8 +79,12 @@ ENS_DEV void add_ray_grad(float dpx, float dpy, float dpz, float zf, int ray, fl
 // one wave: unit = tile * n_slots + slot
 ENS_DEV void ray_grad_unit(const RayGradArgs& A, int64_t unit, int lane) {
     const int p = lane & 15, q = lane >> 4;
-    const int64_t tile = unit / A.n_slots;
+    int64_t tile = unit / A.n_slots;
     const int slot_idx = (int)(unit - tile * A.n_slots);
+    if (A.work != nullptr) {                     // unit counts over the list of active tiles
+        if (tile >= (int64_t)A.n_work[0]) return;
+        tile = A.work[tile];
+    }
     const DevGrid grid = A.grid[slot_idx + 1];
     const float* dgw = A.dgrid_ws + (tile * ACT_SLOTS + slot_idx) * DG_STRIDE;
     const f32x4 dc0 = ld4(dgw + lane * 4), dc1 = ld4(dgw + 256 + lane * 4);

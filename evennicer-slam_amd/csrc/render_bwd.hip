@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(int S, const float* _
                                                            const double* __restrict__ g_var,
                                                            const float* __restrict__ g_rgb,
                                                            float* __restrict__ d_raw, LossSpec ls,
-                                                           const float* __restrict__ rgb) {
+                                                           const float* __restrict__ rgb, WorkList wk) {
     const int lane = threadIdx.x;
     const int64_t ray = blockIdx.x, sidx = ray * S + lane;
     const bool valid = lane < S;
@@ -94,7 +94,10 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(int S, const float* _
     suf -= gww;
     const float ga = gw * T - suf / m;
     const float gocc = ga * (1.f - alpha) * alpha * 10.f;
-    if (valid) *reinterpret_cast<f32x4*>(d_raw + sidx * 4) = f32x4{gc[0] * w, gc[1] * w, gc[2] * w, gocc};
+    const f32x4 dr = f32x4{gc[0] * w, gc[1] * w, gc[2] * w, gocc};
+    if (valid) *reinterpret_cast<f32x4*>(d_raw + sidx * 4) = dr;
+    if (wk.tiles != nullptr)
+        append_active_tiles(wk.tiles, wk.count, ray, S / 16, valid && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f), lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -331,6 +334,8 @@ struct BwdArgs {
     const double* z;
     const float* d_raw;
     const double* draw_scale;   // null, or a device scalar every d_raw value is multiplied by (unit gradients of a fused loss)
+    const int* work;            // saved-activation path: work list of the tiles with non-zero d_raw (null: every tile) ...
+    const int* n_work;          // ... and its length
     const float* act_ws;     // forward activations (render_fwd_kernel) or null: recompute
     int act_light;           // act_ws holds the light layout (coordinates | masks | cell records): light kernel only
     float* dgrid_ws;         // decoder -> grid_bwd_kernel hand-off (saved path): [tile][slot][DG_STRIDE]
@@ -344,6 +349,9 @@ struct BwdArgs {
     int n_roles;
 };
 ENS_DEV float draw_scale_of(const BwdArgs& A) { return A.draw_scale != nullptr ? (float)A.draw_scale[0] : 1.f; }
+// number of work items of the saved-activation roles and the tile behind item v (v < count)
+ENS_DEV int64_t work_count(const BwdArgs& A) { return A.work != nullptr ? (int64_t)A.n_work[0] : (int64_t)A.n_rays * A.ntl; }
+ENS_DEV int64_t work_tile(const BwdArgs& A, int64_t v) { return A.work != nullptr ? (int64_t)A.work[v] : v; }
 
 // ------------------------------------------------------------------------------------------------
 // MLP (middle / fine / color) backward for one workgroup role
@@ -855,7 +863,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         for (int f = 0; f < 8; ++f) aWo[j][f] = 0.f;
     }
 
-    const int64_t n_tiles = (int64_t)A.n_rays * A.ntl;
+    const int64_t n_tiles = work_count(A);                          // (work items; all tiles without a work list)
     const int64_t stride = (int64_t)n_wg * 4;
     STAMP_DECL
     STAMP_START
@@ -881,7 +889,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
               WSQ = wl ? ACTL_Q : SL::Q * 256;
     auto tile_of = [&](int64_t b) {
         const int64_t tr = b + wave;
-        return __builtin_amdgcn_readfirstlane((int)(tr < n_tiles ? tr : n_tiles - 1));
+        return __builtin_amdgcn_readfirstlane((int)work_tile(A, tr < n_tiles ? tr : n_tiles - 1));
     };
     const float dscale = draw_scale_of(A);
     f32x4 draw_n = splat4(0.f);
@@ -1161,7 +1169,7 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
     unsigned fb[4];
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
-    const int64_t n_tiles = (int64_t)A.n_rays * A.ntl;
+    const int64_t n_tiles = work_count(A);
     const int64_t stride = (int64_t)n_wg * 4;
     unsigned round_no = 0, rp = 0;
     // These waves also do the chain waves' bulk data movement: the W^T ring (one layer ahead) and the slot fills from the
@@ -1211,7 +1219,7 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         if (!any4) continue;
         {   // slot `ow` <- the operands the forward parked for chain wave ow's tile of this round
             const int64_t tr = base + ow;
-            const int64_t tile = tr < n_tiles ? tr : n_tiles - 1;
+            const int64_t tile = work_tile(A, tr < n_tiles ? tr : n_tiles - 1);
             const float* __restrict__ wsb = A.act_ws + (tile * ACT_SLOTS + (kind - 1)) * ACT_STRIDE;
             float* myslot = slots + ow * SLOT;
 #pragma unroll
@@ -1493,24 +1501,28 @@ extern "C" int enslam_debug_set_stamp_buffer(void* p) {
 
 int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* z, const double* depth,
                              const double* g_depth, const double* g_var, const float* g_rgb, float* d_raw,
-                             hipStream_t st, const LossSpec* ls, const float* rgb) {
+                             hipStream_t st, const LossSpec* ls, const float* rgb, const WorkList* wl) {
     if (n_rays <= 0) return 0;
     LossSpec l{nullptr, nullptr, 0.f, nullptr, nullptr, nullptr};
     if (ls != nullptr) l = *ls;
-    composite_bwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(S, raw, z, depth, g_depth, g_var, g_rgb, d_raw, l, rgb);
+    WorkList wk{nullptr, nullptr};
+    if (wl != nullptr) wk = *wl;
+    composite_bwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(S, raw, z, depth, g_depth, g_var, g_rgb, d_raw, l, rgb, wk);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
                            const DevScene& sc, const float* d_raw, const float* act_ws, int act_light, float* dgrid_ws,
                            const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,
-                           hipStream_t st, const double* draw_scale) {
+                           hipStream_t st, const double* draw_scale, const WorkList* wl) {
     if (n_rays <= 0) return 0;
     BwdArgs A;
     A.act_light = act_light;
     A.act_ws = stage == 0 ? nullptr : act_ws;
     A.dgrid_ws = dgrid_ws;
     A.n_rays = n_rays; A.ntl = ntl; A.ro = ro; A.rd = rd; A.z = z; A.d_raw = d_raw; A.draw_scale = draw_scale; A.sc = sc;
+    const bool listed = wl != nullptr && wl->tiles != nullptr && act_ws != nullptr && stage != 0;   // (the recompute and coarse roles walk every tile)
+    A.work = listed ? wl->tiles : nullptr; A.n_work = listed ? wl->count : nullptr;
     A.g_ro = (g_ro && g_rd) ? g_ro : nullptr;
     A.g_rd = (g_ro && g_rd) ? g_rd : nullptr;
     // roles and their relative cost (MFMA count per tile: middle/color 270, fine 350)
@@ -1639,12 +1651,13 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
 
 // Second kernel of the saved-activation backward: ray gradients from the decoder kernel's hand-off buffer.
 bool ens_ray_grad_args(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z, const DevScene& sc,
-                       float* dgrid_ws, float* g_ro, float* g_rd, RayGradArgs& A) {
+                       float* dgrid_ws, float* g_ro, float* g_rd, RayGradArgs& A, const WorkList* wl) {
     if (n_rays <= 0 || stage == 0 || !dgrid_ws || !g_ro || !g_rd) return false;
     A.n_rays = n_rays; A.ntl = ntl; A.n_slots = stage;       // middle | middle+fine | middle+fine+color
     A.ro = ro; A.rd = rd; A.z = z; A.dgrid_ws = dgrid_ws; A.g_ro = g_ro; A.g_rd = g_rd;
     for (int a = 0; a < 3; ++a) { A.lo[a] = sc.lo[a]; A.hi[a] = sc.hi[a]; }
     for (int k = 0; k < 4; ++k) A.grid[k] = sc.grid[k];
+    A.work = (wl != nullptr) ? wl->tiles : nullptr; A.n_work = (wl != nullptr) ? wl->count : nullptr;
     return true;
 }
 int ens_launch_ray_grad_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(1024) void composite_fwd_kernel(int n_rays, int S, 
                                                            const double* __restrict__ z_vals,
                                                            double* __restrict__ depth, double* __restrict__ var,
                                                            float* __restrict__ rgb, float* __restrict__ weights,
-                                                           LossSpec ls) {
+                                                           LossSpec ls, WorkList wk) {
     __shared__ double red[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t ray_raw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -606,7 +606,10 @@ __global__ __launch_bounds__(1024) void composite_fwd_kernel(int n_rays, int S, 
         suf -= gww;
         const float ga = gw * T - suf / m;
         const float gocc = ga * (1.f - alpha) * alpha * 10.f;
-        if (valid && rvalid) *reinterpret_cast<f32x4*>(ls.d_raw_unit + sidx * 4) = f32x4{gcl[0] * w, gcl[1] * w, gcl[2] * w, gocc};
+        const f32x4 dr = f32x4{gcl[0] * w, gcl[1] * w, gcl[2] * w, gocc};
+        if (valid && rvalid) *reinterpret_cast<f32x4*>(ls.d_raw_unit + sidx * 4) = dr;
+        if (wk.tiles != nullptr && rvalid)
+            append_active_tiles(wk.tiles, wk.count, ray, S / 16, valid && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f), lane);
     }
     if (ls.gd != nullptr) {                          // (uniform over the launch)
         if (lane == 0) red[wave] = term;
@@ -637,19 +640,21 @@ int launch_stage(int ntl, int64_t n_units, const float* ro, const float* rd, con
 }  // namespace
 
 int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* z, double* depth, double* var,
-                             float* rgb, float* weights, hipStream_t st, const LossSpec* ls) {
+                             float* rgb, float* weights, hipStream_t st, const LossSpec* ls, const WorkList* wl) {
     if (n_rays <= 0) return 0;
     LossSpec l{nullptr, nullptr, 0.f, nullptr, nullptr, nullptr};
     if (ls != nullptr) l = *ls;
-    if (l.gd != nullptr) composite_fwd_kernel<<<dim3((n_rays + 15) / 16), dim3(1024), 0, st>>>(n_rays, S, raw, z, depth, var, rgb, weights, l);
-    else composite_fwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(n_rays, S, raw, z, depth, var, rgb, weights, l);
+    WorkList wk{nullptr, nullptr};
+    if (wl != nullptr && l.d_raw_unit != nullptr) wk = *wl;
+    if (l.gd != nullptr) composite_fwd_kernel<<<dim3((n_rays + 15) / 16), dim3(1024), 0, st>>>(n_rays, S, raw, z, depth, var, rgb, weights, l, wk);
+    else composite_fwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(n_rays, S, raw, z, depth, var, rgb, weights, l, wk);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
                           double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st,
-                          const LossSpec* ls) {
+                          const LossSpec* ls, const WorkList* wl) {
     // Ray mode with raw requested and a moderate ray count: tile-per-wave decoders + separate compositing (more
     // waves in flight).  Large batches (full-image renders) already fill the chip with one wave per ray.
     int tpr = 0;
@@ -678,7 +683,7 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
         else if (stage == 2) render_fwd_ring_kernel<2><<<grid, block, fwd_ring_lds_bytes(2), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
         else render_fwd_ring_kernel<3><<<grid, block, fwd_ring_lds_bytes(3), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
         if (hipGetLastError() != hipSuccess) return -2;
-        return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st, ls);
+        return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st, ls, wl);
     }
     switch (stage) {
         case 0: rc = launch_stage<0>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, act_light, sc, depth, var, rgb, raw, st); break;
@@ -688,5 +693,5 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
         default: return -1;
     }
     if (rc != 0 || tpr == 0) return rc;
-    return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st, ls);
+    return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st, ls, wl);
 }

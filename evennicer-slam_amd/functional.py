@@ -558,6 +558,12 @@ class _RenderFn(torch.autograd.Function):
             if 0 < n_act * 4 <= ACT_WORKSPACE_LIMIT_BYTES and max(d[0] * d[1] * d[2] for d in dims.values()) < (1 << 29):
                 act = torch.empty(n_act, dtype=torch.float32, device=dev)
         loss = None
+        # work list of the backward (tiles with non-zero d_raw): filled by whichever kernel produces d_raw; the counter
+        # comes zeroed out of this call's arena
+        work = wcount = None
+        if act is not None and USE_WORK_LIST and any(ctx.needs_input_grad):
+            work = torch.empty(N * (S // 16), dtype=torch.int32, device=dev)
+            wcount = arena.take(1, torch.int32)
         if plan.loss is None:
             L.check(lib.enslam_render_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                           _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, st),
@@ -569,12 +575,16 @@ class _RenderFn(torch.autograd.Function):
             d_raw_unit = torch.empty((N * S, 4), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
             L.check(lib.enslam_render_loss_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                                _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, _ptr(lgd),
-                                               _ptr(lgc), ctypes.c_float(lw), _ptr(loss), _ptr(d_raw_unit), st),
+                                               _ptr(lgc), ctypes.c_float(lw), _ptr(loss), _ptr(d_raw_unit),
+                                               _ptr(work) if d_raw_unit is not None else None,
+                                               _ptr(wcount) if d_raw_unit is not None else None, st),
                     "enslam_render_loss_fwd")
         ctx.plan, ctx.S, ctx.dims, ctx.act_light, ctx.accum = plan, S, dims, act_light, accum
         ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act, flags)
         ctx.rgb = rgb if plan.loss is not None else None
         ctx.d_raw_unit = d_raw_unit if plan.loss is not None else None
+        ctx.work, ctx.wcount = work, wcount
+        ctx.work_filled = plan.loss is not None and work is not None and d_raw_unit is not None      # (by the forward)
         ctx.grid_shapes = [tuple(g.shape) for g in grids]
         ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
         if loss is not None:
@@ -641,17 +651,23 @@ class _RenderFn(torch.autograd.Function):
             g_rd = zbuf[r0 + 3 * N:r0 + 6 * N].view(N, 3)
             p_ro, p_rd = _ptr(g_ro), _ptr(g_rd)
         d_scale = None
+        work, wcount = ctx.work, ctx.wcount
+        if work is not None and not (gL is not None and ctx.d_raw_unit is not None):
+            if ctx.work_filled:                             # a repeated backward appends again: start from an empty list
+                wcount.zero_()
+            ctx.work_filled = True
         if gL is not None and ctx.d_raw_unit is not None:
             d_raw, d_scale = ctx.d_raw_unit, gL             # unit gradients from the forward, scaled inside the decoder backward
         elif gL is not None:
             d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
             lgd, lgc, lw = plan.loss
             L.check(lib.enslam_composite_loss_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(ctx.rgb), _ptr(lgd), _ptr(lgc),
-                                                  ctypes.c_float(lw), _ptr(gL), _ptr(d_raw), st), "enslam_composite_loss_bwd")
+                                                  ctypes.c_float(lw), _ptr(gL), _ptr(d_raw), _ptr(work), _ptr(wcount), st),
+                    "enslam_composite_loss_bwd")
         else:
             d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
-            L.check(lib.enslam_composite_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
-                                             _ptr(d_raw), st), "enslam_composite_bwd")
+            L.check(lib.enslam_composite_bwd_list(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
+                                                  _ptr(d_raw), _ptr(work), _ptr(wcount), st), "enslam_composite_bwd")
         dgw = None
         if act is not None and need_rays:
             dgw = torch.empty(lib.enslam_grid_handoff_floats(L.STAGE[plan.stage], N, S), dtype=torch.float32, device=dev)
@@ -661,7 +677,7 @@ class _RenderFn(torch.autograd.Function):
             e0.record()
         L.check(lib.enslam_decoder_bwd_scaled(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                               _ptr(d_raw), _ptr(d_scale), _ptr(act), ctx.act_light, _ptr(dgw), gg, gpk, p_ro, p_rd,
-                                              st), "enslam_decoder_bwd")
+                                              _ptr(work), _ptr(wcount), st), "enslam_decoder_bwd")
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
@@ -698,8 +714,8 @@ class _RenderFn(torch.autograd.Function):
                 structs[j] = _fill_params_struct(k, views)
         if ray_pending:
             L.check(lib.enslam_step_finish_rays(nc, srcs, dsts, vs, need_ptrs, npk, kind_arr, pk_arr, structs, L.STAGE[plan.stage],
-                                                N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc), _ptr(dgw), p_ro, p_rd, st),
-                    "enslam_step_finish_rays")
+                                                N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc), _ptr(dgw), p_ro, p_rd,
+                                                _ptr(work), _ptr(wcount), st), "enslam_step_finish_rays")
         elif nc or npk:
             L.check(lib.enslam_step_finish(nc, srcs, dsts, vs, need_ptrs, npk, kind_arr, pk_arr, structs, st), "enslam_step_finish")
         for k in plan.kinds:
@@ -710,6 +726,8 @@ class _RenderFn(torch.autograd.Function):
 # The forward keeps the backward's operands (1.3 KB per sample and decoder: 172 MB at 1000 rays x 48, colour
 # stage) when their total stays under this limit; above it the backward recomputes them (slower, no extra memory).
 ACT_WORKSPACE_LIMIT_BYTES = 8 << 30
+
+USE_WORK_LIST = os.environ.get('ENSLAM_WORK_LIST', '1') == '1'     # backward walks only the tiles with non-zero d_raw
 
 PROFILE = {}        # {'decoder_bwd': [(event_begin, event_end), ...]} when bench.py asks for per-kernel timing
 

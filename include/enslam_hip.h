@@ -200,7 +200,7 @@ int enslam_step_finish_rays(int32_t n_conv, const float *const *src, float *cons
                             const float *const *packed_grads, const enslam_mlp_params *grads, int32_t stage,
                             int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                             const double *z_vals, const enslam_scene *scene, float *dgrid_ws, float *g_rays_o,
-                            float *g_rays_d, void *stream);
+                            float *g_rays_d, const int32_t *work_list, const int32_t *work_count, void *stream);
 
 /* Sample distances along rays (mark_scene / mark_flags non-NULL: also does enslam_mark_blocks' work for stage mark_stage
  * on the samples it has just placed -- one launch less per render call).
@@ -275,10 +275,12 @@ int enslam_render_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
 int enslam_render_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                            const double *z_vals, const enslam_scene *scene, double *depth, double *var, float *rgb,
                            float *raw_out, float *act_ws, int32_t act_light, const float *gt_depth,
-                           const float *gt_color, float w_color, double *loss, float *d_raw_unit, void *stream);
+                           const float *gt_color, float w_color, double *loss, float *d_raw_unit, int32_t *work_list,
+                           int32_t *work_count, void *stream);
 int enslam_composite_loss_bwd(int32_t n_rays, int32_t n_samples, const float *raw, const double *z_vals,
                               const double *depth, const float *rgb, const float *gt_depth, const float *gt_color,
-                              float w_color, const double *g_loss, float *d_raw, void *stream);
+                              float w_color, const double *g_loss, float *d_raw, int32_t *work_list, int32_t *work_count,
+                              void *stream);
 
 /* The two halves of enslam_render_bwd, callable on their own.
  * enslam_composite_bwd: backward of raw2outputs_nerf_color (common.py:284-296): d(depth,var,rgb) -> d_raw [N*S,4].
@@ -300,7 +302,16 @@ int enslam_decoder_bwd_scaled(int32_t stage, int32_t n_rays, int32_t n_samples, 
                               const double *z_vals, const enslam_scene *scene, const float *d_raw,
                               const double *d_raw_scale, const float *act_ws, int32_t act_light, float *dgrid_ws,
                               const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o,
-                              float *g_rays_d, void *stream);
+                              float *g_rays_d, const int32_t *work_list, const int32_t *work_count, void *stream);
+/* Work list (optional everywhere, NULL/NULL = every tile): the 16-sample tiles (ray * n_samples/16 + tile) whose d_raw is
+ * not all zero -- behind a converged surface the transmittance underflows to 0 and the far tiles of most rays carry no
+ * gradient.  The kernel that produces d_raw appends them ray by ray (work_list int32 [n_rays * n_samples/16], work_count
+ * int32 [1], ZERO on entry): enslam_render_loss_fwd (with d_raw_unit), enslam_composite_loss_bwd,
+ * enslam_composite_bwd_list.  enslam_decoder_bwd_scaled (saved-activation roles only) and enslam_step_finish_rays then
+ * walk the list instead of all tiles; both must be given the same list. */
+int enslam_composite_bwd_list(int32_t n_rays, int32_t n_samples, const float *raw, const double *z_vals,
+                              const double *depth, const double *g_depth, const double *g_var, const float *g_rgb,
+                              float *d_raw, int32_t *work_list, int32_t *work_count, void *stream);
 int enslam_ray_grad_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                         const double *z_vals, const enslam_scene *scene, float *dgrid_ws, float *g_rays_o,
                         float *g_rays_d, void *stream);

@@ -39,19 +39,20 @@ def test_bad_arguments_return_error_codes():
     assert lib.enslam_step_prepare(0, None, None, None, 0, None, None, None, None, None, 0, None, None, None, None, 0, st) == 0
     # entry points of the fused loss, the merged finish launch and the gradient bucket
     assert lib.enslam_render_loss_fwd(3, 4, 48, P(ro), P(ro), P(z), ctypes.byref(sc), P(out_d), P(out_d), P(out_c), P(out_c), None, 0,
-                                      P(ro), None, 0.2, P(out_d), None, st) == EINVAL                   # empty scene
+                                      P(ro), None, 0.2, P(out_d), None, None, None, st) == EINVAL       # empty scene
     assert lib.enslam_render_loss_fwd(3, 0, 48, None, None, None, ctypes.byref(sc), None, None, None, None, None, 0, None, None, 0.2,
-                                      None, None, st) == 0
+                                      None, None, None, None, st) == 0
     assert lib.enslam_decoder_bwd_scaled(3, 4, 48, P(ro), P(ro), P(z), ctypes.byref(sc), None, None, None, 0, None, None, None, None,
-                                         None, st) == EINVAL
-    assert lib.enslam_composite_loss_bwd(4, 48, None, P(z), P(out_d), P(out_c), P(ro), None, 0.2, P(out_d), P(ro), st) == EINVAL
-    assert lib.enslam_composite_loss_bwd(4, 48, P(ro), P(z), P(out_d), None, P(ro), P(out_c), 0.2, P(out_d), P(ro), st) == EINVAL  # colour without rgb
+                                         None, None, None, st) == EINVAL
+    assert lib.enslam_composite_bwd_list(4, 48, P(ro), P(z), P(out_d), None, None, None, P(ro), P(ro), None, st) == EINVAL   # list without count
+    assert lib.enslam_composite_loss_bwd(4, 48, None, P(z), P(out_d), P(out_c), P(ro), None, 0.2, P(out_d), P(ro), None, None, st) == EINVAL
+    assert lib.enslam_composite_loss_bwd(4, 48, P(ro), P(z), P(out_d), None, P(ro), P(out_c), 0.2, P(out_d), P(ro), None, None, st) == EINVAL  # colour without rgb
     assert lib.enslam_step_finish_rays(0, None, None, None, None, 0, None, None, None, 3, 4, 40, P(ro), P(ro), P(z), ctypes.byref(sc),
-                                       P(ro), P(ro), P(ro), st) == EUNSUPPORTED                       # sample count
+                                       P(ro), P(ro), P(ro), None, None, st) == EUNSUPPORTED           # sample count
     assert lib.enslam_step_finish_rays(0, None, None, None, None, 0, None, None, None, 3, 4, 48, P(ro), P(ro), P(z), ctypes.byref(sc),
-                                       None, P(ro), P(ro), st) == EINVAL                              # (scene / hand-off missing)
+                                       None, P(ro), P(ro), None, None, st) == EINVAL                  # (scene / hand-off missing)
     assert lib.enslam_step_finish_rays(0, None, None, None, None, 0, None, None, None, 0, 4, 32, None, None, None, None, None, None,
-                                       None, st) == 0                                                 # coarse: plain finish, nothing to do
+                                       None, None, None, st) == 0                                     # coarse: plain finish, nothing to do
     assert lib.enslam_bucket_unpack(0, None, 32, None, None, None, None, 73, None, None, 0, P(ro), st) == EUNSUPPORTED
     torch.cuda.synchronize()
     assert lib.enslam_abi_version() >= 1
