@@ -198,21 +198,31 @@ ENS_DEV void gather8(const Vox& v, const DevGrid& g, int q, f32x4& c0, f32x4& c1
     }
 }
 
-// Work-list append (see WorkList, kernels.hpp): one wave holds the d_raw of one ray, lane = sample.  Tiles whose 16 lanes carry
-// any non-zero component are appended in order; one atomic per ray.
-ENS_DEV void append_active_tiles(int* tiles, int* count, int64_t ray, int ntl, bool lane_nonzero, int lane) {
+// Work-list append (see WorkList, kernels.hpp): one wave holds the d_raw of one ray, lane = sample; the waves of a workgroup
+// (blockDim.x / 64 rays) append together with ONE atomic -- one atomic per ray, all on one address, cost 11 us per 1000
+// rays.  Tiles whose 16 lanes carry any non-zero component are appended in ray order within the workgroup.  Every thread
+// of the workgroup must call this (two barriers); rays beyond the batch pass ray_valid = false.
+ENS_DEV void append_active_tiles_wg(int* tiles, int* count, int64_t ray, int ntl, bool ray_valid, bool lane_nonzero) {
+    __shared__ int wk[16];
+    __shared__ int wbase;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const unsigned long long b = __ballot(lane_nonzero);
     int k = 0;
 #pragma unroll
-    for (int tl = 0; tl < 4; ++tl) k += (tl < ntl && ((b >> (16 * tl)) & 0xFFFFull)) ? 1 : 0;
-    int base = 0;
-    if (lane == 0 && k > 0) base = atomicAdd(count, k);
-    base = __shfl(base, 0);
-    if (lane == 0) {
-        int j = 0;
+    for (int tl = 0; tl < 4; ++tl) k += (ray_valid && tl < ntl && ((b >> (16 * tl)) & 0xFFFFull)) ? 1 : 0;
+    if (lane == 0) wk[wave] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < nw; ++w) { const int c = wk[w]; wk[w] = tot; tot += c; }       // exclusive offsets
+        wbase = tot > 0 ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    if (lane == 0 && k > 0) {
+        int j = wbase + wk[wave];
 #pragma unroll
         for (int tl = 0; tl < 4; ++tl)
-            if (tl < ntl && ((b >> (16 * tl)) & 0xFFFFull)) tiles[base + j++] = (int)(ray * ntl + tl);
+            if (tl < ntl && ((b >> (16 * tl)) & 0xFFFFull)) tiles[j++] = (int)(ray * ntl + tl);
     }
 }
 

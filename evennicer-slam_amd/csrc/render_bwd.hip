@@ -34,7 +34,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // ------------------------------------------------------------------------------------------------
 // composite backward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void composite_bwd_kernel(int S, const float* __restrict__ raw,
+__global__ __launch_bounds__(1024) void composite_bwd_kernel(int n_rays, int S, const float* __restrict__ raw,
                                                            const double* __restrict__ z_vals,
                                                            const double* __restrict__ depth,
                                                            const double* __restrict__ g_depth,
@@ -42,8 +42,10 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(int S, const float* _
                                                            const float* __restrict__ g_rgb,
                                                            float* __restrict__ d_raw, LossSpec ls,
                                                            const float* __restrict__ rgb, WorkList wk) {
-    const int lane = threadIdx.x;
-    const int64_t ray = blockIdx.x, sidx = ray * S + lane;
+    const int lane = threadIdx.x & 63;               // one wave per ray, blockDim.x / 64 rays per workgroup
+    const int64_t ray_raw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const bool rvalid = ray_raw < n_rays;
+    const int64_t ray = rvalid ? ray_raw : n_rays - 1, sidx = ray * S + lane;
     const bool valid = lane < S;
     f32x4 rw = valid ? *reinterpret_cast<const f32x4*>(raw + sidx * 4) : splat4(0.f);
     const double zk = valid ? z_vals[sidx] : 0.0;
@@ -95,9 +97,10 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(int S, const float* _
     const float ga = gw * T - suf / m;
     const float gocc = ga * (1.f - alpha) * alpha * 10.f;
     const f32x4 dr = f32x4{gc[0] * w, gc[1] * w, gc[2] * w, gocc};
-    if (valid) *reinterpret_cast<f32x4*>(d_raw + sidx * 4) = dr;
-    if (wk.tiles != nullptr)
-        append_active_tiles(wk.tiles, wk.count, ray, S / 16, valid && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f), lane);
+    if (valid && rvalid) *reinterpret_cast<f32x4*>(d_raw + sidx * 4) = dr;
+    if (wk.tiles != nullptr)                         // (uniform over the launch)
+        append_active_tiles_wg(wk.tiles, wk.count, ray, S / 16, rvalid,
+                               valid && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1507,7 +1510,8 @@ int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* 
     if (ls != nullptr) l = *ls;
     WorkList wk{nullptr, nullptr};
     if (wl != nullptr) wk = *wl;
-    composite_bwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(S, raw, z, depth, g_depth, g_var, g_rgb, d_raw, l, rgb, wk);
+    if (wk.tiles != nullptr) composite_bwd_kernel<<<dim3((n_rays + 15) / 16), dim3(1024), 0, st>>>(n_rays, S, raw, z, depth, g_depth, g_var, g_rgb, d_raw, l, rgb, wk);
+    else composite_bwd_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(n_rays, S, raw, z, depth, g_depth, g_var, g_rgb, d_raw, l, rgb, wk);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

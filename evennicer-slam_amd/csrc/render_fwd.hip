@@ -608,8 +608,9 @@ __global__ __launch_bounds__(1024) void composite_fwd_kernel(int n_rays, int S, 
         const float gocc = ga * (1.f - alpha) * alpha * 10.f;
         const f32x4 dr = f32x4{gcl[0] * w, gcl[1] * w, gcl[2] * w, gocc};
         if (valid && rvalid) *reinterpret_cast<f32x4*>(ls.d_raw_unit + sidx * 4) = dr;
-        if (wk.tiles != nullptr && rvalid)
-            append_active_tiles(wk.tiles, wk.count, ray, S / 16, valid && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f), lane);
+        if (wk.tiles != nullptr)                     // (uniform over the launch)
+            append_active_tiles_wg(wk.tiles, wk.count, ray, S / 16, rvalid,
+                                   valid && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f));
     }
     if (ls.gd != nullptr) {                          // (uniform over the launch)
         if (lane == 0) red[wave] = term;

@@ -7,7 +7,11 @@ everything else) makes an iteration a single hipGraphLaunch.
 
 Requirements on `step_fn`: it reads and writes only tensors that stay allocated (static inputs: update them
 in place with .copy_ between replays), performs no host synchronisation (.item(), boolean-mask indexing), and
-leaves gradients in `.grad` of the leaves.  The ray count is fixed at capture time."""
+leaves gradients in `.grad` of the leaves.  The ray count is fixed at capture time.  No tensor of an EARLIER
+eager step that still carries an autograd graph (a kept loss, a kept render output) may be alive at capture time:
+its backward nodes were created on another stream and the capture of the new step's backward can crash the process."""
+import gc
+
 import torch
 
 
@@ -22,6 +26,7 @@ class GraphedStep:
                 del out
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        gc.collect()                            # reference cycles holding tensors of the warm-up steps (see below)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = step_fn()

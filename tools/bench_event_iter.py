@@ -64,7 +64,7 @@ def unet_only():
 n = int(os.environ.get('STEPS', 30))
 for f in (full, rgbd_only, path_only, unet_only):
     for _i in range(3): f()
-r = full()
+r = [x for x in full()[:3]]          # floats only: tensors of an eager iteration (autograd graph alive) must not survive into a capture
 t_full, t_rgbd, t_path, t_unet = timed(full, n), timed(rgbd_only, n), timed(path_only, n), timed(unet_only, n)
 rays = int(H * SF) * int(W * SF)
 print(f"config 3, room0, eager: full iteration (200-ray RGB-D + {rays}-ray event render + U-Net + losses + Adam) {t_full * 1e3:.2f} ms; "
@@ -73,8 +73,6 @@ print(f"config 3, room0, eager: full iteration (200-ray RGB-D + {rays}-ray event
 git = None
 if os.environ.get('GRAPH', '1') == '1':
     import gc
-    for f in (full,):
-        f()
     gc.collect()
     git = E.tracker.GraphedCameraIteration(trk, ct, opt, color_img, depth_img, gt_event, gt_mask, pre_color, batch_size=200,
                                            rgbd=True, event=True, scale_factor=SF)
