@@ -395,6 +395,9 @@ def main():
             "unit": "TFLOP/s", "frac": flops / avg / PEAK_F32_MFMA, "traffic": traffic,
             "avg_launch_us": avg * 1e6, "launches": int(len(dur)),
             "peak_measured": 138.9,     # TFLOP/s, v_mfma_f32_16x16x4_f32 micro-benchmark on the box (profiles/r01_peaks.txt)
+            # `achieved` prices the yardstick FLOPs of EVERY sample; tiles whose gradient is exactly zero (transmittance
+            # underflowed behind the room's boundary) are not scheduled at all -- this is the share that was
+            "active_tile_fraction": EF.last_active_tile_fraction(),
             "step_frac": step_flops / PEAK_F32_MFMA / (elapsed / args.steps),
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -584,6 +584,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.rgb = rgb if plan.loss is not None else None
         ctx.d_raw_unit = d_raw_unit if plan.loss is not None else None
         ctx.work, ctx.wcount = work, wcount
+        _last_work[0], _last_work[1] = wcount, N * (S // 16)
         ctx.work_filled = plan.loss is not None and work is not None and d_raw_unit is not None      # (by the forward)
         ctx.grid_shapes = [tuple(g.shape) for g in grids]
         ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
@@ -728,6 +729,18 @@ class _RenderFn(torch.autograd.Function):
 ACT_WORKSPACE_LIMIT_BYTES = 8 << 30
 
 USE_WORK_LIST = os.environ.get('ENSLAM_WORK_LIST', '1') == '1'     # backward walks only the tiles with non-zero d_raw
+_last_work = [None, 0]
+
+
+def last_active_tile_fraction():
+    """Share of the 16-sample tiles of the most recent render call that its backward scheduled (work list of tiles with
+    non-zero d_raw); None when that call kept no list or the list has not been filled yet.  Synchronises."""
+    wcount, n = _last_work
+    if wcount is None or n == 0:
+        return None
+    return float(wcount.item()) / n
+
+
 
 PROFILE = {}        # {'decoder_bwd': [(event_begin, event_end), ...]} when bench.py asks for per-kernel timing
 
