@@ -290,17 +290,22 @@ ENS_DEV void scatter_tile(const float* dep, const Vox& v, const DevGrid& gg, int
 ENS_DEV void scatter_tile_rec(const float* dep, const f32x4& rec, const DevGrid& gg, int lane) {
     const int ch = lane & 31, dxb = lane >> 5;
     const int rowy = gg.W * 32, rowz = gg.H * gg.W * 32;
+    const int stepy = gg.W, stepz = gg.H * gg.W;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     unsigned cur = 0u;
     bool open = false;
-    auto flush = [&]() {
+    // add the accumulators selected by kmask (bit k = row dy + 2 dz) of the lanes selected by half (0: all, 1: voxel x,
+    // 2: voxel x+1) of cell `cur` to the gradient and clear them
+    auto flush = [&](int kmask, int half) {
         const bool okx = !dxb || (cur >> 29 & 1u), oky = cur >> 30 & 1u, okz = cur >> 31;
+        const bool mine = half == 0 || (half == 1) == (dxb == 0);
         float* base = gg.data + (int64_t)(cur & 0x1fffffffu) * 32 + dxb * 32 + ch;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bool ok = okx && (!(k & 1) || oky) && (!(k >> 1) || okz);
+            if (!((kmask >> k) & 1)) continue;
+            const bool ok = mine && okx && (!(k & 1) || oky) && (!(k >> 1) || okz);
             if (ok && acc[k] != 0.f) atomicAdd(base + (k & 1) * rowy + (k >> 1) * rowz, acc[k]);
-            acc[k] = 0.f;
+            if (mine) acc[k] = 0.f;
         }
     };
     // (scalar copies first: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
@@ -315,9 +320,38 @@ ENS_DEV void scatter_tile_rec(const float* dep, const f32x4& rec, const DevGrid&
         const float fx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rx, pt));
         const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ry, pt));
         const float fz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rz, pt));
-        if (!open || lin != cur) {                        // scalar comparison: new cell
-            if (open) flush();
+        if (!open) {
             cur = lin; open = true;
+        } else if (lin != cur) {                          // scalar comparison: new cell
+            // A ray mostly steps into a face neighbour, which shares 4 of the 8 corner voxels: their partial sums stay in
+            // the registers (moved to the rows / voxel column they have in the new cell) and only the face left behind
+            // is added to the gradient -- about half of the atomics of a full flush per cell.  The neighbour flags of
+            // the records guard against index steps that wrap around a row or a slice.
+            const int d = (int)(lin & 0x1fffffffu) - (int)(cur & 0x1fffffffu);
+            if (d == 1 && (cur >> 29 & 1u)) {             // x + 1: old voxel column x+1 becomes column x
+                flush(15, 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float o = __shfl_xor(acc[k], 32); acc[k] = dxb ? 0.f : o; }
+            } else if (d == -1 && (lin >> 29 & 1u)) {     // x - 1: old column x becomes column x+1
+                flush(15, 2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float o = __shfl_xor(acc[k], 32); acc[k] = dxb ? o : 0.f; }
+            } else if (d == stepy && (cur >> 30 & 1u)) {  // y + 1
+                flush(5, 0);
+                acc[0] = acc[1]; acc[2] = acc[3]; acc[1] = 0.f; acc[3] = 0.f;
+            } else if (d == -stepy && (lin >> 30 & 1u)) { // y - 1
+                flush(10, 0);
+                acc[1] = acc[0]; acc[3] = acc[2]; acc[0] = 0.f; acc[2] = 0.f;
+            } else if (d == stepz && (cur >> 31)) {       // z + 1
+                flush(3, 0);
+                acc[0] = acc[2]; acc[1] = acc[3]; acc[2] = 0.f; acc[3] = 0.f;
+            } else if (d == -stepz && (lin >> 31)) {      // z - 1
+                flush(12, 0);
+                acc[2] = acc[0]; acc[3] = acc[1]; acc[0] = 0.f; acc[1] = 0.f;
+            } else {
+                flush(15, 0);
+            }
+            cur = lin;
         }
         const float wx = dxb ? fx : (1.f - fx);
 #pragma unroll
@@ -326,7 +360,7 @@ ENS_DEV void scatter_tile_rec(const float* dep, const f32x4& rec, const DevGrid&
             acc[k] = fmaf(w, val, acc[k]);
         }
     }
-    if (open) flush();
+    if (open) flush(15, 0);
 }
 
 
