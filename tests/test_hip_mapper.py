@@ -210,3 +210,20 @@ def test_fused_loss_falls_back_above_the_tile_mode_limit(monkeypatch):
     assert abs(loss.item() - loss2.item()) <= 1e-12 * abs(loss2.item()) and not depth.requires_grad
     a, b = g['grid_color'].grad, g2['grid_color'].grad
     assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+def test_fused_loss_backward_twice_accumulates():
+    """retain_graph: the unit gradients and the work list of the fused-loss forward serve every backward of the call."""
+    from tests.hip_util import DEV, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+    loss, *_ = renderer.render_batch_ray_rgbd_loss(g, model, rays['rays_d'], rays['rays_o'], DEV, 'color', rays['gt_depth'],
+                                                   rays['gt_color'], 0.2)
+    loss.backward(retain_graph=True)
+    once = g['grid_color'].grad.clone()
+    loss.backward()
+    twice = g['grid_color'].grad
+    assert float(once.abs().max()) > 0
+    assert float((twice - 2 * once).abs().max()) <= 1e-5 * float(once.abs().max())
+    for p in model.parameters():
+        p.grad = None
