@@ -171,3 +171,35 @@ def test_backward_recompute_fallback_matches(tiny, stage, monkeypatch):
     cg, ro, rd, model, loss = _run(tiny, stage, cot=cot)
     worst = _check(g, cg, ro, rd, model)
     assert len(worst) >= 4
+
+
+def test_large_batch_forward_kernel_feeds_the_same_backward():
+    """The one-wave-per-ray forward (ray counts above ENSLAM_TILE_MODE_MAX_RAYS: full-image renders) writes the same
+    activation workspace: run the colour-stage golden check in a child process with the limit lowered to 16 rays."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from tests.util import load, rel_err, GRID_KEYS\n"
+        "from tests.hip_util import tiny_on_gpu\n"
+        "s, bound, model, grids, rays, renderer = tiny_on_gpu()\n"
+        "g = load('tiny_color_mapperloss')\n"
+        "cg = {k: v.clone().requires_grad_(True) for k, v in grids.items()}\n"
+        "ro = rays['rays_o'].clone().requires_grad_(True); rd = rays['rays_d'].clone().requires_grad_(True)\n"
+        "d, v, c = renderer.render_batch_ray(cg, model, rd, ro, 'cuda:0', 'color', gt_depth=rays['gt_depth'])\n"
+        "m = rays['gt_depth'] > 0\n"
+        "loss = torch.abs(rays['gt_depth'][m] - d[m]).sum() + 0.2 * torch.abs(rays['gt_color'] - c).sum()\n"
+        "loss.backward()\n"
+        "assert rel_err(d.detach().cpu().numpy(), g['depth']) <= 1e-4\n"
+        "w = max(rel_err(cg[k].grad.cpu().numpy(), g['g_' + k]) for k in GRID_KEYS if 'g_' + k in g)\n"
+        "w = max(w, rel_err(rd.grad.cpu().numpy(), g['g_rays_d']))\n"
+        "w = max([w] + [rel_err(p.grad.cpu().numpy(), g['gp_' + n]) for n, p in model.named_parameters()\n"
+        "               if 'gp_' + n in g and np.abs(g['gp_' + n]).max() > 0])\n"
+        "print('WORST', w)\n"
+        "assert w <= 1e-3\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ENSLAM_TILE_MODE_MAX_RAYS='16')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'WORST' in r.stdout
