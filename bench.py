@@ -3,16 +3,26 @@
 
 One "step" = Renderer.render_batch_ray (sampling, gather, decoders, compositing) + the mapper's loss
 (Mapper.py:553-562) + backward producing gradients for the three feature grids, EVERY decoder parameter
-(the reference never freezes any, so its autograd computes them all) and the rays -- on synthetic data of
-BASELINE configs[1]: Replica room0, full 4-level grid, stage `color`, 1000 rays x 48 samples per GPU.
+(the reference never freezes any, so its autograd computes them all) and the rays -- on synthetic data.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU; rays are sharded, i.e. every rank renders its
-   own 1000-ray block (weak scaling), and leaf gradients are summed with one bucketed RCCL all-reduce.)
+  python bench.py --gpus N --steps K --warmup W [--config 2|4|5]
+
+  --config 2 (default)  BASELINE configs[1]: Replica room0, full 4-level grid, stage `color`, 1000 rays x 48 samples
+                        PER GPU (weak scaling: every rank renders its own 1000-ray block of an N x 1000 batch)
+  --config 4            BASELINE configs[3]: Replica office0 (91 MB of grids), 5000 rays per iteration SPLIT over the
+                        N GPUs (strong scaling: 625 rays per GPU at N = 8), RCCL all-reduce of the leaf gradients
+  --config 5            BASELINE configs[4] shapes: RPG recording4 (206 MB of grids, RPG camera), synthetic images,
+                        1000 rays per GPU (the real sequence and the callers' pipeline are not in the image)
+
+  N > 1: launched by torch.distributed.run, one rank per GPU.  Leaf gradients are summed with one bucketed RCCL
+  all-reduce (touched 64-voxel blocks only).  The default run (config 2) also measures config 4 on the same ranks
+  and reports it inside the SAME JSON line under "also" (disable with --no-secondary), so that a 1/2/4/8-GPU sweep
+  records both the weak (room0) and the strong (office0, 5000 rays) curve.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the `roofline` and `cpu_baseline` objects).
 """
 import argparse
+import gc as _gcmod
 import json
 import os
 import sys
@@ -39,6 +49,13 @@ SCENES = {      # mapping.bound of the reference configs (configs/Replica/room0.
 CAM = dict(H=680, W=1200, fx=600.0, fy=600.0, cx=599.5, cy=339.5)       # configs/Replica/replica.yaml:37-43
 CAM_RPG = dict(H=260, W=346, fx=196.71854278974607, fy=196.68898128242577, cx=172.5, cy=129.5)     # configs/rpg/rpg.yaml:62-68
 GRID_LEN = {'coarse': 2, 'middle': 0.32, 'fine': 0.16, 'color': 0.16, 'bound_divisible': 0.32}
+
+# measurement configurations of BASELINE.json / SURVEY.md 8(d): scene, rays, how the rays relate to the GPU count
+CONFIGS = {
+    2: dict(scene='room0', rays=1000, scaling='weak', name='config 2'),
+    4: dict(scene='office0', rays=5000, scaling='strong', name='config 4'),
+    5: dict(scene='recording4', rays=1000, scaling='weak', name='config 5 shapes'),
+}
 
 
 def cfg_dict():
@@ -151,55 +168,89 @@ def cpu_baseline(sc, rays, stage, budget_s=20.0):
                       f"1 warm-up at the best of the thread counts tried (rays/s: {others})"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--rays', type=int, default=1000, help='rays per GPU per step')
-    ap.add_argument('--stage', default='color')
-    ap.add_argument('--scene', default='room0')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-kernel-events', action='store_true')
-    ap.add_argument('--torch-loss', action='store_true', help='compute the mapper loss with torch ops instead of the fused HIP loss')
-    ap.add_argument('--separate-loss', action='store_true', help='render_batch_ray, then losses.rgbd_loss as its own launches')
-    ap.add_argument('--eager', action='store_true', help='time the plain Python-driven step instead of hipGraph replays')
-    args = ap.parse_args()
+class Env:
+    """Process-wide facts of a bench run: rank layout, device, communication switches."""
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU implementation")
-    # rehearsal on a one-GPU box: ENSLAM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and ENSLAM_BENCH_BACKEND=gloo
-    # replaces RCCL (which refuses two ranks on one device); the measured runs use neither
-    if os.environ.get('ENSLAM_BENCH_SHARE_GPU') == '1':
-        local_rank = 0
-    backend = os.environ.get('ENSLAM_BENCH_BACKEND', 'nccl')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    import torch.distributed as dist
-    # rehearsal of the communication path on ONE rank with real RCCL (collectives of a 1-rank group): not a measurement
-    force_comm = world == 1 and os.environ.get('ENSLAM_BENCH_FORCE_COMM') == '1'
-    if force_comm:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29777')
-        dist.init_process_group(backend, rank=0, world_size=1, **({'device_id': dev} if backend == 'nccl' else {}))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    def __init__(self, args):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        if args.gpus > 1 and self.world == 1 and os.environ.get('ENSLAM_BENCH_FORCE_COMM') != '1':
+            raise SystemExit(
+                f"bench.py --gpus {args.gpus} must run under torch.distributed.run, one rank per GPU:\n"
+                f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                f"--master-port 29500 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: the hot path has no CPU implementation")
+        # rehearsal on a one-GPU box: ENSLAM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and ENSLAM_BENCH_BACKEND=gloo
+        # replaces RCCL (which refuses two ranks on one device); the measured runs use neither
+        if os.environ.get('ENSLAM_BENCH_SHARE_GPU') == '1':
+            local_rank = 0
+        self.backend = os.environ.get('ENSLAM_BENCH_BACKEND', 'nccl')
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device('cuda', local_rank)
+        # rehearsal of the communication path on ONE rank with real RCCL (collectives of a 1-rank group): not a measurement
+        self.force_comm = self.world == 1 and os.environ.get('ENSLAM_BENCH_FORCE_COMM') == '1'
+        if self.force_comm:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29777')
+            dist.init_process_group(self.backend, rank=0, world_size=1, **({'device_id': self.dev} if self.backend == 'nccl' else {}))
+        if self.world > 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if self.backend == 'nccl':
+                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        self.comm_on = self.world > 1 or self.force_comm
 
+    def timed(self, fn, n):
+        """n calls of fn bracketed by barrier + synchronize on both sides; MAX over ranks of the wall time."""
+        dist = self.dist
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(n):
+            out = fn()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    def close(self):
+        if self.world > 1 or self.force_comm:
+            self.dist.destroy_process_group()
+
+
+def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, want_cpu_baseline):
+    """Measure one configuration.  scaling 'weak': `rays` per rank (batch = world x rays); 'strong': `rays` per
+    iteration, split over the ranks in contiguous blocks (parallel.shard_range)."""
     import evennicer_slam_amd as E
     import evennicer_slam_amd.functional as EF
     from evennicer_slam_amd import parallel as PAR
+    world, rank, dev = env.world, env.rank, env.dev
+    stage = args.stage
 
-    sc = build_scene_cpu(args.scene, seed=0)                      # identical replicas on every rank
-    rays_cpu = make_rays(sc, args.rays, seed=1000 + rank)         # each rank renders its own block of the batch
+    sc = build_scene_cpu(scene, seed=0)                            # identical replicas on every rank
+    if scaling == 'weak':                                          # rank r's block has its own seed; batch = all blocks
+        blocks = [make_rays(sc, rays, seed=1000 + r) for r in range(world)]
+        batch = [torch.cat([b[i] for b in blocks]) for i in range(4)]
+        lo, hi = rank * rays, (rank + 1) * rays
+    else:                                                          # one batch, contiguous block per rank
+        batch = list(make_rays(sc, rays, seed=1000))
+        lo, hi = PAR.shard_range(rays, rank, world)
+    n_local, n_batch = hi - lo, batch[0].shape[0]
+    rays_cpu = [t[lo:hi].contiguous() for t in batch]
     model = sc['model'].to(dev)
     attach_bounds(model, sc['bound'])
     grids = {k: v.to(dev).requires_grad_(True) for k, v in sc['grids'].items()}
@@ -208,23 +259,21 @@ def main():
     rd.requires_grad_(True)
     slam = types.SimpleNamespace(nice=True, bound=sc['bound'], **sc['cam'])
     renderer = E.Renderer(sc['cfg'], None, slam)
-    stage = args.stage
     kinds = EF.stage_kinds(stage)
     leaves = [grids[E._lib.GRID_NAMES[k]] for k in kinds]
     for k in kinds:
         leaves += list(getattr(model, E._lib.MLP_NAMES[k]).parameters())
 
-    comm_on = world > 1 or force_comm
+    comm_on, force_comm = env.comm_on, env.force_comm
     # Ray sharding hands every rank the WHOLE batch (parallel.ShardedRenderer): each rank holds all ranks' rays, so the
     # batch maxima of gt_depth and the union of the touched 64-voxel blocks are computed locally -- one marking launch
     # over all rays before the local step -- and the gradient SUM is the only collective of a step.
     # ENSLAM_BENCH_EXCHANGE_FLAGS=1: the ranks only know their own rays (MAX all-reduces of the depth maximum and of the
-    # block flags instead).
+    # block flags instead; per-rank marking cost independent of the rank count).
     whole_batch = comm_on and stage != 'coarse' and os.environ.get('ENSLAM_BENCH_EXCHANGE_FLAGS') != '1'
     ro_all = rd_all = gd_all = None
     if whole_batch:
-        others = [make_rays(sc, args.rays, seed=1000 + r) for r in range(world)]
-        ro_all, rd_all, gd_all = [torch.cat([o[i] for o in others]).to(dev) for i in range(3)]
+        ro_all, rd_all, gd_all = [batch[i].to(dev) for i in range(3)]
     dmax_static = None
     if comm_on and stage != 'coarse':
         dmax_static = PAR.global_depth_max(gd_all if whole_batch else gd, force=force_comm and not whole_batch)
@@ -268,7 +317,7 @@ def main():
             comm['bytes'] = PAR.allreduce_gradients(leaves, block_flags=prep['flags'], force=force_comm,
                                                     prepared=prep['prepared'])
         elif comm_on:
-            comm['bytes'] = PAR.allreduce_gradients(leaves, block_flags=EF.last_block_flags(), force=force_comm)
+            comm['bytes'] = PAR.allreduce_gradients(leaves, block_flags=renderer.state.last_block_flags(), force=force_comm)
 
     def step():
         pre()
@@ -276,47 +325,49 @@ def main():
         post()
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
 
-    # per-kernel timing of the dominant kernel with HIP events on the launch stream (eager pass of the same step)
-    events = None
-    if not args.no_kernel_events:
-        EF.PROFILE['decoder_bwd'] = []
-        for _ in range(min(args.steps, 50)):
+    # per-kernel timing of the dominant kernel with HIP events on the launch stream (eager passes of the same step):
+    # once as shipped (work list of the tiles with non-zero gradient) and once walking every tile (the dense figure)
+    events = events_dense = None
+    active = None
+    if want_events:
+        n_ev = min(steps, 50)
+        renderer.state.profile['decoder_bwd'] = []
+        for _ in range(n_ev):
             step()
         torch.cuda.synchronize()
-        events = EF.PROFILE.pop('decoder_bwd', None)
-
-    # eager (Python-driven) rate, always reported; the timed region below is graph replay unless --eager
-    def timed(fn, n):
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            out = fn()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, out
+        events = renderer.state.profile.pop('decoder_bwd', None)
+        active = renderer.state.last_active_tile_fraction()
+        if EF.USE_WORK_LIST and stage != 'coarse':
+            EF.USE_WORK_LIST = False
+            try:
+                for _ in range(3):
+                    step()
+                renderer.state.profile['decoder_bwd'] = []
+                for _ in range(n_ev):
+                    step()
+                torch.cuda.synchronize()
+                events_dense = renderer.state.profile.pop('decoder_bwd', None)
+            finally:
+                EF.USE_WORK_LIST = True
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
 
     mode = 'eager'
+    gstep = None
+    phases = None
     if args.eager:
-        elapsed, loss = timed(step, args.steps)
-        eager_elapsed, eager_steps = elapsed, args.steps
+        elapsed, loss = env.timed(step, steps)
+        eager_elapsed, eager_steps = elapsed, steps
     else:
-        eager_steps = min(args.steps, 50)
-        eager_elapsed, _ = timed(step, eager_steps)
+        eager_steps = min(steps, 50)
+        eager_elapsed, _ = env.timed(step, eager_steps)
         del _
         from evennicer_slam_amd.graph import GraphedStep
-        import gc as _gcmod
         for t in leaves:
             t.grad = None
         ro.grad = None
@@ -328,7 +379,7 @@ def main():
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); timing the eager step", file=sys.stderr)
             gstep = None
         if gstep is None:
-            elapsed, loss = timed(step, args.steps)
+            elapsed, loss = env.timed(step, steps)
         else:
             phases = [0.0, 0.0, 0.0] if os.environ.get('ENSLAM_BENCH_PHASES') == '1' else None
 
@@ -354,9 +405,9 @@ def main():
                 # Replays and eager collectives interleave on one stream; if that ever behaves badly on a node (it did
                 # when two ranks of a rehearsal shared one GPU), fall back to the Python-driven step.  Both modes do
                 # the same work; the choice is made on max-over-ranks times, so every rank takes the same branch.
-                trial = min(10, args.steps)
-                tg, _l = timed(graph_step, trial)
-                te, _l = timed(step, trial)
+                trial = min(10, steps)
+                tg, _l = env.timed(graph_step, trial)
+                te, _l = env.timed(step, trial)
                 del _l
                 if rank == 0 and os.environ.get('ENSLAM_BENCH_PHASES'):
                     print(f"[bench] trial: graph {tg / trial * 1e3:.3f} ms/step, eager {te / trial * 1e3:.3f} ms/step", file=sys.stderr)
@@ -364,51 +415,131 @@ def main():
                     mode = 'eager'
                     for t in leaves:
                         t.grad = None
-            elapsed, loss = timed(graph_step if mode == 'hipgraph' else step, args.steps)
+            elapsed, loss = env.timed(graph_step if mode == 'hipgraph' else step, steps)
+
+    # where a multi-rank step spends its time (HIP events around the three parts of 20 extra steps, this rank's stream;
+    # outside the timed region): what precedes the local step, the local step, the gradient collective with its glue
+    comm_ms = None
+    if comm_on:
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(20)]
+        local = (lambda: gstep.replay()) if (mode == 'hipgraph' and gstep is not None) else local_step
+        for e in ev:
+            e[0].record()
+            pre()
+            e[1].record()
+            local()
+            e[2].record()
+            post()
+            e[3].record()
+        torch.cuda.synchronize()
+        comm_ms = {"pre_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev])),
+                   "local_step_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in ev])),
+                   "gradient_allreduce_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))}
 
     S = 48 if stage != 'coarse' else 32
-    n_points = args.rays * S
+    total_rays = n_batch                                            # rays all ranks processed in one step
+    pretty = 'RPG' if scene == 'recording4' else 'Replica'
+    per = f"{rays} rays x {S} samples per GPU" if scaling == 'weak' else f"{rays} rays x {S} samples per iteration split over {world} GPU(s)"
     out = {
-        "metric": "rendered rays/sec (fwd+bwd)", "value": world * args.rays * args.steps / elapsed, "unit": "rays/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{'RPG' if args.scene == 'recording4' else 'Replica'} {args.scene} full 4-level grid, stage {stage}, {args.rays} rays x {S} samples "
-                               f"per GPU, render_batch_ray + mapper loss + backward (grads: grids, all decoder params, rays)",
-                   "rays_per_gpu": args.rays, "samples_per_ray": S,
+        "metric": "rendered rays/sec (fwd+bwd)", "value": total_rays * steps / elapsed, "unit": "rays/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{pretty} {scene} full 4-level grid, stage {stage}, {per}, render_batch_ray + mapper loss + "
+                               f"backward (grads: grids, all decoder params, rays)",
+                   "rays_per_gpu": n_local, "rays_per_step": total_rays, "samples_per_ray": S,
                    "parallelism": "1 GPU" if world == 1 else f"ray-sharded dp{world}, one bucketed RCCL all-reduce of leaf grads "
-                                                            f"(touched 64-voxel blocks only: {comm['bytes'] / 1e6:.1f} MB per step)"},
+                                                            f"(touched 64-voxel blocks only)"},
         "loss": float(loss.item()), "mode": mode, "loss_impl": "torch" if args.torch_loss else ("fused HIP (losses.rgbd_loss)" if args.separate_loss or stage == 'coarse'
                                                                   else "fused into the compositing launches (render_batch_ray_rgbd_loss)"),
-        "eager_rays_per_s": world * args.rays * eager_steps / eager_elapsed,
+        "eager_rays_per_s": total_rays * eager_steps / eager_elapsed,
     }
+    if comm_on:
+        out["comm"] = dict(comm_ms, bucket_bytes=int(comm['bytes']), mode=mode,
+                           flags="marked locally from the whole batch" if whole_batch else "MAX all-reduce of per-rank flags")
     if events:
         dur = np.array([a.elapsed_time(b) for a, b in events]) * 1e-3          # seconds
         avg = float(dur.mean())
+        n_points = n_local * S
         flops = n_points * 2 * FLOP_FWD_PER_POINT[stage]                        # dX + dW of every linear layer
-        step_flops = args.rays * S * 3 * FLOP_FWD_PER_POINT[stage]
-        traffic = None          # HBM-side bytes per launch from the committed PMC passes (profiles/r01_traffic.json)
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and args.rays == 1000 and stage == 'color':
-            traffic = json.load(open(tpath)).get("decoder_bwd_split_kernel", {}).get("bytes_per_launch")
+        step_flops = n_local * S * 3 * FLOP_FWD_PER_POINT[stage]
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes + WRITE_SIZE); they are NOT measured in this run
+        traffic, tsrc = None, None
+        for tname in ("r02_traffic.json", "r01_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and scene == 'room0' and n_local == 1000 and stage == 'color':
+                traffic = json.load(open(tpath)).get("decoder_bwd_split_kernel", {}).get("bytes_per_launch")
+                tsrc = f"profiles/{tname} (separate --pmc passes of this command; not measured in this run)"
+                break
+        frac = flops / avg / PEAK_F32_MFMA
         out["roofline"] = {
             "kernel": "decoder_bwd_split_kernel", "bound": "mfma", "achieved": flops / avg / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-            "unit": "TFLOP/s", "frac": flops / avg / PEAK_F32_MFMA, "traffic": traffic,
+            "unit": "TFLOP/s", "frac": frac, "traffic": traffic, "traffic_source": tsrc,
             "avg_launch_us": avg * 1e6, "launches": int(len(dur)),
-            "peak_measured": 138.9,     # TFLOP/s, v_mfma_f32_16x16x4_f32 micro-benchmark on the box (profiles/r01_peaks.txt)
-            # `achieved` prices the yardstick FLOPs of EVERY sample; tiles whose gradient is exactly zero (transmittance
-            # underflowed behind the room's boundary) are not scheduled at all -- this is the share that was
-            "active_tile_fraction": EF.last_active_tile_fraction(),
-            "step_frac": step_flops / PEAK_F32_MFMA / (elapsed / args.steps),
+            # `frac` prices the yardstick FLOPs of EVERY sample against the shipped kernel, which does not schedule the
+            # tiles whose gradient is exactly zero (transmittance underflowed behind the room's boundary).  The two
+            # figures below separate that algorithmic skipping from kernel efficiency:
+            #   frac_executed = frac x active_tile_fraction : FLOPs of the tiles the kernel actually walked / time
+            #   frac_dense    : the same kernel made to walk every tile (ENSLAM_WORK_LIST=0), yardstick FLOPs / its time
+            "active_tile_fraction": active,
+            "frac_executed": frac * active if active is not None else None,
+            "step_frac": step_flops / PEAK_F32_MFMA / (elapsed / steps),
         }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if events_dense:
+            dd = float(np.mean([a.elapsed_time(b) for a, b in events_dense])) * 1e-3
+            out["roofline"]["frac_dense"] = flops / dd / PEAK_F32_MFMA
+            out["roofline"]["avg_launch_us_dense"] = dd * 1e6
+    if want_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc, rays_cpu, stage)
-    if rank == 0 and not args.eager and mode == 'hipgraph' and gstep is not None and phases is not None:
+    if rank == 0 and phases is not None:
         print("[bench] phases ms/step: depth-max all-reduce %.3f, graph replay %.3f, gradient all-reduce %.3f"
-              % tuple(p / args.steps * 1e3 for p in phases), file=sys.stderr)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1 or force_comm:
-        dist.destroy_process_group()
+              % tuple(p / steps * 1e3 for p in phases), file=sys.stderr)
+    # release this workload's device memory before the next one is built
+    del gstep, grids, model, leaves, renderer
+    EF.clear_caches()
+    _gcmod.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS), help='measurement configuration (see module docstring)')
+    ap.add_argument('--rays', type=int, default=None, help='override the configuration\'s ray count (per GPU if weak, per step if strong)')
+    ap.add_argument('--scene', default=None, help='override the configuration\'s scene (room0, office0, recording4)')
+    ap.add_argument('--scaling', default=None, choices=('weak', 'strong'))
+    ap.add_argument('--stage', default='color')
+    ap.add_argument('--no-secondary', action='store_true', help='default run: skip the extra config-4 measurement reported under "also"')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--torch-loss', action='store_true', help='compute the mapper loss with torch ops instead of the fused HIP loss')
+    ap.add_argument('--separate-loss', action='store_true', help='render_batch_ray, then losses.rgbd_loss as its own launches')
+    ap.add_argument('--eager', action='store_true', help='time the plain Python-driven step instead of hipGraph replays')
+    args = ap.parse_args()
+
+    env = Env(args)
+    spec = dict(CONFIGS[args.config])
+    customised = args.rays is not None or args.scene is not None or args.scaling is not None
+    scene = args.scene or spec['scene']
+    rays = args.rays if args.rays is not None else spec['rays']
+    scaling = args.scaling or spec['scaling']
+    primary = run_workload(env, args, scene, rays, scaling, args.steps, args.warmup,
+                           want_events=not args.no_kernel_events,
+                           want_cpu_baseline=env.rank == 0 and env.world == 1 and not args.no_cpu_baseline)
+    primary["config"]["baseline_config"] = spec['name'] if not customised else "custom"
+    if args.config == 2 and not customised and not args.no_secondary and args.stage == 'color':
+        s4 = CONFIGS[4]
+        sec = run_workload(env, args, s4['scene'], s4['rays'], s4['scaling'], max(20, args.steps // 2), max(5, args.warmup // 2),
+                           want_events=False, want_cpu_baseline=False)
+        keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "mode", "loss", "comm", "eager_rays_per_s")
+        primary["also"] = {"config4": dict({k: sec[k] for k in keep if k in sec}, workload=sec["config"]["workload"],
+                                           rays_per_gpu=sec["config"]["rays_per_gpu"])}
+    if env.rank == 0:
+        print(json.dumps(primary), flush=True)
+    env.close()
 
 
 if __name__ == '__main__':

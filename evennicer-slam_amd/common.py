@@ -113,33 +113,67 @@ def get_camera_from_tensor(inputs):
 
 
 def get_tensor_from_camera(RT, Tquad=False):
-    """camera-to-world [3|4, 4] -> 7-vector (quaternion first, or translation first with Tquad).  The reference
-    goes through mathutils.Matrix.to_quaternion on the host; this is the same conversion (largest-diagonal branch,
-    real part >= 0 up to the sign convention of a unit quaternion) in float64 torch ops, result float32 on RT's device."""
+    """camera-to-world [3|4, 4] -> 7-vector (quaternion first, or translation first with Tquad), a float32 tensor on
+    the CPU whatever RT's device -- exactly what the reference returns (src/common.py:231-252 moves RT to the host
+    and its `gpu_id` is read after that move, so the result never goes back to the device).
+
+    The reference calls `mathutils.Matrix(R).to_quaternion()`; mathutils (pinned 2.81.2, environment.yaml:150) is
+    not in this image, so this restates Blender 2.81's `mat3_to_quat` = `normalize_m3` + `mat3_normalized_to_quat`
+    branch for branch: float32 matrix, columns normalised, the trace branch whenever 0.25 * (1 + trace) > 1e-4
+    (real part > 0), otherwise the largest-diagonal branches WITHOUT forcing the real part positive (near 180 degree
+    rotations can come back with a small negative real part, as from mathutils), then `normalize_qt`.  Sums in
+    float32 / float64 as in the C source.  Pinned on w >= 0 cases by tests/golden/ate_cases.npz and the tracker
+    fixture; the negative-w branches have no reference-generated fixture (mathutils absent)."""
     if not torch.is_tensor(RT):
         RT = torch.from_numpy(np.asarray(RT))
-    dev = RT.device
-    M = RT.detach().to('cpu', torch.float64)
-    R, T = M[:3, :3], M[:3, 3]
-    m00, m01, m02, m10, m11, m12, m20, m21, m22 = [float(v) for v in R.reshape(-1)]
-    tr = m00 + m11 + m22
-    if tr > 0:
-        s = 2.0 * (tr + 1.0) ** 0.5
-        q = [0.25 * s, (m21 - m12) / s, (m02 - m20) / s, (m10 - m01) / s]
-    elif m00 > m11 and m00 > m22:
-        s = 2.0 * (1.0 + m00 - m11 - m22) ** 0.5
-        q = [(m21 - m12) / s, 0.25 * s, (m01 + m10) / s, (m02 + m20) / s]
-    elif m11 > m22:
-        s = 2.0 * (1.0 + m11 - m00 - m22) ** 0.5
-        q = [(m02 - m20) / s, (m01 + m10) / s, 0.25 * s, (m12 + m21) / s]
+    M = RT.detach().to('cpu')
+    T = M[:3, 3].to(torch.float32)
+    f32 = np.float32
+    R = M[:3, :3].to(torch.float32).numpy().astype(np.float32)
+    # Blender stores mat[col][row]: its row vectors are the columns of R; normalize_m3 normalises those
+    mat = R.T.copy()
+    for i in range(3):
+        n = f32(np.sqrt(f32(mat[i, 0] * mat[i, 0] + mat[i, 1] * mat[i, 1] + mat[i, 2] * mat[i, 2])))
+        if n > f32(0):
+            mat[i] = mat[i] / n
+    q = np.zeros(4, dtype=np.float32)
+    tr = 0.25 * float(f32(f32(f32(f32(1.0) + mat[0, 0]) + mat[1, 1]) + mat[2, 2]))
+    if tr > float(f32(1e-4)):
+        s = np.sqrt(tr)
+        q[0] = f32(s)
+        s = 1.0 / (4.0 * s)
+        q[1] = f32(float(f32(mat[1, 2] - mat[2, 1])) * s)
+        q[2] = f32(float(f32(mat[2, 0] - mat[0, 2])) * s)
+        q[3] = f32(float(f32(mat[0, 1] - mat[1, 0])) * s)
+    elif mat[0, 0] > mat[1, 1] and mat[0, 0] > mat[2, 2]:
+        s = float(f32(2.0) * f32(np.sqrt(f32(f32(f32(f32(1.0) + mat[0, 0]) - mat[1, 1]) - mat[2, 2]))))
+        q[1] = f32(0.25 * s)
+        s = 1.0 / s
+        q[0] = f32(float(f32(mat[1, 2] - mat[2, 1])) * s)
+        q[2] = f32(float(f32(mat[1, 0] + mat[0, 1])) * s)
+        q[3] = f32(float(f32(mat[2, 0] + mat[0, 2])) * s)
+    elif mat[1, 1] > mat[2, 2]:
+        s = float(f32(2.0) * f32(np.sqrt(f32(f32(f32(f32(1.0) + mat[1, 1]) - mat[0, 0]) - mat[2, 2]))))
+        q[2] = f32(0.25 * s)
+        s = 1.0 / s
+        q[0] = f32(float(f32(mat[2, 0] - mat[0, 2])) * s)
+        q[1] = f32(float(f32(mat[1, 0] + mat[0, 1])) * s)
+        q[3] = f32(float(f32(mat[2, 1] + mat[1, 2])) * s)
     else:
-        s = 2.0 * (1.0 + m22 - m00 - m11) ** 0.5
-        q = [(m10 - m01) / s, (m02 + m20) / s, (m12 + m21) / s, 0.25 * s]
-    quad = torch.tensor(q, dtype=torch.float64)
-    if quad[0] < 0:
-        quad = -quad
-    out = torch.cat([T, quad]) if Tquad else torch.cat([quad, T])
-    return out.float().to(dev)
+        s = float(f32(2.0) * f32(np.sqrt(f32(f32(f32(f32(1.0) + mat[2, 2]) - mat[0, 0]) - mat[1, 1]))))
+        q[3] = f32(0.25 * s)
+        s = 1.0 / s
+        q[0] = f32(float(f32(mat[0, 1] - mat[1, 0])) * s)
+        q[1] = f32(float(f32(mat[2, 0] + mat[0, 2])) * s)
+        q[2] = f32(float(f32(mat[2, 1] + mat[1, 2])) * s)
+    ln = f32(np.sqrt(f32(f32(f32(q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3])))      # normalize_qt
+    if ln != f32(0):
+        q = (q * f32(f32(1.0) / ln)).astype(np.float32)
+    else:
+        q = np.array([1, 0, 0, 0], dtype=np.float32)
+    quad = torch.from_numpy(q)
+    # the reference concatenates float64 numpy pieces (mathutils floats widen to Python floats) and casts .float()
+    return torch.cat([T, quad]) if Tquad else torch.cat([quad, T])
 
 
 def sample_pdf(bins, weights, N_samples, det=False, device='cuda:0'):

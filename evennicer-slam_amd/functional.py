@@ -29,6 +29,58 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+# ------------------------------------------------------------------------------------------------
+# hipGraph capture bookkeeping (graph.GraphedStep)
+# ------------------------------------------------------------------------------------------------
+# Cached device-side forms (voxel-major grids, packed decoders) that are CREATED while a stream capture is recording live
+# in the graph's private memory pool and only hold data once that graph has been replayed; every replay rewrites them
+# with the values its inputs had at the START of the replay.  They are therefore tagged with the capture they were made
+# in and are invisible to everything outside that capture (an eager render after replays re-packs from the live tensors).
+_capture = {'epoch': 0, 'active': 0, 'raw_writes': None}
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def _cap_tag():
+    """0 outside a capture, else the id of the capture being recorded."""
+    return _capture['active'] if _capturing() else 0
+
+
+def _tag_visible(tag):
+    return tag == 0 or tag == _cap_tag()
+
+
+def begin_capture():
+    """Called by graph.GraphedStep right before it starts recording: new capture id, fresh log of raw writes."""
+    _capture['epoch'] += 1
+    _capture['active'] = _capture['epoch']
+    _capture['raw_writes'] = []
+
+
+def end_capture():
+    """-> the tensors that kernels of the captured step write behind torch's back (note_raw_write)."""
+    log, _capture['raw_writes'] = _capture['raw_writes'] or [], None
+    _capture['active'] = 0
+    seen, out = set(), []
+    for t in log:
+        if id(t) not in seen:
+            seen.add(id(t))
+            out.append(t)
+    return out
+
+
+def note_raw_write(tensors):
+    """A library kernel is about to overwrite these tensors in place (mapper.FusedAdam, MaskedGridOptimizer): bump their
+    version counters so the caches keyed on `_version` miss, and -- under capture -- remember them so that every replay
+    of the graph bumps them again (the Python call itself only runs at capture time)."""
+    for t in tensors:
+        torch._C._increment_version(t)
+    if _capture['raw_writes'] is not None and _capturing():
+        _capture['raw_writes'].extend(tensors)
+
+
 def bound6(bound):
     """[3,2] tensor -> (c_double*6) x_lo,x_hi,y_lo,y_hi,z_lo,z_hi."""
     b = bound.detach().to('cpu', torch.float64).reshape(-1).tolist()
@@ -130,17 +182,21 @@ class _PackCache:
     def __init__(self):
         self.key = None
         self.packed = None
+        self.tag = 0            # capture the packing was made in (0: eager memory)
+
+    def fresh(self, key):
+        return key == self.key and self.packed is not None and _tag_visible(self.tag)
 
     def get(self, kind, ps):
         key = tuple((id(p), p.data_ptr(), p._version) for p in ps)
-        if key != self.key:
+        if not self.fresh(key):
             _check_params(kind, ps)
             n = L.lib().enslam_packed_floats(kind)
             # fresh buffer: an earlier forward's saved packing stays valid for its backward
             packed = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
             s = _fill_params_struct(kind, ps)
             L.check(L.lib().enslam_pack_mlp(kind, ctypes.byref(s), _ptr(packed), _stream()), "enslam_pack_mlp")
-            self.key, self.packed = key, packed
+            self.key, self.packed, self.tag = key, packed, _cap_tag()       # (only after the launch was accepted)
         return self.packed
 
 
@@ -150,18 +206,28 @@ _pack_caches = weakref.WeakKeyDictionary()      # decoder module -> _PackCache
 def packed_decoders(items, arena=None, defer=False):
     """Packed forms of several decoders [(module, kind, params)]; stale ones are rebuilt with ONE zero-fill and ONE
     launch (up to three decoders per launch).  defer=True (at most three stale decoders): nothing is launched, the
-    second return value holds the arguments (n, kinds, structs, ptrs) for enslam_step_prepare, or None."""
+    second return value holds the arguments (n, kinds, structs, ptrs) for enslam_step_prepare, or None, and the third
+    a `commit()` the caller invokes once that launch has been accepted -- a cache entry is only marked fresh then, so a
+    failure in between (allocation, a refused launch) cannot leave a "fresh" entry pointing at a zero-filled buffer."""
     out, stale = [], []
     for i, (dec, kind, ps) in enumerate(items):
         cache = _pack_caches.get(dec)
         if cache is None:
             cache = _pack_caches[dec] = _PackCache()
         key = tuple((id(p), p.data_ptr(), p._version) for p in ps)
-        if key == cache.key:
+        if cache.fresh(key):
             out.append(cache.packed)
         else:
             out.append(None)
             stale.append((i, cache, key))
+    pending = []
+
+    def commit():
+        tag = _cap_tag()
+        for cache, key, packed in pending:
+            cache.key, cache.packed, cache.tag = key, packed, tag
+        del pending[:]
+
     if stale:
         lib = L.lib()
         sizes = [lib.enslam_packed_floats(items[i][1]) for i, _, _ in stale]
@@ -175,7 +241,7 @@ def packed_decoders(items, arena=None, defer=False):
             if where != getattr(cache, 'where', None):
                 _check_params(items[i][1], items[i][2])
                 cache.where, cache.struct = where, _fill_params_struct(items[i][1], items[i][2])
-            cache.key, cache.packed = key, pieces[j]
+            pending.append((cache, key, pieces[j]))
             out[i] = pieces[j]
         deferred = None
         for g0 in range(0, len(stale), 3):
@@ -185,15 +251,18 @@ def packed_decoders(items, arena=None, defer=False):
             for j, (i, cache, key) in enumerate(grp):
                 kinds[j] = items[i][1]
                 structs[j] = cache.struct
-                ptrs[j] = cache.packed.data_ptr()
+                ptrs[j] = out[i].data_ptr()
             if defer and len(stale) <= 3:
                 deferred = (n, kinds, structs, ptrs)
             else:
                 L.check(lib.enslam_pack_mlp_multi(n, kinds, structs, ptrs, _stream()), "enslam_pack_mlp_multi")
         if defer:
-            return out, deferred
+            if deferred is None:
+                commit()
+            return out, deferred, commit
+        commit()
     elif defer:
-        return out, None
+        return out, None, commit
     return out
 
 
@@ -207,21 +276,45 @@ def packed_decoder(dec, kind, params=None):
 # ------------------------------------------------------------------------------------------------
 # grids: voxel-major copies, cached per (storage, version)
 # ------------------------------------------------------------------------------------------------
+class _GridEntry:
+    __slots__ = ('ref', 'version', 'vm', 'valid', 'tag')
+
+    def __init__(self, ref, version, vm, valid, tag):
+        self.ref, self.version, self.vm, self.valid, self.tag = ref, version, vm, valid, tag
+
+
+def _check_grid(g):
+    if g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32 or g.dtype != torch.float32:
+        raise L.EnslamError(f"feature grid must be float32 [1,32,D,H,W], got {tuple(g.shape)} {g.dtype}")
+    _require_hip(g, "feature grids")
+
+
 class _GridCache:
     """Voxel-major copies keyed on tensor IDENTITY + version counter.  (A data_ptr key would go stale when the
     caching allocator hands a freed grid's address to a new tensor, e.g. Tracker.update_para_from_mapping's
-    per-frame clones.)  Entries die with their source tensor."""
+    per-frame clones.)  Entries die with their source tensor.  An entry is either dense (every voxel converted,
+    `valid is None`) or sparse (`valid` = bitmap of the 64-voxel blocks converted so far); entries made while a
+    hipGraph capture records are only visible inside that capture (see _capture)."""
 
     def __init__(self):
-        self.items = {}          # id(tensor) -> (weakref, version, voxel-major tensor)
+        self.items = {}          # id(tensor) -> _GridEntry
+
+    def _lookup(self, g, sparse):
+        e = self.items.get(id(g))
+        if e is not None and e.ref() is g and e.version == g._version and (e.valid is not None) == sparse and _tag_visible(e.tag):
+            return e
+        return None
+
+    def _store(self, g, vm, valid):
+        key, items = id(g), self.items
+        items[key] = _GridEntry(weakref.ref(g, lambda _r, key=key, items=items: items.pop(key, None)), g._version, vm, valid,
+                                _cap_tag())
 
     def get(self, g):
-        if g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32 or g.dtype != torch.float32:
-            raise L.EnslamError(f"feature grid must be float32 [1,32,D,H,W], got {tuple(g.shape)} {g.dtype}")
-        _require_hip(g, "feature grids")
-        e = self.items.get(id(g))
-        if e is not None and e[0]() is g and e[1] == g._version and len(e) == 3:
-            return e[2]
+        _check_grid(g)
+        e = self._lookup(g, False)
+        if e is not None:
+            return e.vm
         src = g.detach()
         if not src.is_contiguous():
             src = src.contiguous()
@@ -229,20 +322,16 @@ class _GridCache:
         # fresh buffer each refresh: an earlier forward's saved copy stays valid for its backward
         vm = torch.empty((V, 32), dtype=torch.float32, device=g.device)
         L.check(L.lib().enslam_grid_to_voxel_major(_ptr(src), _ptr(vm), V, _stream()), "grid_to_voxel_major")
-        key, items = id(g), self.items
-        self.items[key] = (weakref.ref(g, lambda _r, key=key, items=items: items.pop(key, None)), g._version, vm)
+        self._store(g, vm, None)
         return vm
-
 
     def get_many(self, grids):
         """Voxel-major copies of several grids; all cache misses are converted in ONE launch."""
         out, miss = [], []
         for i, g in enumerate(grids):
-            e = self.items.get(id(g))
-            if e is not None and e[0]() is g and e[1] == g._version and len(e) == 3:
-                out.append(e[2])
-            else:
-                out.append(None)
+            e = self._lookup(g, False)
+            out.append(e.vm if e is not None else None)
+            if e is None:
                 miss.append(i)
         if len(miss) == 1:
             out[miss[0]] = self.get(grids[miss[0]])
@@ -251,9 +340,7 @@ class _GridCache:
             srcs, dsts, vs, keep = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), []
             for j, i in enumerate(miss):
                 g = grids[i]
-                if g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32 or g.dtype != torch.float32:
-                    raise L.EnslamError(f"feature grid must be float32 [1,32,D,H,W], got {tuple(g.shape)} {g.dtype}")
-                _require_hip(g, "feature grids")
+                _check_grid(g)
                 src = g.detach()
                 src = src if src.is_contiguous() else src.contiguous()
                 V = g.shape[2] * g.shape[3] * g.shape[4]
@@ -263,11 +350,8 @@ class _GridCache:
                 out[i] = vm
             L.check(L.lib().enslam_grids_convert(n, srcs, dsts, vs, 1, _stream()), "enslam_grids_convert")
             for i in miss:
-                g = grids[i]
-                key, items = id(g), self.items
-                items[key] = (weakref.ref(g, lambda _r, key=key, items=items: items.pop(key, None)), g._version, out[i])
+                self._store(grids[i], out[i], None)
         return out
-
 
     def get_many_sparse(self, grids, need, arena=None, defer=False):
         """Voxel-major copies in which (at least) the 64-voxel blocks flagged in need[i] (uint8 tensors) are valid.
@@ -276,19 +360,16 @@ class _GridCache:
         srcs, dsts, vs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)()
         needs, valids, out, keep = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), [], []
         for i, g in enumerate(grids):
-            e = self.items.get(id(g))
-            if e is not None and e[0]() is g and e[1] == g._version and len(e) == 4:
-                vm, valid = e[2], e[3]
+            e = self._lookup(g, True)
+            if e is not None:
+                vm, valid = e.vm, e.valid
             else:
-                if g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32 or g.dtype != torch.float32:
-                    raise L.EnslamError(f"feature grid must be float32 [1,32,D,H,W], got {tuple(g.shape)} {g.dtype}")
-                _require_hip(g, "feature grids")
+                _check_grid(g)
                 V = g.shape[2] * g.shape[3] * g.shape[4]
                 vm = torch.empty((V, 32), dtype=torch.float32, device=g.device)
                 valid = (arena.take((V + 63) // 64, torch.uint8) if arena is not None else
                          torch.zeros((V + 63) // 64, dtype=torch.uint8, device=g.device))
-                key, items = id(g), self.items
-                items[key] = (weakref.ref(g, lambda _r, key=key, items=items: items.pop(key, None)), g._version, vm, valid)
+                self._store(g, vm, valid)
             src = g.detach()
             src = src if src.is_contiguous() else src.contiguous()
             keep.append(src)
@@ -324,15 +405,15 @@ def refresh_in_place(c, decoders, stage='color'):
         if isinstance(g, VoxelMajorGrid):
             continue                                    # already the kernels' layout: nothing cached
         e = _grid_cache.items.get(id(g))
-        if e is not None and e[0]() is g and len(e) == 3 and e[1] != g._version:
+        if e is not None and e.ref() is g and e.valid is None and e.tag == 0 and e.version != g._version:
             src = g.detach()
             src = src if src.is_contiguous() else src.contiguous()
-            L.check(lib.enslam_grid_to_voxel_major(_ptr(src), _ptr(e[2]), e[2].shape[0], _stream()), "grid_to_voxel_major")
-            _grid_cache.items[id(g)] = (e[0], g._version, e[2])
+            L.check(lib.enslam_grid_to_voxel_major(_ptr(src), _ptr(e.vm), e.vm.shape[0], _stream()), "grid_to_voxel_major")
+            e.version = g._version
             n += 1
         dec = getattr(decoders, L.MLP_NAMES[k])
         cache = _pack_caches.get(dec)
-        if cache is None or cache.packed is None:
+        if cache is None or cache.packed is None or cache.tag != 0:
             continue
         ps = decoder_params(dec, k)
         key = tuple((id(p), p.data_ptr(), p._version) for p in ps)
@@ -368,13 +449,38 @@ def stage_kinds(stage):
 # ------------------------------------------------------------------------------------------------
 # the differentiable render call
 # ------------------------------------------------------------------------------------------------
-_last_flags = {}        # id(grid tensor) -> uint8 flags of the 64-voxel blocks the latest render call touched
+class RenderState:
+    """What a render call leaves behind for its caller, per Renderer (two renderers -- a tracker's and a mapper's in one
+    process, possibly on different streams -- do not see each other's):
+      flags    {id(grid tensor): uint8 flags} of the 64-voxel blocks the latest call touched (parallel.allreduce_gradients
+               sends only those); under hipGraph replay the buffers are rewritten in place by every replay
+      work     (counter tensor, number of tiles) of the latest call's backward work list
+      profile  {'decoder_bwd': [(event, event), ...]} when a caller (bench.py) asks for per-kernel timing"""
+
+    def __init__(self):
+        self.flags = {}
+        self.work = (None, 0)
+        self.profile = {}
+
+    def last_block_flags(self):
+        return dict(self.flags)
+
+    def last_active_tile_fraction(self):
+        """Share of the 16-sample tiles of the most recent render call that its backward scheduled (work list of tiles
+        with non-zero d_raw); None when that call kept no list.  Synchronises."""
+        wcount, n = self.work
+        if wcount is None or n == 0:
+            return None
+        return float(wcount.item()) / n
+
+
+_default_state = RenderState()      # calls made without a Renderer (functional.render with a bare plan)
+_latest_state = [_default_state]
 
 
 def last_block_flags():
-    """{id(grid tensor): flags} of the most recent render call (parallel.allreduce_gradients uses them to send only
-    the touched blocks).  Under hipGraph replay the flag buffers are rewritten in place by every replay."""
-    return dict(_last_flags)
+    """`RenderState.last_block_flags()` of whichever renderer rendered last in this process (single-renderer callers)."""
+    return _latest_state[0].last_block_flags()
 
 
 class VoxelMajorGrid:
@@ -424,6 +530,7 @@ class RenderPlan:
         self.n_params = {k: (12 if k == L.MLP_COARSE else 23) for k in kinds}
         self.vm = {}                            # kind -> VoxelMajorGrid for grids passed in the device layout
         self.loss = None                        # (gt_depth [N] f32, gt_color [N,3] f32 | None, w_color): fused mapper loss
+        self.state = _default_state             # the calling Renderer's RenderState
 
 
 class _Accumulators:
@@ -499,7 +606,9 @@ class _RenderFn(torch.autograd.Function):
         arena = _ZeroArena(dev, 2 * sum(nblk) + 4 * sum(lib.enslam_packed_floats(k) for k in plan.kinds) + 256 + 32)
         flags = [None] * nk
         grids_vm, packed = {k: vmg[k].vm for k in vmg}, {}
-        _last_flags.clear()
+        state = plan.state
+        _latest_state[0] = state
+        state.flags = {}
         msc, fptr = None, None
         if dense:                       # the sampler marks the blocks of the samples it places
             flag_buf = arena.take(sum(nblk), torch.uint8)
@@ -510,7 +619,7 @@ class _RenderFn(torch.autograd.Function):
                 flags[i] = fl
                 fptr[k] = fl.data_ptr()
                 msc.grids[k].D, msc.grids[k].H, msc.grids[k].W = dims[k]
-                _last_flags[id(grids[i])] = fl
+                state.flags[id(grids[i])] = fl
         L.check(lib.enslam_sample_rays(N, plan.n_lin, plan.n_surf, _ptr(ro), _ptr(rd), _ptr(gd), plan.bound6,
                                        _ptr(plan.t_lin), _ptr(plan.t_surf), plan.lindisp, _ptr(t_rand),
                                        _ptr(scratch), int(plan.depth_max is not None), _ptr(z), L.STAGE[plan.stage],
@@ -529,7 +638,7 @@ class _RenderFn(torch.autograd.Function):
         for k in plan.kinds:
             items.append((plan.decoders[k], k, tensors[po:po + plan.n_params[k]]))
             po += plan.n_params[k]
-        pks, pack_args = packed_decoders(items, arena, defer=True)
+        pks, pack_args, pack_commit = packed_decoders(items, arena, defer=True)
         for k, pk in zip(plan.kinds, pks):
             packed[k] = pk
         # ONE launch: pack the stale decoders, convert the touched blocks, clear the backward's accumulators
@@ -543,6 +652,7 @@ class _RenderFn(torch.autograd.Function):
                                             accum.n_flat if accum is not None else 0, st), "enslam_step_prepare")
             if accum is not None:
                 accum.clean = True
+        pack_commit()
         del keep_
         sc = _scene_struct(plan.stage, plan.bound6, plan.coarse_bound6, grids_vm, dims, packed)
         depth = torch.empty(N, dtype=torch.float64, device=dev)
@@ -584,7 +694,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.rgb = rgb if plan.loss is not None else None
         ctx.d_raw_unit = d_raw_unit if plan.loss is not None else None
         ctx.work, ctx.wcount = work, wcount
-        _last_work[0], _last_work[1] = wcount, N * (S // 16)
+        state.work = (wcount, N * (S // 16))
         ctx.work_filled = plan.loss is not None and work is not None and d_raw_unit is not None      # (by the forward)
         ctx.grid_shapes = [tuple(g.shape) for g in grids]
         ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
@@ -672,7 +782,7 @@ class _RenderFn(torch.autograd.Function):
         dgw = None
         if act is not None and need_rays:
             dgw = torch.empty(lib.enslam_grid_handoff_floats(L.STAGE[plan.stage], N, S), dtype=torch.float32, device=dev)
-        ev = PROFILE.get('decoder_bwd')
+        ev = plan.state.profile.get('decoder_bwd')
         if ev is not None:                      # bench.py: HIP events around the dominant kernel, on this stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -729,20 +839,11 @@ class _RenderFn(torch.autograd.Function):
 ACT_WORKSPACE_LIMIT_BYTES = 8 << 30
 
 USE_WORK_LIST = os.environ.get('ENSLAM_WORK_LIST', '1') == '1'     # backward walks only the tiles with non-zero d_raw
-_last_work = [None, 0]
 
 
 def last_active_tile_fraction():
-    """Share of the 16-sample tiles of the most recent render call that its backward scheduled (work list of tiles with
-    non-zero d_raw); None when that call kept no list or the list has not been filled yet.  Synchronises."""
-    wcount, n = _last_work
-    if wcount is None or n == 0:
-        return None
-    return float(wcount.item()) / n
-
-
-
-PROFILE = {}        # {'decoder_bwd': [(event_begin, event_end), ...]} when bench.py asks for per-kernel timing
+    """`RenderState.last_active_tile_fraction()` of whichever renderer rendered last in this process."""
+    return _latest_state[0].last_active_tile_fraction()
 
 
 def render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params_flat):

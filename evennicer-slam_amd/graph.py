@@ -27,10 +27,19 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         gc.collect()                            # reference cycles holding tensors of the warm-up steps (see below)
+        from . import functional as EF
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = step_fn()
+        EF.begin_capture()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = step_fn()
+        finally:
+            # tensors the captured kernels overwrite behind torch's back (FusedAdam, MaskedGridOptimizer): the Python
+            # calls that announce those writes only ran now, so every replay announces them again
+            self.raw_writes = EF.end_capture()
 
     def replay(self):
         self.graph.replay()
+        for t in self.raw_writes:
+            torch._C._increment_version(t)
         return self.out

@@ -16,7 +16,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .functional import VoxelMajorGrid, _ptr, _require_hip, _stream
+from .functional import VoxelMajorGrid, _ptr, _require_hip, _stream, note_raw_write
 
 GRID_KEYS = ('grid_coarse', 'grid_middle', 'grid_fine', 'grid_color')
 
@@ -186,7 +186,8 @@ class FusedAdam:
             P[i], G[i], M[i], V[i] = p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
             numel[i] = p.numel()
         self.step_t += 1
-        for p in self.params:                 # raw kernel writes: tell torch (and the packed-decoder cache) they changed
-            torch._C._increment_version(p)
+        # raw kernel writes: tell torch (and the packed-decoder cache) they changed -- now, and on every replay when
+        # this call is being captured (graph.GraphedStep.replay)
+        note_raw_write(self.params)
         L.check(L.lib().enslam_adam_tensors(n, P, G, M, V, numel, _ptr(self.lr_t), _ptr(self.step_t), self.betas[0],
                                             self.betas[1], self.eps, _stream()), "enslam_adam_tensors")

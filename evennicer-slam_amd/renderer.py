@@ -29,6 +29,8 @@ class Renderer(object):
         self._tvals = {}
         # ray-sharded callers (parallel.ShardedRenderer) set this to functional.batch_depth_max(whole batch)
         self.depth_max_override = None
+        # what render calls leave behind for this renderer's caller (touched-block flags, work-list size, profiling hooks)
+        self.state = EF.RenderState()
 
     # ------------------------------------------------------------------ helpers
     def _t_vals(self, device, n_lin, n_surf):
@@ -102,6 +104,7 @@ class Renderer(object):
         plan = EF.RenderPlan(stage, self.bound, self._coarse_bound(decoders), n_lin, n_surf, self.lindisp, t_lin,
                              t_surf, kinds, decs, depth_max=self.depth_max_override if gt_depth is not None else None)
         plan.loss = loss
+        plan.state = self.state
         grids = []
         for k in kinds:
             g = c[L.GRID_NAMES[k]]

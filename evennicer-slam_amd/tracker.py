@@ -266,6 +266,10 @@ class GraphedCameraIteration(object):
             return tuple(z if o[k] is None else o[k].detach() for k in ('rgbd', 'event', 'mask'))
 
         self.graph = GraphedStep(it, warmup=warmup)
+        # The captured iteration reads the device-side forms (voxel-major copies, packed decoders) of exactly these
+        # objects: the graph owns them from here on (refresh_map copies a replaced map INTO them).
+        self._map_c = {k: trk.c[k] for k in ('grid_middle', 'grid_fine', 'grid_color')}
+        self._map_decoders = trk.decoders
 
     def set_frame(self, gt_color, gt_depth, gt_event=None, gt_mask=None, pre_gt_color=None):
         self.gt_color.copy_(gt_color)
@@ -274,11 +278,46 @@ class GraphedCameraIteration(object):
             for dst, src in zip(self.frame, self.trk.prepare_event_frame(gt_event, gt_mask, pre_gt_color, self.scale_factor)):
                 dst.copy_(src)
 
-    def refresh_map(self):
-        """Call after the tracker's map (`trk.c` tensors, `trk.decoders` parameters) was updated in place: the captured
-        iteration reads the cached voxel-major grids and packed decoders, which this rewrites in place."""
+    def refresh_map(self, c=None, decoders=None):
+        """Make the captured iteration see a new map.  `c` / `decoders` default to what the tracker holds now
+        (`trk.c`, `trk.decoders`).  The reference's `Tracker.update_para_from_mapping` (Tracker.py:247-259) REPLACES
+        its map per frame (`self.c[key] = val.clone()`, `self.decoders = copy.deepcopy(shared_decoders)`); an in-place
+        update (`trk.c[key].copy_(val)`) works as well.  Either way the new values are copied into the tensors and the
+        decoder module the graph was captured with, the tracker is pointed back at those objects, and their cached
+        voxel-major / packed forms are rewritten in place.  Returns the number of device buffers rewritten (>= 1 unless
+        nothing changed); raises when the new map does not have the captured shapes."""
+        from . import _lib as L
         from .functional import refresh_in_place
-        return refresh_in_place(self.trk.c, self.trk.decoders, 'color')
+        trk = self.trk
+        c = trk.c if c is None else c
+        decoders = trk.decoders if decoders is None else decoders
+        with torch.no_grad():
+            for k, cap in self._map_c.items():
+                new = c[k]
+                if new is not cap:
+                    if tuple(new.shape) != tuple(cap.shape):
+                        raise L.EnslamError(f"refresh_map: {k} has shape {tuple(new.shape)}, the captured iteration was recorded "
+                                            f"with {tuple(cap.shape)}; capture a new GraphedCameraIteration")
+                    cap.copy_(new)
+            if decoders is not self._map_decoders:
+                mine = dict(self._map_decoders.named_parameters())
+                theirs = dict(decoders.named_parameters())
+                if set(mine) != set(theirs):
+                    raise L.EnslamError("refresh_map: the new decoders do not have the captured module's parameters")
+                for name, p in mine.items():
+                    p.copy_(theirs[name])
+                for name in ('bound',):                                  # plain attributes the renderer reads
+                    for sub in ('', 'coarse_decoder', 'middle_decoder', 'fine_decoder', 'color_decoder'):
+                        src = getattr(decoders, sub) if sub else decoders
+                        dst = getattr(self._map_decoders, sub) if sub else self._map_decoders
+                        if hasattr(src, name):
+                            setattr(dst, name, getattr(src, name))
+        if trk.c is None:
+            trk.c = {}
+        for k, cap in self._map_c.items():
+            trk.c[k] = cap
+        trk.decoders = self._map_decoders
+        return refresh_in_place(trk.c, trk.decoders, 'color')
 
     def step(self):
         return self.graph.replay()

@@ -162,6 +162,39 @@ def test_static_shape_and_graphed_iteration_match_fixture(monkeypatch):
     assert abs(l_rgbd.item() - o['rgbd'].item()) <= 1e-6 * abs(o['rgbd'].item())
     assert abs(l_event.item() - o['event'].item()) <= 1e-5 * abs(o['event'].item())
     assert abs(stale[0] - o['rgbd'].item()) > 1e-4 * abs(o['rgbd'].item())      # (before the refresh it rendered the old map)
+    del o
+
+    # the reference's protocol REPLACES the map per frame (Tracker.py:247-259: `self.c[key] = val.clone()`,
+    # `self.decoders = copy.deepcopy(shared_decoders)`): the graph owns its map buffers and copies the new map into them
+    import copy
+    captured = {k: trk.c[k] for k in ('grid_middle', 'grid_fine', 'grid_color')}
+    captured_dec = trk.decoders
+    with torch.no_grad():
+        shared_c = {k: v.clone() for k, v in trk.c.items()}
+        shared_c['grid_middle'].mul_(0.8)
+        shared_c['grid_color'].add_(0.02)
+        shared_dec = copy.deepcopy(trk.decoders)
+        shared_dec.fine_decoder.pts_linears[1].weight.mul_(1.1)
+    trk.c = {k: v.clone() for k, v in shared_c.items()}             # update_para_from_mapping
+    trk.decoders = copy.deepcopy(shared_dec)
+    assert git.refresh_map() >= 3
+    assert all(trk.c[k] is captured[k] for k in captured) and trk.decoders is captured_dec
+    assert torch.equal(trk.c['grid_middle'], shared_c['grid_middle'])
+    l_rgbd, l_event, l_mask = git.step()
+    # ground truth: an eager iteration on a FRESH tracker map holding the same values
+    trk2_c, trk2_dec = trk.c, trk.decoders
+    trk.c = {k: v.clone() for k, v in shared_c.items()}
+    trk.decoders = copy.deepcopy(shared_dec)
+    o = trk.iteration_losses(ct, img['gt_color'], img['gt_depth'], frame, int(fx['batch_size']), True, True, sf,
+                             static_shapes=True)
+    trk.c, trk.decoders = trk2_c, trk2_dec
+    assert abs(l_rgbd.item() - o['rgbd'].item()) <= 1e-6 * abs(o['rgbd'].item())
+    assert abs(l_event.item() - o['event'].item()) <= 1e-5 * abs(o['event'].item())
+    # explicit arguments work as well, and a wrong shape is refused
+    assert git.refresh_map(shared_c, shared_dec) >= 0
+    bad = dict(shared_c, grid_color=shared_c['grid_color'][:, :, :-1].contiguous())
+    with pytest.raises(Exception):
+        git.refresh_map(bad, shared_dec)
 
 
 def E_tracker():

@@ -227,3 +227,57 @@ def test_fused_loss_backward_twice_accumulates():
     assert float((twice - 2 * once).abs().max()) <= 1e-5 * float(once.abs().max())
     for p in model.parameters():
         p.grad = None
+
+
+def test_eager_consumers_see_decoders_a_captured_optimiser_stepped():
+    """A captured mapper iteration (render + fused loss + backward + FusedAdam on the colour decoder) mutates the decoder
+    parameters on every replay through raw kernel writes, and packs its decoders into graph-pool memory.  An eager
+    consumer afterwards (render_img, eval_points for meshing, the visualiser) must render with the CURRENT parameters:
+    same result as a freshly cloned module that never saw the graph."""
+    import copy
+    import gc
+    import evennicer_slam_amd.functional as EF
+    from evennicer_slam_amd.graph import GraphedStep
+    from evennicer_slam_amd.mapper import FusedAdam
+    from tests.hip_util import DEV, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+    params = list(model.color_decoder.parameters())
+    opt = FusedAdam(params, lr=1e-2)
+    one = {}
+
+    def it():
+        for t in g.values():
+            t.grad = None
+        opt.zero_grad()
+        loss, *_ = renderer.render_batch_ray_rgbd_loss(g, model, rays['rays_d'], rays['rays_o'], DEV, 'color', rays['gt_depth'],
+                                                       rays['gt_color'], 0.2)
+        if 'g' not in one:
+            one['g'] = torch.ones_like(loss)
+        loss.backward(gradient=one['g'])
+        opt.step()
+        return loss
+
+    before = model.color_decoder.output_linear.weight.detach().clone()
+    gc.collect()
+    gs = GraphedStep(it)
+    versions = [p._version for p in params]
+    l0 = gs.replay().item()
+    for _ in range(3):
+        l1 = gs.replay().item()
+    assert l1 != l0                                                     # the optimiser really steps inside the graph
+    assert all(p._version > v for p, v in zip(params, versions))        # ... and every replay announces its writes
+    assert float((model.color_decoder.output_linear.weight - before).abs().max()) > 0
+    with torch.no_grad():
+        d1, u1, c1 = renderer.render_batch_ray(grids, model, rays['rays_d'], rays['rays_o'], DEV, 'color', gt_depth=rays['gt_depth'])
+        fresh = copy.deepcopy(model)
+        d2, u2, c2 = renderer.render_batch_ray(grids, fresh, rays['rays_d'], rays['rays_o'], DEV, 'color', gt_depth=rays['gt_depth'])
+        p = rays['rays_o'][:50].double() + 0.3 * rays['rays_d'][:50].double()
+        r1 = renderer.eval_points(p, model, grids, 'color', DEV)
+        r2 = renderer.eval_points(p, fresh, grids, 'color', DEV)
+    assert torch.equal(c1, c2) and torch.equal(d1, d2) and torch.equal(r1, r2)
+    # the next replay still works and keeps stepping
+    l2 = gs.replay().item()
+    assert l2 != l1
+    del gs
+    EF.clear_caches()

@@ -17,7 +17,7 @@ def run(grid_grad, par_grad, ray_grad, stage='color', steps=30):
     grids = {k: v.to(dev).requires_grad_(bool(grid_grad)) for k, v in sc['grids'].items()}
     for p in model.parameters(): p.requires_grad_(bool(par_grad))
     ro = ro0.clone().requires_grad_(bool(ray_grad)); rd = rd0.clone().requires_grad_(bool(ray_grad))
-    EF.PROFILE['decoder_bwd'] = []
+    renderer.state.profile['decoder_bwd'] = []
     fwd = []
     for i in range(steps + 5):
         for p in model.parameters(): p.grad = None
@@ -29,7 +29,7 @@ def run(grid_grad, par_grad, ray_grad, stage='color', steps=30):
         fwd.append((a, b))
         bench.mapper_loss(d, c, gd, gc, stage).backward()
     torch.cuda.synchronize()
-    ev = EF.PROFILE.pop('decoder_bwd')
+    ev = renderer.state.profile.pop('decoder_bwd')
     t = np.array([x.elapsed_time(y) for x, y in ev[5:]]) * 1e3
     tf = np.array([x.elapsed_time(y) for x, y in fwd[5:]]) * 1e3
     print(f"stage {stage:6s} grid_grad={int(grid_grad)} par_grad={int(par_grad)} ray_grad={int(ray_grad)}: decoder_bwd median {np.median(t):8.1f} us  min {t.min():8.1f}   fwd(all launches) median {np.median(tf):7.1f} us", flush=True)

@@ -15,14 +15,14 @@ grids = {k: v.to(dev).requires_grad_(True) for k, v in sc['grids'].items()}
 ro, rd, gd, gc = [t.to(dev) for t in bench.make_rays(sc, 1000, 1000)]
 renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **bench.CAM))
 def run(tag):
-    EF.PROFILE['decoder_bwd'] = []
+    renderer.state.profile['decoder_bwd'] = []
     for _ in range(30):
         EF.clear_caches()
         for g in grids.values(): g.grad = None
         loss, depth, var, color = renderer.render_batch_ray_rgbd_loss(grids, model, rd, ro, dev, 'color', gd, gc, 0.2)
         loss.backward()
     torch.cuda.synchronize()
-    ev = EF.PROFILE.pop('decoder_bwd')
+    ev = renderer.state.profile.pop('decoder_bwd')
     t = np.array([a.elapsed_time(b) for a, b in ev][5:]) * 1e3
     print(f"work list {'on' if EF.USE_WORK_LIST else 'off'}; {tag}: decoder backward {t.mean():.1f} us (min {t.min():.1f}), loss {loss.item():.1f}, "
           f"|grad fine| {float(grids['grid_fine'].grad.abs().sum()):.6e}")
