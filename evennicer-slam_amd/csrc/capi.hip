@@ -693,3 +693,10 @@ int enslam_ray_points(int32_t n_rays, int32_t n_samples, const float* rays_o, co
 }
 
 }  // extern "C"
+
+int enslam_fourier_sincos(int64_t n, const float* x, float* sin_out, float* cos_out, void* stream) {
+    if (n < 0) return ENSLAM_EINVAL;
+    if (n == 0) return ENSLAM_OK;
+    if (!x || (!sin_out && !cos_out)) return ENSLAM_EINVAL;
+    return ens_launch_sincos(n, x, sin_out, cos_out, (hipStream_t)stream);
+}

@@ -275,14 +275,24 @@ ENS_DEV void out_layer(f32x4 (&o)[NTL], const float* __restrict__ Wo, const floa
     }
 }
 
-// sin / cos of the Fourier argument p@B (|x| up to a few thousand: B ~ 25*randn, decoder.py:21-22).
-// Range reduction in float64 (one fma against pi/2: exact to ~1e-9 for |x| < 1e7), then the
-// classic float32 minimax polynomials on [-pi/4, pi/4].  ~1 ulp; no calls, no tables.
+// sin / cos of the Fourier argument p@B (|x| up to a few thousand: B ~ 25*randn, decoder.py:21-22), float32 only.
+// Range reduction: k = rint(x * 2/pi), r = x - k*pi/2 with the Cody-Waite split of pi/2 into three float32 constants
+// (twice Cephes' sinf DP1..DP3): C1 has 8 significant bits, so k*C1 is exact for |k| < 2^16 and the first fused
+// multiply-add returns x - k*C1 exactly; the other two round once each.  |error of r| < 1.5e-7 for |x| < 1e5 (the argument
+// itself carries 1.2e-4 of float32 rounding at |x| = 2000), then the classic float32 minimax polynomials on
+// [-pi/4, pi/4].  No float64 instructions (they issue at half rate), no calls, no tables.
+// tests/test_hip_forward.py::test_fourier_embedding_large_arguments pins |x| up to 4000 against float64.
+ENS_DEV float ens_reduce_pio2(float x, int& n) {
+    const float k = rintf(x * 0.63661977236758134308f);                 // 2/pi
+    float r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188216e-8f, r);
+    n = (int)k;
+    return r;
+}
 ENS_DEV void ens_sincosf(float x, float& s, float& c) {
-    const double xd = (double)x;
-    const double k = rint(xd * 0.63661977236758134308);             // 2/pi
-    const float r = (float)fma(-k, 1.57079632679489661923, xd);
-    const int n = (int)k;
+    int n;
+    const float r = ens_reduce_pio2(x, n);
     const float z = r * r;
     const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
     const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
@@ -295,10 +305,8 @@ ENS_DEV void ens_sincosf(float x, float& s, float& c) {
 // sin alone: the same reduction and the same two polynomials, but only the one the quadrant selects is evaluated
 // (coefficients chosen by n & 1) -- bit-identical to the s of ens_sincosf.
 ENS_DEV float ens_sinf(float x) {
-    const double xd = (double)x;
-    const double k = rint(xd * 0.63661977236758134308);
-    const float r = (float)fma(-k, 1.57079632679489661923, xd);
-    const int n = (int)k;
+    int n;
+    const float r = ens_reduce_pio2(x, n);
     const bool odd = n & 1;
     const float z = r * r;
     const float k3 = odd ? 2.443315711809948e-5f : -1.9515295891e-4f;
@@ -307,6 +315,19 @@ ENS_DEV float ens_sinf(float x) {
     const float t = fmaf(fmaf(k3, z, k2), z, k1) * z;
     const float v = fmaf(t, odd ? z : r, odd ? fmaf(-0.5f, z, 1.f) : r);
     return (n & 2) ? -v : v;
+}
+// cos alone, same scheme (the backward's d sin(x)/dx)
+ENS_DEV float ens_cosf(float x) {
+    int n;
+    const float r = ens_reduce_pio2(x, n);
+    const bool odd = n & 1;                                             // odd quadrant: |cos| = sin polynomial
+    const float z = r * r;
+    const float k3 = odd ? -1.9515295891e-4f : 2.443315711809948e-5f;
+    const float k2 = odd ? 8.3321608736e-3f : -1.388731625493765e-3f;
+    const float k1 = odd ? -1.6666654611e-1f : 4.166664568298827e-2f;
+    const float t = fmaf(fmaf(k3, z, k2), z, k1) * z;
+    const float v = fmaf(t, odd ? r : z, odd ? r : fmaf(-0.5f, z, 1.f));
+    return ((n + 1) & 2) ? -v : v;
 }
 
 // wave-wide helpers (64 lanes)

@@ -124,6 +124,7 @@ int ens_launch_ray_points(int n_rays, int S, const float* ro, const float* rd, c
                           double* pts, uint8_t* mask, hipStream_t st);
 int ens_launch_voxel_index(int64_t n, const double* pts, const double* bound, int D, int H, int W, int* ix, int* iy,
                            int* iz, float* fx, float* fy, float* fz, hipStream_t st);
+int ens_launch_sincos(int64_t n, const float* x, float* s, float* c, hipStream_t st);
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
                           double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st,

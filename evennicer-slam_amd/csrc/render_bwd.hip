@@ -733,11 +733,7 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
             for (int t = 0; t < 6; ++t) {                               // cos(arg) recomputed: cheaper than carrying it
                 const f32x4 arg = MFMA16(pk[L.oBT() + (16 * t + p) * 4 + q], pc, splat4(0.f));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sv, cv;
-                    ens_sincosf(arg[r], sv, cv);
-                    demb[t][r] *= cv;
-                }
+                for (int r = 0; r < 4; ++r) demb[t][r] *= ens_cosf(arg[r]);
             }
             if (want_w) {
                 __syncthreads();                                     // every wave is done reading EMB
@@ -1097,11 +1093,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 const float a = *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(ring0 + OBT + ((16 * t + p) * 4 + q) * 4));
                 const f32x4 arg = MFMA16(a, pc, splat4(0.f));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sv, cv;
-                    ens_sincosf(arg[r], sv, cv);
-                    demb[t][r] *= cv;
-                }
+                for (int r = 0; r < 4; ++r) demb[t][r] *= ens_cosf(arg[r]);
             }
             if (want_w) {
                 __syncthreads();                                     // every wave is done reading EMB

@@ -367,6 +367,14 @@ __global__ void voxel_index_kernel(int64_t n, const double* __restrict__ pts, do
     fx[i] = v.fx; fy[i] = v.fy; fz[i] = v.fz;
 }
 
+// the embedding's sin (forward: ens_sinf) and cos (backward: ens_cosf), exactly as the render kernels evaluate them
+__global__ void sincos_kernel(int64_t n, const float* __restrict__ x, float* __restrict__ s, float* __restrict__ c) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (s != nullptr) s[i] = ens_sinf(x[i]);
+    if (c != nullptr) c[i] = ens_cosf(x[i]);
+}
+
 // ------------------------------------------------------------------ [32][V] <-> [V][32]
 // 64 voxels per block through a padded LDS tile; both sides move 256-byte rows.
 ENS_DEV void to_vm_block(const float* __restrict__ src, float* __restrict__ dst, int64_t V, int64_t blk);
@@ -597,16 +605,19 @@ __global__ __launch_bounds__(256) void pack_kernel(PackJob job, float* __restric
 // convert the touched blocks to voxel-major, clear the gradient accumulators.  After the backward: transposed-back
 // grid gradients and unpacked decoder gradients.
 __global__ __launch_bounds__(256) void step_kernel(PackJob pj, int unpack, ConvJob cj, int to_vm, ConvJob zj,
-                                                   float* __restrict__ flat, int64_t n_flat, int nb_pack, int nb_conv,
+                                                   float* __restrict__ flat, int64_t n_flat, int nb_ray, int nb_pack, int nb_conv,
                                                    int nb_zero, RayGradArgs rg) {
+    // Workgroups are dispatched in blockIdx order: the ray-gradient units (latency-bound: float64 geometry, a dependent
+    // corner re-gather, a coordinate-gradient reduction; 16 us as a launch of its own) come FIRST so that they run under
+    // the bandwidth-bound roles (zero-fill / transposed-back gradients) instead of behind them.
     const int b = blockIdx.x;
-    if (b < nb_pack) pack_body(pj, nullptr, unpack, b >> 2, b & 3, 4);
-    else if (b < nb_pack + nb_conv) convert_body(cj, to_vm, b - nb_pack);
-    else if (b < nb_pack + nb_conv + nb_zero) zero_body(zj, flat, n_flat, b - nb_pack - nb_conv);
-    else {                                  // ray gradients: one wave per (tile, decoder slot), four per workgroup
-        const int64_t unit = (int64_t)(b - nb_pack - nb_conv - nb_zero) * 4 + (threadIdx.x >> 6);
+    if (b < nb_ray) {                       // ray gradients: one wave per (tile, decoder slot), four per workgroup
+        const int64_t unit = (int64_t)b * 4 + (threadIdx.x >> 6);
         if (unit < (int64_t)rg.n_rays * rg.ntl * rg.n_slots) ray_grad_unit(rg, unit, (int)(threadIdx.x & 63));
     }
+    else if (b < nb_ray + nb_pack) pack_body(pj, nullptr, unpack, (b - nb_ray) >> 2, (b - nb_ray) & 3, 4);
+    else if (b < nb_ray + nb_pack + nb_conv) convert_body(cj, to_vm, b - nb_ray - nb_pack);
+    else zero_body(zj, flat, n_flat, b - nb_ray - nb_pack - nb_conv);
 }
 
 }  // namespace
@@ -641,8 +652,9 @@ int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_v
     const int64_t nb = (int64_t)nb_pack + nb_conv + nb_zero + nb_ray;
     if (nb <= 0) return 0;
     if (nb > 0x7fffffff) return -1;
+    if (nb_ray > 0x7fffffff) return -1;
     step_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(pj, unpack ? 1 : 0, cj, to_vm ? 1 : 0, zj, flat, flat ? n_flat : 0,
-                                                          nb_pack, nb_conv, (int)nb_zero, r);
+                                                          (int)nb_ray, nb_pack, nb_conv, (int)nb_zero, r);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -785,6 +797,12 @@ int ens_launch_ray_points(int n_rays, int S, const float* ro, const float* rd, c
     if (n <= 0) return 0;
     ray_points_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n_rays, S, ro, rd, z, b[0], b[1], b[2],
                                                                                 b[3], b[4], b[5], pts, mask);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ens_launch_sincos(int64_t n, const float* x, float* s, float* c, hipStream_t st) {
+    if (n <= 0) return 0;
+    sincos_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, x, s, c);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -892,6 +892,15 @@ def voxel_index(points, bound, shape):
     return outs
 
 
+def fourier_sincos(x):
+    """Parity helper: (sin, cos) float32 of float32 arguments as the embedding kernels evaluate them."""
+    _require_hip(x, "x")
+    xx = x.detach().contiguous().float().reshape(-1)
+    s, c = torch.empty_like(xx), torch.empty_like(xx)
+    L.check(L.lib().enslam_fourier_sincos(xx.numel(), _ptr(xx), _ptr(s), _ptr(c), _stream()), "enslam_fourier_sincos")
+    return s.reshape(x.shape), c.reshape(x.shape)
+
+
 def ray_points(rays_o, rays_d, z_vals, bound):
     """Parity helper: float64 sample points [N*S,3] and the strict in-bound mask."""
     lib = L.lib()

@@ -341,6 +341,10 @@ int enslam_voxel_index(int64_t n_points, const double *points, const double *bou
 int enslam_ray_points(int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                       const double *z_vals, const double *bound_host, double *points, uint8_t *mask, void *stream);
 
+/* Parity helper: the device sin / cos the Fourier embedding and its backward use (decoder.py:26-30: torch.sin of
+ * p @ B in float32) on n float32 arguments; either output may be NULL. */
+int enslam_fourier_sincos(int64_t n, const float *x, float *sin_out, float *cos_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

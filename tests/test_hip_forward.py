@@ -125,3 +125,28 @@ def test_room0_coarse200_config0():
     ok, err, mag = _close(var.cpu().numpy(), g["var"])
     assert ok, (err, mag)
     assert float(color.abs().max()) == 0.0
+
+
+def test_fourier_embedding_large_arguments():
+    """The embedding's own sin / cos (float32 Cody-Waite reduction + minimax polynomials, csrc/common.hpp) against
+    float64 libm on the argument range of p @ B (B ~ 25 * randn, |p| up to ~10: a few thousand), at quadrant
+    boundaries and on huge / tiny / special arguments.  Bar: 2e-7 absolute (the outputs' 1e-4 budget is spent on the
+    float32 rounding of the argument itself, 1.2e-4 at |x| = 2000)."""
+    import evennicer_slam_amd.functional as EF
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([
+        (torch.rand(200000, generator=g) - 0.5) * 8000.0,                           # |x| <= 4000
+        torch.randn(50000, generator=g) * 25.0 * 3.0,                               # typical p @ B
+        torch.arange(-2600, 2600, dtype=torch.float64).mul(np.pi / 4).float(),      # every multiple of pi/4 to |x| ~ 2000
+        torch.arange(-2600, 2600, dtype=torch.float64).mul(np.pi / 4).float() * (1 + 6e-8),
+        torch.tensor([0.0, -0.0, 1e-30, -1e-30, 1e-8, 0.5, -0.5, 2000.0, -2000.0, 1999.9999, 4000.0, 3e4, -3e4]),
+    ]).cuda()
+    s, c = EF.fourier_sincos(x)
+    xd = x.double().cpu()
+    es = (s.double().cpu() - torch.sin(xd)).abs()
+    ec = (c.double().cpu() - torch.cos(xd)).abs()
+    assert float(es.max()) < 2e-7, float(es.max())
+    assert float(ec.max()) < 2e-7, float(ec.max())
+    assert float(s[x == 0].abs().max()) == 0.0 and float((c[x == 0] - 1).abs().max()) == 0.0
+    # the pair is consistent: sin^2 + cos^2 = 1 to float32 rounding
+    assert float((s.double() ** 2 + c.double() ** 2 - 1).abs().max()) < 5e-7
