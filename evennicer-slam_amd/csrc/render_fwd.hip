@@ -437,6 +437,21 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
     FST(sx, 6)      // output layer (weights from global)
 }
 
+// In the colour stage the launch is split into two ROLES of workgroups: the occupancy decoders (middle + fine, 588 MFMAs
+// per tile) and the colour decoder (254) run in different workgroups on the same 4 tiles.  The three workgroups a CU
+// holds then differ in length and drift out of phase, so one workgroup's VALU-bound stretches (embedding sin, gathers,
+// workspace stores) run under another's MFMA stretches instead of all three hitting the same unit at the same time; the
+// two roles write disjoint bytes of raw (w | x,y,z).  role = bit 3 of blockIdx (blocks are dealt round-robin over the 8
+// XCDs: a role chosen by blockIdx & 1 would load the XCDs 2.3 : 1).
+// (Measured, round 2, same box: split 109 us vs 87 us unsplit.  The de-phasing itself raised the per-workgroup rate by ~11 %,
+// but 1500 workgroups on 768 resident slots run in two staggered rounds whose tail costs more.  Kept behind
+// -DENS_EXP_FWD_SPLIT for A/B runs; the shipped kernel runs all three decoders of a tile group in one workgroup.)
+#ifdef ENS_EXP_FWD_SPLIT
+constexpr bool fwd_split_roles(int stage) { return stage == 3; }
+#else
+constexpr bool fwd_split_roles(int) { return false; }
+#endif
+
 template <int STAGE>
 __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles, int tiles_per_ray,
                                                                  const float* __restrict__ rays_o,
@@ -444,6 +459,10 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
                                                                  const double* __restrict__ z_vals, DevScene sc,
                                                                  float* __restrict__ raw_out, float* __restrict__ act_ws, int wli) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
+    constexpr bool SPLIT = fwd_split_roles(STAGE);
+    const int role = SPLIT ? (int)((blockIdx.x >> 3) & 1) : 0;               // 0: occupancy decoders, 1: colour decoder
+    const int64_t grp = SPLIT ? (int64_t)(blockIdx.x >> 4) * 8 + (blockIdx.x & 7) : (int64_t)blockIdx.x;
+    if (grp * 4 >= n_tiles) return;                                            // (whole workgroup: padding of the split grid)
     const bool wl = wli != 0;
     const int WSS = wl ? ACTL_STRIDE : ACT_STRIDE, WSV = wl ? ACTL_VOX : ACT_VOX;
     StampCtx sx;
@@ -452,13 +471,14 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     float* ring = fsm;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
     float* stage = fsm + 2 * RB + wave * 256;
-    const int64_t tile_raw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t tile_raw = grp * 4 + wave;
     const bool tvalid = tile_raw < n_tiles;
     const int64_t tile = tvalid ? tile_raw : n_tiles - 1;
     const int64_t ray = tile / tiles_per_ray;
     const int64_t sidx = tile * 16 + p;
 
-    ring_load(ring, sc.packed[1] + XyzLay{32}.oW(0), (XyzLay{32}.oW(1) - XyzLay{32}.oW(0)) / 4, wave, lane);   // chunk 0
+    if (role == 0) ring_load(ring, sc.packed[1] + XyzLay{32}.oW(0), (XyzLay{32}.oW(1) - XyzLay{32}.oW(0)) / 4, wave, lane);   // chunk 0
+    else ring_load(ring, sc.packed[3] + XyzLay{32}.oW(0), (XyzLay{32}.oW(1) - XyzLay{32}.oW(0)) / 4, wave, lane);
 
     double pw[3];
     {
@@ -479,47 +499,63 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     float* wsb = (act_ws != nullptr && tvalid) ? act_ws + (tile * ACT_SLOTS) * (int64_t)WSS : nullptr;
     f32x4 occ = splat4(0.f), col = splat4(0.f);
 
-    f32x4 cm[2];
-    {
-        const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[1]);
-        gather8(v, sc.grid[1], q, cm[0], cm[1]);
-        if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + WSV + p * 4) = vox_record(v, sc.grid[1]);
-    }
-    FST(sx, 0)      // geometry + first gather
-    __syncthreads();                                                                   // chunk 0 landed
-    FST(sx, 5)
-    mlp_xyz_ring<2, 0, RB, (STAGE >= 2 ? 64 : 0)>(sc.packed[1], STAGE >= 2 ? sc.packed[2] : nullptr, ring, pc, cm, occ, wsb,
-                                                   wl, stage, w32, w96, w128, w32, wq, wave, lane, p, q, sx);
-    if constexpr (STAGE >= 2) {
-        f32x4 cf[4];
+    if (role == 0) {
+        f32x4 cm[2];
         {
-            const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[2]);
-            gather8(v, sc.grid[2], q, cf[0], cf[1]);
-            if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + WSS + WSV + p * 4) = vox_record(v, sc.grid[2]);
+            const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[1]);
+            gather8(v, sc.grid[1], q, cm[0], cm[1]);
+            if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + WSV + p * 4) = vox_record(v, sc.grid[1]);
         }
-        cf[2] = cm[0];
-        cf[3] = cm[1];
-        FST(sx, 7)  // later gathers
-        f32x4 of;
-        mlp_xyz_ring<4, 5, RB, (STAGE == 3 ? 32 : 0)>(sc.packed[2], STAGE == 3 ? sc.packed[3] : nullptr, ring, pc, cf, of,
-                                                      wsb ? wsb + WSS : nullptr, wl, stage, w32, w96, w128, w64, wq, wave,
-                                                      lane, p, q, sx);
-        occ[0] = of[0] + occ[0];                                                        // fine_occ + middle_occ
+        FST(sx, 0)      // geometry + first gather
+        __syncthreads();                                                                   // chunk 0 landed
+        FST(sx, 5)
+        mlp_xyz_ring<2, 0, RB, (STAGE >= 2 ? 64 : 0)>(sc.packed[1], STAGE >= 2 ? sc.packed[2] : nullptr, ring, pc, cm, occ, wsb,
+                                                       wl, stage, w32, w96, w128, w32, wq, wave, lane, p, q, sx);
+        if constexpr (STAGE >= 2) {
+            f32x4 cf[4];
+            {
+                const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[2]);
+                gather8(v, sc.grid[2], q, cf[0], cf[1]);
+                if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + WSS + WSV + p * 4) = vox_record(v, sc.grid[2]);
+            }
+            cf[2] = cm[0];
+            cf[3] = cm[1];
+            FST(sx, 7)  // later gathers
+            f32x4 of;
+            mlp_xyz_ring<4, 5, RB, ((STAGE == 3 && !SPLIT) ? 32 : 0)>(sc.packed[2], (STAGE == 3 && !SPLIT) ? sc.packed[3] : nullptr,
+                                                                     ring, pc, cf, of, wsb ? wsb + WSS : nullptr, wl, stage, w32,
+                                                                     w96, w128, w64, wq, wave, lane, p, q, sx);
+            occ[0] = of[0] + occ[0];                                                        // fine_occ + middle_occ
+        }
     }
     if constexpr (STAGE == 3) {
-        f32x4 cc[2];
-        {
-            const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[3]);
-            gather8(v, sc.grid[3], q, cc[0], cc[1]);
-            if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + 2 * WSS + WSV + p * 4) = vox_record(v, sc.grid[3]);
+        if (role == 1 || !SPLIT) {
+            f32x4 cc[2];
+            {
+                const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[3]);
+                gather8(v, sc.grid[3], q, cc[0], cc[1]);
+                if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + 2 * WSS + WSV + p * 4) = vox_record(v, sc.grid[3]);
+            }
+            FST(sx, 7)
+            if (SPLIT) {
+                __syncthreads();                                                           // chunk 0 (colour layer 0) landed
+                FST(sx, 5)
+            }
+            mlp_xyz_ring<2, 10, RB, 0>(sc.packed[3], nullptr, ring, pc, cc, col, wsb ? wsb + 2 * WSS : nullptr, wl, stage,
+                                       w32, w96, w128, w32, wq, wave, lane, p, q, sx);
         }
-        FST(sx, 7)
-        mlp_xyz_ring<2, 10, RB, 0>(sc.packed[3], nullptr, ring, pc, cc, col, wsb ? wsb + 2 * WSS : nullptr, wl, stage,
-                                   w32, w96, w128, w32, wq, wave, lane, p, q, sx);
     }
     if (q == 0 && tvalid) {                                                             // rows 0..3 live on q == 0 lanes
         const float o = inb ? occ[0] : 100.f;                                           // Renderer.py:58
-        *reinterpret_cast<f32x4*>(raw_out + sidx * 4) = f32x4{col[0], col[1], col[2], o};
+        if (!SPLIT) {
+            *reinterpret_cast<f32x4*>(raw_out + sidx * 4) = f32x4{col[0], col[1], col[2], o};
+        } else if (role == 0) {
+            raw_out[sidx * 4 + 3] = o;
+        } else {
+            raw_out[sidx * 4 + 0] = col[0];
+            raw_out[sidx * 4 + 1] = col[1];
+            raw_out[sidx * 4 + 2] = col[2];
+        }
     }
     FST(sx, 8)
     FST_FLUSH(sx, blockIdx.x, wave, lane)
@@ -679,7 +715,9 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
                 return -2;
             attr_set = true;
         }
-        const dim3 grid((unsigned)((n_units + 3) / 4)), block(256);
+        const int64_t groups = (n_units + 3) / 4;
+        // colour stage: two roles per group of 4 tiles, interleaved in runs of 8 blocks (render_fwd_ring_kernel)
+        const dim3 grid((unsigned)(fwd_split_roles(stage) ? ((groups + 7) / 8) * 16 : groups)), block(256);
         if (stage == 1) render_fwd_ring_kernel<1><<<grid, block, fwd_ring_lds_bytes(1), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
         else if (stage == 2) render_fwd_ring_kernel<2><<<grid, block, fwd_ring_lds_bytes(2), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
         else render_fwd_ring_kernel<3><<<grid, block, fwd_ring_lds_bytes(3), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);

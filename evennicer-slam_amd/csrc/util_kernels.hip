@@ -398,6 +398,15 @@ ENS_DEV void convert_body(const ConvJob& job, int to_vm, int b) {
         if (!needed) {                                       // untouched block of a gradient: zeros, nothing read
             const int64_t v0 = blk * 64, V = job.V[g];
             float* dst = job.dst[g];
+            if ((V & 3) == 0 && v0 + 64 <= V && ((uintptr_t)dst & 15) == 0) {
+                // 16 bytes per lane: a wave instruction clears four 256-byte row segments (two instructions per wave
+                // and block instead of eight)
+                const int row = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+#pragma unroll
+                for (int cc = row; cc < 32; cc += 16)
+                    *reinterpret_cast<f32x4*>(dst + (int64_t)cc * V + v0 + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                return;
+            }
             const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
             for (int cc = ty; cc < 32; cc += 4)
