@@ -108,6 +108,11 @@ bool stage_ok(int stage, const DevScene& d) {
 
 extern "C" {
 
+// samples per ray the render kernels take: whole 16-sample tiles, at most 64 (one wave composites a ray).  64 = the padded
+// second pass of hierarchical sampling (N_samples + N_importance + N_surface = 56 in the reference's iMAP-style configs),
+// served by the tile-per-wave forward only (ENSLAM_EUNSUPPORTED from the launcher beyond its ray limit).
+static bool samples_ok(int32_t n) { return n == 16 || n == 32 || n == 48 || n == 64; }
+
 int enslam_abi_version(void) { return ENSLAM_ABI_VERSION; }
 const char* enslam_arch(void) { return "gfx950"; }
 
@@ -278,7 +283,7 @@ int enslam_step_finish_rays(int32_t n_conv, const float* const* src, float* cons
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0 || stage == ENSLAM_STAGE_COARSE)
         return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, nullptr, stream);
-    if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
+    if (!samples_ok(n_samples)) return ENSLAM_EUNSUPPORTED;
     DevScene d;
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
     if (!rays_o || !rays_d || !z_vals || !dgrid_ws || !g_rays_o || !g_rays_d) return ENSLAM_EINVAL;
@@ -496,7 +501,7 @@ int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const fl
                       float* raw_out, float* act_ws, int32_t act_light, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
-    if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
+    if (!samples_ok(n_samples)) return ENSLAM_EUNSUPPORTED;
     DevScene d;
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
     if (!rays_o || !rays_d || !z_vals || !depth || !var || !rgb) return ENSLAM_EINVAL;
@@ -514,7 +519,7 @@ int enslam_render_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, con
                            void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
-    if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
+    if (!samples_ok(n_samples)) return ENSLAM_EUNSUPPORTED;
     DevScene d;
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
     if (!rays_o || !rays_d || !z_vals || !depth || !var || !rgb || !raw_out || !gt_depth || !loss) return ENSLAM_EINVAL;
@@ -607,7 +612,7 @@ int enslam_decoder_bwd_scaled(int32_t stage, int32_t n_rays, int32_t n_samples, 
                               const int32_t* work_count, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
-    if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
+    if (!samples_ok(n_samples)) return ENSLAM_EUNSUPPORTED;
     DevScene d;
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
     if (!rays_o || !rays_d || !z_vals || !d_raw || !grad_grids || !grad_packed) return ENSLAM_EINVAL;
@@ -633,7 +638,7 @@ int enslam_ray_grad_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const 
                         float* g_rays_d, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0 || stage == ENSLAM_STAGE_COARSE) return ENSLAM_OK;
-    if (n_samples != 16 && n_samples != 32 && n_samples != 48) return ENSLAM_EUNSUPPORTED;
+    if (!samples_ok(n_samples)) return ENSLAM_EUNSUPPORTED;
     DevScene d;
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
     if (!rays_o || !rays_d || !z_vals || !dgrid_ws || !g_rays_o || !g_rays_d) return ENSLAM_EINVAL;

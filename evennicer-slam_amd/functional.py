@@ -531,6 +531,11 @@ class RenderPlan:
         self.vm = {}                            # kind -> VoxelMajorGrid for grids passed in the device layout
         self.loss = None                        # (gt_depth [N] f32, gt_color [N,3] f32 | None, w_color): fused mapper loss
         self.state = _default_state             # the calling Renderer's RenderState
+        # hierarchical sampling's second pass (Renderer.py:182-197): sample distances given by the caller instead of the
+        # sampler -- float64 [N, S] with S a multiple of 16 (<= 64), of which the first s_valid per ray are real samples
+        # (the rest pad the last tile: evaluated, but left out of the compositing and given zero gradient)
+        self.z_given = None
+        self.s_valid = None
 
 
 class _Accumulators:
@@ -592,7 +597,16 @@ class _RenderFn(torch.autograd.Function):
         ro = rays_o.detach().contiguous().float()
         rd = rays_d.detach().contiguous().float()
         gd = gt_depth.detach().contiguous().float().reshape(-1) if gt_depth is not None else None
-        z = torch.empty((N, S), dtype=torch.float64, device=dev)
+        SV = None                                   # real samples per ray when the last tile is padded
+        if plan.z_given is not None:
+            z = plan.z_given.detach().to(torch.float64).contiguous()
+            S = int(z.shape[1])
+            if tuple(z.shape) != (N, S) or S % 16 != 0 or S > 64 or plan.loss is not None:
+                raise L.EnslamError(f"given sample distances must be float64 [N, 16k <= 64] without a fused loss, got {tuple(z.shape)}")
+            if plan.s_valid is not None and plan.s_valid < S:
+                SV = int(plan.s_valid)
+        else:
+            z = torch.empty((N, S), dtype=torch.float64, device=dev)
         scratch = plan.depth_max if plan.depth_max is not None else torch.empty(2, dtype=torch.float32, device=dev)
         # blocks of 64 voxels this batch touches, per grid (one zeroed byte buffer for all grids).  Grids that
         # arrive in the device layout (plan.vm) need none of this.
@@ -620,11 +634,15 @@ class _RenderFn(torch.autograd.Function):
                 fptr[k] = fl.data_ptr()
                 msc.grids[k].D, msc.grids[k].H, msc.grids[k].W = dims[k]
                 state.flags[id(grids[i])] = fl
-        L.check(lib.enslam_sample_rays(N, plan.n_lin, plan.n_surf, _ptr(ro), _ptr(rd), _ptr(gd), plan.bound6,
-                                       _ptr(plan.t_lin), _ptr(plan.t_surf), plan.lindisp, _ptr(t_rand),
-                                       _ptr(scratch), int(plan.depth_max is not None), _ptr(z), L.STAGE[plan.stage],
-                                       ctypes.byref(msc) if msc is not None else None, fptr, st),
-                "enslam_sample_rays")
+        if plan.z_given is None:
+            L.check(lib.enslam_sample_rays(N, plan.n_lin, plan.n_surf, _ptr(ro), _ptr(rd), _ptr(gd), plan.bound6,
+                                           _ptr(plan.t_lin), _ptr(plan.t_surf), plan.lindisp, _ptr(t_rand),
+                                           _ptr(scratch), int(plan.depth_max is not None), _ptr(z), L.STAGE[plan.stage],
+                                           ctypes.byref(msc) if msc is not None else None, fptr, st),
+                    "enslam_sample_rays")
+        elif msc is not None:                       # the samples are given: block marking as a launch of its own
+            L.check(lib.enslam_mark_blocks(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(msc), fptr, st),
+                    "enslam_mark_blocks")
         if static:
             for (i, k), vm in zip(static, _grid_cache.get_many([grids[i] for i, _ in static])):
                 grids_vm[k] = vm
@@ -671,7 +689,7 @@ class _RenderFn(torch.autograd.Function):
         # work list of the backward (tiles with non-zero d_raw): filled by whichever kernel produces d_raw; the counter
         # comes zeroed out of this call's arena
         work = wcount = None
-        if act is not None and USE_WORK_LIST and any(ctx.needs_input_grad):
+        if act is not None and USE_WORK_LIST and any(ctx.needs_input_grad) and SV is None:
             work = torch.empty(N * (S // 16), dtype=torch.int32, device=dev)
             wcount = arena.take(1, torch.int32)
         if plan.loss is None:
@@ -689,6 +707,14 @@ class _RenderFn(torch.autograd.Function):
                                                _ptr(work) if d_raw_unit is not None else None,
                                                _ptr(wcount) if d_raw_unit is not None else None, st),
                     "enslam_render_loss_fwd")
+        ctx.sv = None
+        if SV is not None:
+            # compositing over the real samples only (the kernels above composited the padded rays): contiguous [N, SV] views
+            raw_v = raw.view(N, S, 4)[:, :SV].contiguous()
+            z_v = z[:, :SV].contiguous()
+            L.check(lib.enslam_composite_fwd(N, SV, _ptr(raw_v), _ptr(z_v), _ptr(depth), _ptr(var), _ptr(rgb), None, st),
+                    "enslam_composite_fwd")
+            ctx.sv = (SV, raw_v, z_v)
         ctx.plan, ctx.S, ctx.dims, ctx.act_light, ctx.accum = plan, S, dims, act_light, accum
         ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act, flags)
         ctx.rgb = rgb if plan.loss is not None else None
@@ -775,6 +801,14 @@ class _RenderFn(torch.autograd.Function):
             L.check(lib.enslam_composite_loss_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(ctx.rgb), _ptr(lgd), _ptr(lgc),
                                                   ctypes.c_float(lw), _ptr(gL), _ptr(d_raw), _ptr(work), _ptr(wcount), st),
                     "enslam_composite_loss_bwd")
+        elif ctx.sv is not None:                            # padded last tile: gradient of the real samples, zeros for the pad
+            SV, raw_v, z_v = ctx.sv
+            d_raw_v = torch.empty((N, SV, 4), dtype=torch.float32, device=dev)
+            L.check(lib.enslam_composite_bwd(N, SV, _ptr(raw_v), _ptr(z_v), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
+                                             _ptr(d_raw_v), st), "enslam_composite_bwd")
+            d_raw = torch.zeros((N, S, 4), dtype=torch.float32, device=dev)
+            d_raw[:, :SV] = d_raw_v
+            d_raw = d_raw.view(N * S, 4)
         else:
             d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
             L.check(lib.enslam_composite_bwd_list(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),

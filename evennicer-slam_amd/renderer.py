@@ -77,10 +77,11 @@ class Renderer(object):
             return loss, depth.detach(), var.detach(), color.detach()
         return self._render(c, decoders, rays_d, rays_o, device, stage, gt_depth, (gd, gc, float(w_color)))
 
-    def _render(self, c, decoders, rays_d, rays_o, device, stage, gt_depth, loss):
-        if self.N_importance > 0:
-            raise NotImplementedError("hierarchical sampling (N_importance > 0) is not exercised by the NICE "
-                                      "configuration and is not built on the HIP path")
+    def _render(self, c, decoders, rays_d, rays_o, device, stage, gt_depth, loss, z_given=None, s_valid=None):
+        if self.N_importance > 0 and z_given is None:
+            if loss is not None:
+                raise NotImplementedError("render_batch_ray_rgbd_loss with N_importance > 0: use render_batch_ray + losses.rgbd_loss")
+            return self._render_hierarchical(c, decoders, rays_d, rays_o, device, stage, gt_depth)
         if stage not in L.STAGE:
             raise ValueError(f"unknown stage {stage!r}")
         EF._require_hip(rays_o, "rays")
@@ -94,17 +95,18 @@ class Renderer(object):
                                    "torch.max over an empty tensor raises here too)")
         n_lin, n_surf = self.N_samples, (self.N_surface if gt_depth is not None else 0)
         S = n_lin + n_surf
-        if S not in (16, 32, 48):
-            raise NotImplementedError(f"N_samples + N_surface = {S}: kernels are built for 16, 32 or 48 samples")
+        if z_given is None and S not in (16, 32, 48, 64):
+            raise NotImplementedError(f"N_samples + N_surface = {S}: kernels are built for 16, 32, 48 or 64 samples")
         dev = rays_o.device
         t_lin, t_surf = self._t_vals(dev, n_lin, self.N_surface)
-        t_rand = torch.rand((N, n_lin), device=dev) if self.perturb > 0. else None
+        t_rand = torch.rand((N, n_lin), device=dev) if (self.perturb > 0. and z_given is None) else None
         kinds = EF.stage_kinds(stage)
         decs = {k: getattr(decoders, L.MLP_NAMES[k]) for k in kinds}
         plan = EF.RenderPlan(stage, self.bound, self._coarse_bound(decoders), n_lin, n_surf, self.lindisp, t_lin,
                              t_surf, kinds, decs, depth_max=self.depth_max_override if gt_depth is not None else None)
         plan.loss = loss
         plan.state = self.state
+        plan.z_given, plan.s_valid = z_given, s_valid
         grids = []
         for k in kinds:
             g = c[L.GRID_NAMES[k]]
@@ -119,6 +121,52 @@ class Renderer(object):
             z = rays_o.new_zeros((0,))
             return z.double(), z.double(), rays_o.new_zeros((0, 3))
         return EF.render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params)
+
+    HIERARCHICAL_MAX_RAYS = 32768        # 64-sample rays run on the tile-per-wave forward (its ray limit)
+
+    def _render_hierarchical(self, c, decoders, rays_d, rays_o, device, stage, gt_depth):
+        """`render_batch_ray` with N_importance > 0 (Renderer.py:182-197): a first pass over the N_samples + N_surface
+        distances gives the weights, `sample_pdf` (common.py:19-63, torch ops, deterministic when perturb == 0) draws
+        N_importance more distances from them, and the sorted union is rendered.  The reference detaches the new distances
+        and returns only the second pass's outputs, so no gradient flows through the first pass: it runs forward-only
+        (sampler, `eval_points`, compositing kernels); the second pass is the differentiable HIP render on GIVEN distances,
+        its last 16-sample tile padded (the pad is evaluated but neither composited nor given gradient)."""
+        from .common import sample_pdf
+        if stage == 'coarse':
+            gt_depth = None
+        N = rays_o.shape[0]
+        if N == 0:
+            z = rays_o.new_zeros((0,))
+            return z.double(), z.double(), rays_o.new_zeros((0, 3))
+        if N > self.HIERARCHICAL_MAX_RAYS:
+            if gt_depth is not None:
+                raise NotImplementedError("hierarchical sampling of more than 32768 depth-guided rays in one call: the sampler's "
+                                          "batch maxima (Renderer.py:110,145) span the call; split the batch in the caller")
+            outs = [self._render_hierarchical(c, decoders, rays_d[i:i + self.HIERARCHICAL_MAX_RAYS],
+                                              rays_o[i:i + self.HIERARCHICAL_MAX_RAYS], device, stage, None)
+                    for i in range(0, N, self.HIERARCHICAL_MAX_RAYS)]
+            return tuple(torch.cat(t, 0) for t in zip(*outs))
+        dev = rays_o.device
+        n_surf = self.N_surface if gt_depth is not None else 0
+        gd = gt_depth.reshape(-1) if gt_depth is not None else None
+        with torch.no_grad():
+            t_rand = torch.rand((N, self.N_samples), device=dev) if self.perturb > 0. else None
+            z1 = EF.sample_rays(rays_o, rays_d, gd, self.bound, self.N_samples, n_surf, self.lindisp, t_rand,
+                                depth_max=self.depth_max_override if gd is not None else None)
+            pts, _ = EF.ray_points(rays_o.detach(), rays_d.detach(), z1, self.bound)
+            raw1 = EF.eval_points(pts, decoders, c, stage, self.bound, apply_mask=True, coarse_bound=self._coarse_bound(decoders))
+            _, _, _, weights = EF.composite(raw1.view(N, z1.shape[1], 4), z1)
+            z_mid = .5 * (z1[..., 1:] + z1[..., :-1])
+            z_samples = sample_pdf(z_mid, weights[..., 1:-1], self.N_importance, det=(self.perturb == 0.), device=dev)
+            z2, _ = torch.sort(torch.cat([z1, z_samples.to(z1.dtype)], -1), -1)
+            S2 = z2.shape[1]
+            S_pad = -(-S2 // 16) * 16
+            if S_pad > 64:
+                raise NotImplementedError(f"N_samples + N_importance + N_surface = {S2}: at most 64 samples per ray")
+            if S_pad > S2:
+                z2 = torch.cat([z2, z2[:, -1:].expand(N, S_pad - S2)], -1)
+            z2 = z2.contiguous()
+        return self._render(c, decoders, rays_d, rays_o, device, stage, gt_depth, None, z_given=z2, s_valid=S2)
 
     def _render_chunks(self, c, decoders, rays_o, rays_d, device, stage, gt_depth):
         depth_l, var_l, col_l = [], [], []

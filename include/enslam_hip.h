@@ -223,7 +223,8 @@ int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const floa
 
 /* Forward of Renderer.render_batch_ray lines 173-181 + eval_points (Renderer.py:24-62) +
  * NICE.forward (decoder.py:312-342) + raw2outputs_nerf_color (common.py:256-297, occupancy):
- * points, bound mask, trilinear gather, decoders, alpha compositing.  S must be 16, 32 or 48.
+ * points, bound mask, trilinear gather, decoders, alpha compositing.  S must be 16, 32, 48 or 64 (64: tile-per-wave
+ * forward only, i.e. up to 32768 rays per call; ENSLAM_EUNSUPPORTED beyond).
  * raw_out (may be NULL) receives the per-sample (r,g,b,occ) needed by enslam_render_bwd. */
 int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                       const double *z_vals, const enslam_scene *scene, double *depth, double *var, float *rgb,

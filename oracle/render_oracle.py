@@ -24,7 +24,8 @@ Reference functions restated (file:line in /root/reference):
                          <- src/conv_onet/models/decoder.py:177-203,262-274,312-342
   eval_points            <- src/utils/Renderer.py:24-62
   composite              <- src/common.py:256-297 (occupancy branch)
-  render_batch_ray       <- src/utils/Renderer.py:64-199
+  render_batch_ray       <- src/utils/Renderer.py:64-199 (incl. the N_importance second pass, :182-197)
+  inverse_cdf_samples    <- src/common.py:19-63 (sample_pdf)
 """
 import numpy as np
 import torch
@@ -270,14 +271,42 @@ def composite(raw, z):
     return depth, var, rgb, w
 
 
+def inverse_cdf_samples(bins, weights, n, det=True):
+    """src/common.py:19-63 (sample_pdf): n samples per ray from the piecewise-constant density `weights` [B, M-1] over the
+    bin edges `bins` [B, M] by inverting its CDF; det: evenly spaced quantiles, else one torch.rand draw (CPU generator)."""
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    shape = list(cdf.shape[:-1]) + [n]
+    u = torch.linspace(0., 1., steps=n).expand(shape) if det else torch.rand(shape)
+    u = u.contiguous()
+    above = torch.searchsorted(cdf, u, right=True)
+    below = torch.clamp(above - 1, min=0)
+    above = torch.clamp(above, max=cdf.shape[-1] - 1)
+    c_lo, c_hi = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
+    b_lo, b_hi = torch.gather(bins, -1, below), torch.gather(bins, -1, above)
+    span = c_hi - c_lo
+    span = torch.where(span < 1e-5, torch.ones_like(span), span)
+    return b_lo + ((u - c_lo) / span) * (b_hi - b_lo)
+
+
 def render_batch_ray(params, grids, rays_d, rays_o, stage, bound, gt_depth=None,
                      n_samples=32, n_surface=16, coarse_enlarge=2, lindisp=False, t_rand=None,
-                     return_aux=False):
-    """(depth f64 [N], var f64 [N], rgb f32 [N,3]).  Argument order rays_d, rays_o as the reference."""
+                     return_aux=False, n_importance=0, det=True):
+    """(depth f64 [N], var f64 [N], rgb f32 [N,3]).  Argument order rays_d, rays_o as the reference.
+    n_importance > 0: Renderer.py:182-197 -- inverse-CDF samples of the first pass's weights (detached), merged with the
+    first pass's distances and rendered again; only that second pass is returned."""
     z = sample_depths(rays_o, rays_d, gt_depth, bound, n_samples, n_surface, stage, lindisp, t_rand)
     pts = (rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]).reshape(-1, 3)
     raw = eval_points(params, grids, pts, stage, bound, coarse_enlarge).reshape(z.shape[0], z.shape[1], 4)
     depth, var, rgb, w = composite(raw, z)
+    if n_importance > 0:
+        mid = .5 * (z[..., 1:] + z[..., :-1])
+        extra = inverse_cdf_samples(mid, w[..., 1:-1], n_importance, det=det).detach()
+        z = torch.sort(torch.cat([z, extra], -1), -1)[0]
+        pts = (rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]).reshape(-1, 3)
+        raw = eval_points(params, grids, pts, stage, bound, coarse_enlarge).reshape(z.shape[0], z.shape[1], 4)
+        depth, var, rgb, w = composite(raw, z)
     if return_aux:
         return depth, var, rgb, dict(z_vals=z, pts=pts, raw=raw, weights=w)
     return depth, var, rgb

@@ -177,3 +177,35 @@ def test_room0_coarse200_config0():
     for k, v in params.items():
         if "gp_" + k in g:
             assert rel_err(v.grad.numpy(), g["gp_" + k]) < 1e-5, k
+
+
+def test_oracle_hierarchical_sampling_matches_reference():
+    """N_importance = 8 (Renderer.py:182-197 + sample_pdf, common.py:19-63): the oracle's second pass against the
+    reference fixture -- merged sample distances, outputs and gradients."""
+    import torch
+    from oracle import render_oracle as R
+    from tests.util import tiny_scene
+    g = load("tiny_importance")
+    for stage in ('color', 'middle', 'coarse'):
+        params, grids, bound, s = tiny_scene()
+        params = {k: v.requires_grad_(True) for k, v in params.items()}
+        grids = {k: v.requires_grad_(True) for k, v in grids.items()}
+        ro = torch.from_numpy(s['rays_o']).requires_grad_(True)
+        rd = torch.from_numpy(s['rays_d']).requires_grad_(True)
+        gd, gc = torch.from_numpy(s['gt_depth']), torch.from_numpy(s['gt_color'])
+        depth, var, rgb, aux = R.render_batch_ray(params, grids, rd, ro, stage, bound, gt_depth=None if stage == 'coarse' else gd,
+                                                  return_aux=True, n_importance=int(g['N_importance']))
+        assert aux['z_vals'].shape == g[f'{stage}_z_vals'].shape
+        assert np.abs(aux['z_vals'].detach().numpy() - g[f'{stage}_z_vals']).max() <= 1e-9
+        for name, got in (('depth', depth), ('var', var), ('color', rgb)):
+            assert rel_err(got.detach().numpy(), g[f'{stage}_{name}']) <= 1e-6, (stage, name)
+        if stage == 'coarse':
+            loss = (depth * torch.from_numpy(g['cot_depth'])).sum() + (var * torch.from_numpy(g['cot_var'])).sum() + \
+                   (rgb * torch.from_numpy(g['cot_color'])).sum()
+        else:
+            loss = R.mapper_loss(depth, rgb, gd, gc, stage)
+        loss.backward()
+        assert abs(loss.item() - float(g[f'{stage}_loss'])) <= 1e-6 * max(1.0, abs(float(g[f'{stage}_loss'])))
+        assert rel_err(rd.grad.numpy(), g[f'{stage}_g_rays_d']) <= 1e-5
+        key = {'color': 'grid_color', 'middle': 'grid_middle', 'coarse': 'grid_coarse'}[stage]
+        assert rel_err(grids[key].grad.numpy(), g[f'{stage}_g_{key}']) <= 1e-5
