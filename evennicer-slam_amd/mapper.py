@@ -191,3 +191,154 @@ class FusedAdam:
         note_raw_write(self.params)
         L.check(L.lib().enslam_adam_tensors(n, P, G, M, V, numel, _ptr(self.lr_t), _ptr(self.step_t), self.betas[0],
                                             self.betas[1], self.eps, _stream()), "enslam_adam_tensors")
+
+
+class MapperIteration:
+    """The joint-optimisation loop of `Mapper.optimize_map` (src/Mapper.py:326-641, RGB-D part) on the device layout:
+    frustum-masked grids in `MaskedGridOptimizer`, the optimised decoders and -- with `BA` -- the camera tensors of the
+    optimised frames in `FusedAdam`s (the reference's one torch.optim.Adam with a parameter group each, :396-407).
+
+      frames  list of dicts, in the reference's `optimize_frame` order (selected keyframes ..., current frame last):
+              {'depth': [H,W], 'color': [H,W,3], 'c2w': [3|4,4] estimated pose, 'fixed': bool}; with BA every frame
+              that is not `fixed` (the reference fixes the oldest keyframe, :376-377) gets a camera tensor
+              (`camera_tensors[i]`: given, or `common.get_tensor_from_camera(c2w)`), optimised in the colour stage
+              with `BA_cam_lr` (:486-490) and turned into rays by the fused pose -> ray launch of `tracker.py`
+      keys    grids this mapper optimises ((`grid_coarse`,) for the coarse mapper, :326-328)
+
+    `step(joint_iter, num_joint_iters)` is one iteration (:448-602): stage and learning rates of the schedule, one
+    `get_samples` draw of `pixels // len(frames)` pixels per frame (:502-535), the in-bound prefilter (:537-547), render,
+    loss, backward, optimiser steps.  `static_shapes=True` keeps the ray count fixed (no boolean indexing, no host
+    synchronisation): rays the reference drops are rendered but carry no loss, the sampler's batch maxima are taken over
+    the kept rays -- the kept rays get exactly the samples, losses and gradients of the reference's filtered batch, and
+    the whole iteration, per-iteration pixel draw included, can be captured in one hipGraph (`graphed()`).
+    `finish()` writes the grids back (`val[mask] = val_grad`, :596-602) and returns the camera tensors."""
+
+    def __init__(self, cfg, renderer, c, decoders, frames, cam, masks=None, keys=('grid_middle', 'grid_fine', 'grid_color'),
+                 camera_tensors=None, device=None, static_shapes=False):
+        from .common import get_tensor_from_camera
+        m = cfg['mapping']
+        self.cfg, self.renderer, self.c, self.decoders = cfg, renderer, c, decoders
+        self.keys = tuple(keys)
+        self.coarse_mapper = self.keys == ('grid_coarse',)
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = (cam[k] for k in ('H', 'W', 'fx', 'fy', 'cx', 'cy'))
+        self.device = device if device is not None else c[self.keys[0]].device
+        self.w_color_loss, self.lr_factor = m['w_color_loss'], m['lr_factor']
+        self.BA, self.BA_cam_lr = bool(m.get('BA', False)) and not self.coarse_mapper, m.get('BA_cam_lr', 0.0)
+        self.middle_iter_ratio, self.fine_iter_ratio = m['middle_iter_ratio'], m['fine_iter_ratio']
+        self.fix_fine, self.fix_color = m.get('fix_fine', True), m.get('fix_color', False)
+        self.pixels = m['pixels']
+        self.static_shapes = static_shapes
+        self.frames = frames
+        self.grid_opt = MaskedGridOptimizer(c, masks, keys=self.keys)
+        dec_params = []                                                     # :363-369
+        if not self.fix_fine:
+            dec_params += list(decoders.fine_decoder.parameters())
+        if not self.fix_color:
+            dec_params += list(decoders.color_decoder.parameters())
+        self.dec_opt = FusedAdam(dec_params, lr=0.0) if dec_params else None
+        self.camera_tensors = [None] * len(frames)
+        if self.BA:                                                         # :374-390
+            for i, f in enumerate(frames):
+                if f.get('fixed', False):
+                    continue
+                t = camera_tensors[i] if camera_tensors is not None and camera_tensors[i] is not None else \
+                    get_tensor_from_camera(f['c2w'])
+                self.camera_tensors[i] = t.detach().to(self.device, torch.float32).clone().requires_grad_(True)
+        cams = [t for t in self.camera_tensors if t is not None]
+        self.cam_opt = FusedAdam(cams, lr=0.0) if cams else None
+        self._bound_dev = renderer.bound.to(self.device)
+        self._one = None
+        self.last = {}
+
+    def stage_of(self, joint_iter, num_joint_iters):                       # :460-467
+        if self.coarse_mapper:
+            return 'coarse'
+        if joint_iter <= int(num_joint_iters * self.middle_iter_ratio):
+            return 'middle'
+        if joint_iter <= int(num_joint_iters * self.fine_iter_ratio):
+            return 'fine'
+        return 'color'
+
+    def sample_batch(self):
+        """One `get_samples` draw per frame (:502-535) -> concatenated rays_o, rays_d, gt_depth, gt_color (float32)."""
+        from .common import get_samples
+        from .tracker import get_samples_from_camera_tensor
+        H, W = self.H, self.W
+        n = self.pixels // len(self.frames)
+        ro, rd, gd, gc = [], [], [], []
+        for f, ct in zip(self.frames, self.camera_tensors):
+            if ct is not None:
+                o, d, dep, col = get_samples_from_camera_tensor(0, H, 0, W, n, H, W, self.fx, self.fy, self.cx, self.cy, ct,
+                                                                f['depth'], f['color'], self.device)
+            else:
+                o, d, dep, col = get_samples(0, H, 0, W, n, H, W, self.fx, self.fy, self.cx, self.cy, f['c2w'], f['depth'],
+                                             f['color'], self.device)
+            ro.append(o.float()); rd.append(d.float()); gd.append(dep.float()); gc.append(col.float())
+        return torch.cat(ro), torch.cat(rd), torch.cat(gd), torch.cat(gc)
+
+    def step(self, joint_iter, num_joint_iters, stage=None):
+        """One joint iteration; returns the (device) loss tensor.  `stage` overrides the schedule (captured steps)."""
+        from .losses import rgbd_loss
+        stage = stage or self.stage_of(joint_iter, num_joint_iters)
+        st = self.cfg['mapping']['stage'][stage]
+        f = self.lr_factor
+        if self.dec_opt is not None:                                        # :469-490
+            self.dec_opt.set_lr(st['decoders_lr'] * f)
+            self.dec_opt.zero_grad()
+        if self.cam_opt is not None:
+            if stage == 'color':
+                self.cam_opt.set_lr(self.BA_cam_lr)
+            self.cam_opt.zero_grad()
+        ro, rd, gd, gc = self.sample_batch()
+        keep = None
+        with torch.no_grad():                                               # :537-547
+            t = (self._bound_dev.unsqueeze(0) - ro.detach().unsqueeze(-1)) / rd.detach().unsqueeze(-1)
+            t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
+            inside = t >= gd
+        r = self.renderer
+        prev = r.depth_max_override
+        if self.static_shapes:
+            keep = inside
+            if not self.coarse_mapper:
+                mx = torch.where(inside, gd, gd.new_zeros(())).max().reshape(1)
+                r.depth_max_override = torch.cat([mx, mx * 1.2]).contiguous()
+        else:
+            rd, ro, gd, gc = rd[inside], ro[inside], gd[inside], gc[inside]
+        try:
+            depth, unc, color = r.render_batch_ray(self.grid_opt.render_grids(), self.decoders, rd, ro, self.device, stage,
+                                                   gt_depth=None if self.coarse_mapper else gd)
+        finally:
+            r.depth_max_override = prev
+        use_color = stage == 'color'
+        if keep is None:
+            loss = rgbd_loss(depth, color if use_color else None, gd, gc, self.w_color_loss)          # :553-562
+        else:
+            # dropped rays: no depth term (gt_depth 0) and no colour term (target = the rendered colour itself: |0|, sign 0)
+            gd_l = torch.where(keep, gd, torch.zeros_like(gd))
+            gc_l = torch.where(keep[:, None], gc, color.detach()) if use_color else gc
+            loss = rgbd_loss(depth, color if use_color else None, gd_l, gc_l, self.w_color_loss)
+        if self._one is None:
+            self._one = torch.ones_like(loss)
+        loss.backward(gradient=self._one)                                   # :573
+        if self.dec_opt is not None:
+            self.dec_opt.step()                                             # :575 (one optimizer.step() in the reference)
+        if self.cam_opt is not None:
+            self.cam_opt.step()
+        self.grid_opt.step({k: st[k[5:] + '_lr'] * f for k in self.keys})
+        self.last = dict(stage=stage, inside=inside, n_rays=ro.shape[0])
+        return loss.detach()
+
+    def graphed(self, stage, warmup=3):
+        """The iteration of one stage as ONE hipGraph (static shapes): `replay()` runs an iteration with fresh pixels."""
+        from .graph import GraphedStep
+        if not self.static_shapes:
+            raise L.EnslamError("MapperIteration.graphed needs static_shapes=True")
+        st = self.cfg['mapping']['stage'][stage]
+        # learning rates are device scalars: set them before capture, they stay adjustable between replays
+        self.grid_opt.set_lr({k: st[k[5:] + '_lr'] * self.lr_factor for k in self.keys})
+        return GraphedStep(lambda: self.step(0, 1, stage=stage), warmup=warmup)
+
+    def finish(self):
+        """Write the optimised voxels back into the caller's grids; returns the camera tensors (None for fixed frames)."""
+        self.grid_opt.write_back()
+        return [None if t is None else t.detach() for t in self.camera_tensors]

@@ -1,0 +1,119 @@
+"""Run-harness pieces that need no GPU: the cv2-free Replica_event reader, the frustum mask, and the
+checkpoint the harness's Logger writes -- read back the way the reference's src/tools/eval_ate.py reads it
+(:281-303) and scored by the REFERENCE's own evaluate_ate when /root/reference is present (build container)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import evennicer_slam_amd as E
+from evennicer_slam_amd import datasets as D
+
+REF = '/root/reference'
+
+
+def _sequence(tmp_path, n=4, H=24, W=32, seed=0):
+    rng = np.random.default_rng(seed)
+    frames = [(rng.random((H, W, 3)), (rng.random((H, W)) * 3).astype(np.float32)) for _ in range(n)]
+    poses = []
+    for i in range(n):
+        p = np.eye(4)
+        p[:3, 3] = [0.1 * i, 0.02 * i, -0.05 * i]
+        poses.append(p)
+    events = [rng.integers(0, 3, (H, W, 2)).astype(np.uint8) for _ in range(n - 1)]
+    inp, evf = D.write_replica_event_sequence(str(tmp_path), frames, poses, 6553.5, events)
+    cfg = {'dataset': 'replica_event', 'cam': dict(H=H, W=W, fx=20., fy=20., cx=15.5, cy=11.5, png_depth_scale=6553.5, crop_edge=0),
+           'data': {'input_folder': inp, 'event_folder': evf}}
+    return cfg, frames, poses, events
+
+
+def test_replica_event_reader_roundtrip(tmp_path):
+    cfg, frames, poses, events = _sequence(tmp_path)
+    ds = D.get_dataset(cfg, types.SimpleNamespace(input_folder=None, event_folder=None), 1, device='cpu')
+    assert len(ds) == 4
+    idx, color, depth, event, mask, pose = ds[2]
+    assert idx == 2 and color.dtype == torch.float64 and depth.dtype == torch.float32 and event.dtype == torch.uint8
+    assert tuple(color.shape) == (24, 32, 3) and tuple(event.shape) == (24, 32, 2) and mask.dtype == torch.int64
+    assert float((color - torch.from_numpy(frames[2][0])).abs().max()) < 0.03          # JPEG, quality 100
+    assert float((depth - torch.from_numpy(frames[2][1])).abs().max()) < 1.0 / 6553.5
+    assert np.array_equal(event.numpy(), events[1])                                     # (-, +) of the png's (0, -, +)
+    assert np.array_equal(mask.numpy(), (events[1] != 0).any(-1).astype(np.int64))
+    assert np.allclose(pose.numpy(), poses[2], atol=1e-6)
+    assert int(ds[0][3].abs().max()) == 0                                               # frame 0: all-black event image
+    # crop_edge and scale follow the reference (:104-113)
+    cfg['cam']['crop_edge'] = 2
+    ds2 = D.get_dataset(cfg, types.SimpleNamespace(input_folder=None, event_folder=None), 2.0, device='cpu')
+    _, c2, d2, e2, m2, p2 = ds2[1]
+    assert tuple(d2.shape) == (20, 28) and tuple(e2.shape) == (20, 28, 2)
+    assert np.allclose(d2.numpy(), 2.0 * frames[1][1][2:-2, 2:-2], atol=2.0 / 6553.5)
+    assert np.allclose(p2[:3, 3].numpy(), 2.0 * poses[1][:3, 3], atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        D.get_dataset(dict(cfg, cam=dict(cfg['cam'], distortion=[0.1, 0, 0, 0])), types.SimpleNamespace(), 1, device='cpu')
+
+
+def test_frustum_mask_selects_what_the_camera_sees():
+    from evennicer_slam_amd.slam import frustum_mask
+    bound = torch.tensor([[-2.0, 2.0], [-2.0, 2.0], [-2.0, 2.0]], dtype=torch.float64)
+    cam = dict(H=48, W=64, fx=50.0, fy=50.0, cx=31.5, cy=23.5)
+    c2w = torch.eye(4)                                       # camera at the origin looking down -z (the path's convention)
+    depth = torch.full((48, 64), 1.0)
+    m = frustum_mask(c2w, depth, (21, 21, 21), bound, cam)
+    assert m.dtype == torch.bool and tuple(m.shape) == (21, 21, 21)
+    ax = torch.linspace(-2, 2, 21)
+    zi = lambda z: int(torch.argmin((ax - z).abs()))
+    c = 10                                                   # x = y = 0
+    assert bool(m[zi(-1.0), c, c]) and bool(m[zi(-1.4), c, c])           # on the axis, in front, within depth + 0.5
+    assert not bool(m[zi(-1.8), c, c])                                   # beyond depth + 0.5
+    assert not bool(m[zi(1.0), c, c])                                    # behind the camera
+    assert bool(m[zi(0.2), c, c])                                        # within 0.5 m of the camera centre
+    assert not bool(m[zi(-1.0), c, 20])                                  # far off-axis: outside the image
+    depth0 = torch.zeros((48, 64))
+    depth0[:, :32] = 1.0
+    m0 = frustum_mask(c2w, depth0, (21, 21, 21), bound, cam)             # zero depth -> filled with the maximum
+    assert bool(m0[zi(-1.0), c, zi(0.2)]) and bool(m0[zi(-1.0), c, zi(-0.2)])     # one lands on a zero-depth pixel, one on a valid one
+
+
+def _write_checkpoint(tmp_path, n=30, seed=3):
+    rng = np.random.default_rng(seed)
+    gt = torch.eye(4).repeat(n, 1, 1)
+    est = torch.eye(4).repeat(n, 1, 1)
+    t = np.linspace(0, 4, n)
+    gt[:, :3, 3] = torch.from_numpy(np.stack([np.cos(t), np.sin(0.7 * t), 0.3 * t], 1)).float()
+    est[:, :3, 3] = gt[:, :3, 3] + torch.from_numpy(0.02 * rng.standard_normal((n, 3))).float() + torch.tensor([0.3, -0.1, 0.2])
+    model = E.get_model({'model': {'c_dim': 32, 'coarse_bound_enlarge': 2, 'pos_embedding_method': 'fourier'}, 'data': {'dim': 3},
+                         'coarse': True, 'grid_len': {'coarse': 2, 'middle': 0.32, 'fine': 0.16, 'color': 0.16}})
+    slam = types.SimpleNamespace(verbose=False, ckptsdir=str(tmp_path), shared_c={'grid_coarse': torch.zeros(1, 32, 2, 2, 2)},
+                                 gt_c2w_list=gt, shared_decoders=model, estimate_c2w_list=est)
+    path = E.eval_ate.Logger({}, None, slam).log(n - 1, [], [0, 5, 10])
+    return path, gt, est
+
+
+def test_checkpoint_format_and_ate_against_the_reference_tool(tmp_path):
+    import evennicer_slam_amd.eval_ate as EA
+    path, gt, est = _write_checkpoint(tmp_path)
+    assert os.path.basename(path) == '00029.tar' and EA.latest_checkpoint(str(tmp_path)) == path
+    ckpt = torch.load(path, map_location='cpu', weights_only=False)
+    assert set(ckpt) == {'c', 'decoder_state_dict', 'gt_c2w_list', 'estimate_c2w_list', 'keyframe_list', 'selected_keyframes', 'idx'}
+    mine = EA.evaluate_checkpoint(path, scale=1.0)
+    assert mine['compared_pose_pairs'] == 30 and 0.0 < mine['absolute_translational_error.rmse'] < 0.1
+    if not os.path.isdir(REF):
+        pytest.skip("reference checkout not present (GPU box): cross-check runs in the build container")
+    # the reference's own tool on the same checkpoint: eval_ate.py:281-303 load the lists; convert_poses needs mathutils
+    # (absent), but evaluate_ate only reads the translations, so they are taken from the lists directly
+    sys.path.insert(0, REF)
+    try:
+        import importlib
+        for k in [k for k in sys.modules if k == 'src' or k.startswith('src.')]:
+            del sys.modules[k]
+        ref = importlib.import_module('src.tools.eval_ate')
+    finally:
+        sys.path.remove(REF)
+    N = ckpt['idx']
+    first = {i: np.concatenate([ckpt['gt_c2w_list'][i][:3, 3].numpy(), [0, 0, 0, 1]]) for i in range(N + 1)}
+    second = {i: np.concatenate([ckpt['estimate_c2w_list'][i][:3, 3].numpy(), [0, 0, 0, 1]]) for i in range(N + 1)}
+    theirs = ref.evaluate_ate(first, second, "")
+    for k, v in theirs.items():
+        assert abs(mine[k] - v) <= 1e-9 * max(1.0, abs(v)), k

@@ -1,0 +1,83 @@
+"""-m gpu: the single-process run harness (slam.SLAM) end to end on a synthetic Replica_event-layout
+sequence: frames rendered from a random map along a short trajectory, written as jpg / png / traj.txt, read back by the
+cv2-free reader, tracked and mapped on the HIP path with the reference's schedule, logged as a reference-format
+checkpoint and scored with eval_ate.  No dataset or pretrained weights exist in the image, so the assertions are about
+the pipeline (every stage runs, poses stay close to the ground truth on this easy sequence, BA and the static-shape
+mapper take part), not about reconstruction quality."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _cfg(inp, evf, H, W):
+    from tests.hip_util import cfg_like
+    cfg = cfg_like(grid_len={'coarse': 0.8, 'middle': 0.4, 'fine': 0.2, 'color': 0.2, 'bound_divisible': 0.32})
+    cfg.update({'dataset': 'replica_event', 'scale': 1,
+                'cam': dict(H=H, W=W, fx=50.0, fy=50.0, cx=31.5, cy=23.5, png_depth_scale=6553.5, crop_edge=0),
+                'data': {'dim': 3, 'input_folder': inp, 'event_folder': evf}})
+    cfg['mapping'] = {'bound': [[-1.0, 1.1], [-0.9, 0.8], [-0.7, 0.6]], 'w_color_loss': 0.2, 'lr_factor': 1, 'BA': True,
+                      'BA_cam_lr': 0.001, 'middle_iter_ratio': 0.4, 'fine_iter_ratio': 0.6, 'fix_fine': True, 'fix_color': False,
+                      'pixels': 120, 'iters_first': 30, 'iters': 8, 'every_frame': 2, 'keyframe_every': 1, 'mapping_window_size': 4,
+                      'frustum_feature_selection': True,
+                      'stage': {'coarse': dict(decoders_lr=0.0, coarse_lr=0.001, middle_lr=0.0, fine_lr=0.0, color_lr=0.0),
+                                'middle': dict(decoders_lr=0.0, coarse_lr=0.0, middle_lr=0.1, fine_lr=0.0, color_lr=0.0),
+                                'fine': dict(decoders_lr=0.0, coarse_lr=0.0, middle_lr=0.005, fine_lr=0.005, color_lr=0.0),
+                                'color': dict(decoders_lr=0.005, coarse_lr=0.0, middle_lr=0.005, fine_lr=0.005, color_lr=0.005)}}
+    cfg['tracking'] = {'device': DEV, 'w_color_loss': 0.5, 'ignore_edge_W': 4, 'ignore_edge_H': 4, 'handle_dynamic': True,
+                       'use_color_in_tracking': True, 'lr': 0.001, 'pixels': 100, 'iters': 6, 'const_speed_assumption': True,
+                       'gt_camera': False}
+    cfg['event'] = {'activate_events': False, 'blur': True, 'kernel_sizes': [9], 'kernel_weights': [1], 'unblurred_weight': 0,
+                    'balancer': 0.025, 'scale_factor': 0.5}
+    return cfg
+
+
+def test_run_harness_on_a_synthetic_sequence(tmp_path):
+    import evennicer_slam_amd as E
+    from evennicer_slam_amd import datasets as D
+    from evennicer_slam_amd.slam import SLAM
+    from tests.hip_util import tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    H, W, n = 48, 64, 9
+    frames, poses, events = [], [], []
+    th = 0.3
+    base = torch.tensor([[np.cos(th), 0, np.sin(th), 0.1], [0, 1, 0, -0.05], [-np.sin(th), 0, np.cos(th), 0.2], [0, 0, 0, 1.0]],
+                        dtype=torch.float32)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for i in range(n):
+            c2w = base.clone()
+            c2w[:3, 3] += torch.tensor([0.01 * i, 0.004 * i, -0.006 * i])
+            gt = torch.rand(H, W, generator=g) * 0.8 + 0.4                      # guide depths for the sampler
+            d, u, c = renderer.render_img(grids, model, c2w[:3].to(DEV), DEV, 'color', gt_depth=gt.to(DEV))
+            frames.append((c.clamp(0, 1).cpu().numpy(), d.clamp(0.05, 5.0).float().cpu().numpy()))
+            poses.append(c2w.numpy())
+            if i > 0:
+                events.append(np.zeros((H, W, 2), dtype=np.uint8))
+    inp, evf = D.write_replica_event_sequence(str(tmp_path / 'data'), frames, poses, 6553.5, events)
+    cfg = _cfg(inp, evf, H, W)
+    ds = D.get_dataset(cfg, types.SimpleNamespace(input_folder=None, event_folder=None), cfg['scale'], device=DEV)
+    assert len(ds) == n and len(ds[3]) == 6
+    torch.manual_seed(0)
+    np.random.seed(0)
+    slam = SLAM(cfg, ds, str(tmp_path / 'out'), device=DEV, static_shapes=True)
+    res = slam.run()
+    assert res['frames'] == n and res['fps'] > 0
+    ckpt = torch.load(res['ckpt'], map_location='cpu', weights_only=False)
+    assert ckpt['idx'] == n - 1 and len(ckpt['keyframe_list']) >= 4
+    assert set(ckpt['c']) == {'grid_coarse', 'grid_middle', 'grid_fine', 'grid_color'}
+    assert set(ckpt['decoder_state_dict']) == set(model.state_dict())
+    est, gtl = ckpt['estimate_c2w_list'], ckpt['gt_c2w_list']
+    assert torch.equal(est[0], gtl[0])                                          # frame 0 takes the ground-truth pose
+    assert bool(torch.isfinite(est).all())
+    assert float((est[1:, :3, 3] - gtl[1:, :3, 3]).norm(dim=1).max()) < 0.05    # stays on the (1 cm / frame) trajectory
+    ate = slam.evaluate(res['ckpt'])
+    assert ate['compared_pose_pairs'] == n and 0.0 <= ate['absolute_translational_error.rmse'] < 0.05
+    # the map really was optimised, the tracker works on its own copy of it
+    assert float((slam.shared_c['grid_middle'] - 0).abs().max()) > 0.02
+    assert slam.tracker.c['grid_middle'] is not slam.shared_c['grid_middle']
+    assert torch.equal(slam.tracker.c['grid_middle'], slam.shared_c['grid_middle'])

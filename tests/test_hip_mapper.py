@@ -281,3 +281,109 @@ def test_eager_consumers_see_decoders_a_captured_optimiser_stepped():
     assert l2 != l1
     del gs
     EF.clear_caches()
+
+
+# ------------------------------------------------------------------------------------------------ bundle adjustment
+def _ba_setup(static_shapes, monkeypatch):
+    """MapperIteration on the tiny scene with the fixture's frames, masks, camera tensors and pixel draws."""
+    import evennicer_slam_amd as E
+    from evennicer_slam_amd.mapper import MapperIteration
+    from tests.hip_util import DEV, cfg_like, tiny_on_gpu
+    g = load("tiny_mapper_ba")
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    H, W, fx, fy, cx, cy = [float(v) for v in g['cam']]
+    cam = dict(H=int(H), W=int(W), fx=fx, fy=fy, cx=cx, cy=cy)
+    cfg = cfg_like()
+    cfg['mapping'] = {'w_color_loss': float(g['w_color_loss']), 'lr_factor': float(g['lr_factor']), 'BA': True,
+                      'BA_cam_lr': float(g['BA_cam_lr']), 'middle_iter_ratio': 0.4, 'fine_iter_ratio': 0.6, 'fix_fine': True,
+                      'fix_color': False, 'pixels': int(g['pixs_per_image']) * 3,
+                      'stage': {'coarse': dict(decoders_lr=0.0, coarse_lr=0.001, middle_lr=0.0, fine_lr=0.0, color_lr=0.0),
+                                'middle': dict(decoders_lr=0.0, coarse_lr=0.0, middle_lr=0.1, fine_lr=0.0, color_lr=0.0),
+                                'fine': dict(decoders_lr=0.0, coarse_lr=0.0, middle_lr=0.005, fine_lr=0.005, color_lr=0.0),
+                                'color': dict(decoders_lr=0.005, coarse_lr=0.0, middle_lr=0.005, fine_lr=0.005, color_lr=0.005)}}
+    frames = [dict(depth=torch.from_numpy(g[f'depth_{f}']).to(DEV), color=torch.from_numpy(g[f'color_{f}']).to(DEV),
+                   c2w=torch.from_numpy(g[f'est_c2w_{f}']).to(DEV), fixed=(f == 0)) for f in range(3)]
+    cts = [None] + [torch.from_numpy(g['camera_tensors'][f]) for f in (1, 2)]
+    masks = {k: torch.from_numpy(g['mask_' + k]).to(DEV) for k in KEYS}
+    it = MapperIteration(cfg, renderer, grids, model, frames, cam, masks=masks, keys=KEYS, camera_tensors=cts,
+                         static_shapes=static_shapes)
+    draws = iter(torch.from_numpy(g['idx']).reshape(-1, g['idx'].shape[-1]).to(DEV))
+    monkeypatch.setattr(torch, 'randint', lambda *a, **k: next(draws))
+    return g, it, grids, model
+
+
+@pytest.mark.parametrize("static_shapes", [False, True])
+def test_bundle_adjustment_iterations_match_reference_fixture(monkeypatch, static_shapes):
+    """8 joint iterations with BA (Mapper.py:374-407,481-490,502-547): losses, the number of rays the prefilter keeps,
+    the gradients reaching the two camera tensors, the camera tensors after every Adam step, final grids and colour
+    decoder -- once with the reference's dynamic-shape prefilter and once with the static-shape (capturable) form."""
+    g, it, grids, model = _ba_setup(static_shapes, monkeypatch)
+    n = int(g['num_joint_iters'])
+    for j in range(n):
+        grads_before = None
+        loss = it.step(j, n)
+        assert it.last['stage'] == str(g['stages'][j])
+        assert int(it.last['inside'].sum()) == int(g['n_inside'][j])
+        assert it.last['n_rays'] == (72 if static_shapes else int(g['n_inside'][j]))
+        assert abs(loss.item() - g['losses'][j]) <= 1e-4 * abs(g['losses'][j]), (j, loss.item(), g['losses'][j])
+        cams = torch.stack([t.detach() for t in it.camera_tensors if t is not None]).cpu().numpy()
+        assert np.abs(cams - g['cam_after'][j]).max() <= 2e-6, j
+        cg = torch.stack([t.grad for t in it.camera_tensors if t is not None]).cpu().numpy()
+        ref = g['cam_grads'][j]
+        assert np.abs(cg - ref).max() <= 1e-3 * np.abs(ref).max(), j
+    it.finish()
+    moved = np.abs(g['cam_after'][-1] - g['camera_tensors'][1:]).max()
+    assert moved > 1e-3                                                  # the cameras really moved (colour stage)
+    for k in KEYS:
+        assert np.abs(grids[k].cpu().numpy() - g['final_' + k]).max() <= 5e-5, k
+    for name, ref in g.items():
+        if name.startswith('final_cd_'):
+            got = dict(model.color_decoder.named_parameters())[name[len('final_cd_'):]].detach().cpu().numpy()
+            assert np.abs(got - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), name
+
+
+def test_graphed_mapper_iteration_draws_new_rays_every_replay():
+    """The static-shape iteration captured as ONE hipGraph: every replay draws new pixels (torch.randint on the device
+    generator inside the graph), filters, renders, steps -- and equals the eager static-shape iteration fed the same
+    generator state."""
+    import gc
+    import evennicer_slam_amd as E
+    from evennicer_slam_amd.mapper import MapperIteration
+    from tests.hip_util import DEV, cfg_like, tiny_on_gpu
+    g = load("tiny_mapper_ba")
+
+    def build():
+        s, bound, model, grids, rays, renderer = tiny_on_gpu()
+        H, W, fx, fy, cx, cy = [float(v) for v in g['cam']]
+        cam = dict(H=int(H), W=int(W), fx=fx, fy=fy, cx=cx, cy=cy)
+        cfg = cfg_like()
+        cfg['mapping'] = {'w_color_loss': 0.2, 'lr_factor': 1.0, 'BA': True, 'BA_cam_lr': 0.001, 'middle_iter_ratio': 0.4,
+                          'fine_iter_ratio': 0.6, 'fix_fine': True, 'fix_color': False, 'pixels': 72,
+                          'stage': {'color': dict(decoders_lr=0.005, coarse_lr=0.0, middle_lr=0.005, fine_lr=0.005, color_lr=0.005)}}
+        frames = [dict(depth=torch.from_numpy(g[f'depth_{f}']).to(DEV), color=torch.from_numpy(g[f'color_{f}']).to(DEV),
+                       c2w=torch.from_numpy(g[f'est_c2w_{f}']).to(DEV), fixed=(f == 0)) for f in range(3)]
+        cts = [None] + [torch.from_numpy(g['camera_tensors'][f]) for f in (1, 2)]
+        masks = {k: torch.from_numpy(g['mask_' + k]).to(DEV) for k in KEYS}
+        return MapperIteration(cfg, renderer, grids, model, frames, cam, masks=masks, keys=KEYS, camera_tensors=cts,
+                               static_shapes=True), grids
+
+    # eager reference: 3 warm-up iterations (what GraphedStep runs before capturing) + 4 more, one RNG stream
+    it_e, grids_e = build()
+    torch.manual_seed(5)
+    for _ in range(3):
+        it_e.step(0, 1, stage='color')
+    eager = [it_e.step(0, 1, stage='color').item() for _ in range(4)]
+    cams_e = torch.stack([t.detach() for t in it_e.camera_tensors if t is not None]).clone()
+    gc.collect()
+    it_g, grids_g = build()
+    torch.manual_seed(5)
+    gs = it_g.graphed('color', warmup=3)
+    graphed = [gs.replay().item() for _ in range(4)]
+    torch.cuda.synchronize()
+    assert len(set(graphed)) == 4                                        # new pixels every replay
+    # same generator stream -> same draws -> same losses and the same cameras
+    assert np.abs(np.array(graphed) - np.array(eager)).max() <= 1e-5 * max(eager)
+    cams_g = torch.stack([t.detach() for t in it_g.camera_tensors if t is not None])
+    assert float((cams_g - cams_e).abs().max()) <= 2e-6
+    del gs
+    gc.collect()
