@@ -364,6 +364,80 @@ ENS_DEV void scatter_tile_rec(const float* dep, const f32x4& rec, const DevGrid&
 }
 
 
+// The same scatter as a resumable state machine: the dW waves of decoder_bwd_split_kernel run it in four 4-sample pieces
+// between their owned products.  val[pt] = this lane's channel (lane & 31) of sample pt's feature gradient; the cell records
+// come as four wave-wide integers (lane = sample).
+struct ScatterSt {
+    float acc[4];
+    unsigned cur;
+    bool open;
+};
+ENS_DEV void scatter_flush(ScatterSt& st, const DevGrid& gg, int lane, int kmask, int half) {
+    const int ch = lane & 31, dxb = lane >> 5;
+    const int rowy = gg.W * 32, rowz = gg.H * gg.W * 32;
+    const unsigned cur = st.cur;
+    const bool okx = !dxb || (cur >> 29 & 1u), oky = cur >> 30 & 1u, okz = cur >> 31;
+    const bool mine = half == 0 || (half == 1) == (dxb == 0);
+    float* base = gg.data + (int64_t)(cur & 0x1fffffffu) * 32 + dxb * 32 + ch;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!((kmask >> k) & 1)) continue;
+        const bool ok = mine && okx && (!(k & 1) || oky) && (!(k >> 1) || okz);
+        if (ok && st.acc[k] != 0.f) atomicAdd(base + (k & 1) * rowy + (k >> 1) * rowz, st.acc[k]);
+        if (mine) st.acc[k] = 0.f;
+    }
+}
+template <int P0>
+ENS_DEV void scatter_piece(ScatterSt& st, const float (&val)[16], int ri, int rx, int ry, int rz, const DevGrid& gg, int lane) {
+    const int dxb = lane >> 5;
+    const int stepy = gg.W, stepz = gg.H * gg.W;
+#pragma unroll
+    for (int pt = P0; pt < P0 + 4; ++pt) {
+        const float v = val[pt];
+        if (!__any(v != 0.f)) continue;
+        const unsigned lin = (unsigned)__builtin_amdgcn_readlane(ri, pt);
+        const float fx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rx, pt));
+        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ry, pt));
+        const float fz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rz, pt));
+        if (!st.open) {
+            st.cur = lin; st.open = true;
+        } else if (lin != st.cur) {                        // new cell: keep the partial sums of shared corner voxels (see scatter_tile_rec)
+            const unsigned cur = st.cur;
+            const int d = (int)(lin & 0x1fffffffu) - (int)(cur & 0x1fffffffu);
+            if (d == 1 && (cur >> 29 & 1u)) {
+                scatter_flush(st, gg, lane, 15, 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float o = __shfl_xor(st.acc[k], 32); st.acc[k] = dxb ? 0.f : o; }
+            } else if (d == -1 && (lin >> 29 & 1u)) {
+                scatter_flush(st, gg, lane, 15, 2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float o = __shfl_xor(st.acc[k], 32); st.acc[k] = dxb ? o : 0.f; }
+            } else if (d == stepy && (cur >> 30 & 1u)) {
+                scatter_flush(st, gg, lane, 5, 0);
+                st.acc[0] = st.acc[1]; st.acc[2] = st.acc[3]; st.acc[1] = 0.f; st.acc[3] = 0.f;
+            } else if (d == -stepy && (lin >> 30 & 1u)) {
+                scatter_flush(st, gg, lane, 10, 0);
+                st.acc[1] = st.acc[0]; st.acc[3] = st.acc[2]; st.acc[0] = 0.f; st.acc[2] = 0.f;
+            } else if (d == stepz && (cur >> 31)) {
+                scatter_flush(st, gg, lane, 3, 0);
+                st.acc[0] = st.acc[2]; st.acc[1] = st.acc[3]; st.acc[2] = 0.f; st.acc[3] = 0.f;
+            } else if (d == -stepz && (lin >> 31)) {
+                scatter_flush(st, gg, lane, 12, 0);
+                st.acc[2] = st.acc[0]; st.acc[3] = st.acc[1]; st.acc[0] = 0.f; st.acc[1] = 0.f;
+            } else {
+                scatter_flush(st, gg, lane, 15, 0);
+            }
+            st.cur = lin;
+        }
+        const float wx = dxb ? fx : (1.f - fx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float w = (wx * ((k & 1) ? fy : (1.f - fy))) * ((k >> 1) ? fz : (1.f - fz));
+            st.acc[k] = fmaf(w, v, st.acc[k]);
+        }
+    }
+}
+
 struct BwdArgs {
     int n_rays, ntl;
     const float* ro;
@@ -408,6 +482,46 @@ constexpr int ring_floats(int ct) { return cmax(32 * 128 + 32 + 32 * 16 * ct + 3
 
 
 __shared__ int ens_vote[2][4];      // per-round activity flags of the 4 waves (double buffered by round parity)
+
+// ---- elastic hand-offs of decoder_bwd_split_kernel ------------------------------------------------------------------
+// Inside a round the chain waves (0..3) and the dW waves (4..7) of a workgroup no longer meet at workgroup barriers: they
+// hand tiles over through monotonic counters in LDS (one ds_add per wave and hand-off, polled with ds_read + s_sleep).
+// A chain wave therefore never waits for the dW waves' MFMAs of the layer it has just deposited, the dW waves run up to
+// two layers behind and fill the MFMA pipe while the chain wave is in its vector / scalar stretches (feature-gradient
+// scatter, embedding tail, deposits), and no wait includes vmcnt(0) -- a __syncthreads() made every chain wave wait for
+// the acknowledges of the float atomics it had just issued.  One workgroup barrier per round (the activity vote) remains.
+//   SY_DEP+i   chain waves have deposited dh_i / dpre_i of layer i                    (+4 per executed round)
+//   SY_DW+i    dW waves have read everything layer i's owned products need          (+4 per executed round)
+//   SY_DARG    chain waves have deposited d_arg (tiles HX2..HX1 of their slot)      (+4 per executed round)
+//   SY_FILL    dW waves' slot fills from the activation workspace have landed       (+4 per executed round)
+//   SY_RING    W^T ring chunks landed (the chain waves stream the ring themselves)   (+4 per chunk)
+//   SY_RDONE   chain waves have read a ring chunk (its buffer may be refilled)       (+4 per chunk)
+//   SY_STG     chain waves have staged dC of their tile for the scatter              (+4 per executed round)
+//   SY_STGDONE dW waves have taken the staged dC of the previous round into registers (+4 per executed round after the first)
+// The feature-gradient scatter (8 k of the chain wave's 43 k cycles per round, branchy scalar code with float atomics) runs
+// on the dW waves: dW wave v scatters chain wave v's previous tile in four 4-sample pieces between its owned products.
+// LDS operations of one wave execute in issue order, so a counter increment issued after a wave's writes (reads) is seen
+// only after them.  Every wait is bounded (ENS_SPIN_LIMIT polls): a protocol error ends in wrong numbers, which the
+// parity tests catch, never in a hung GPU.
+enum { SY_DEP = 0, SY_DW = 5, SY_DARG = 10, SY_FILL = 11, SY_RING = 12, SY_RDONE = 13, SY_STG = 14, SY_STGDONE = 15, SY_N = 16 };
+__shared__ int ens_sync[SY_N];
+constexpr int ENS_SPIN_LIMIT = 1 << 21;
+ENS_DEV void sy_signal(int idx, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&ens_sync[idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+ENS_DEV void sy_wait(int idx, int target) {
+    for (int it = 0; it < ENS_SPIN_LIMIT; ++it) {
+        const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ens_sync[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (v >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+// workgroup barrier that orders LDS traffic only (no vmcnt(0): global stores / atomics in flight are nobody's business here)
+ENS_DEV void wg_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // deposit tile T (byte offset T*1024 behind dep = slot base + ((p>>2)*64 + (p&3) + 16q)*4)
 template <int T>
@@ -900,8 +1014,13 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     const int64_t stride = (int64_t)n_wg * 4;
     STAMP_DECL
     STAMP_START
-    if constexpr (!SPLIT) prefetch(IC(4), 0);                       // (SPLIT: the dW waves stream the ring and fill the slots)
+    prefetch(IC(4), 0);                                             // (the chain waves stream the W^T ring; SPLIT: the dW waves fill the slots)
+    if constexpr (SPLIT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sy_signal(SY_RING, lane);                                   // chunk 0 (layer 4 of the first executed round)
+    }
     unsigned round_no = 0, rp = 0;                                  // rp: ring buffer of this round's first chunk
+    unsigned r_exec = 0;                                            // executed (not skipped) rounds so far: targets of the hand-off counters
     // The feature-gradient scatter of a tile is deferred into the next executed round (after its first barrier): the
     // ~30 atomics of a tile then drain under that round's MFMAs instead of in front of its loads (vmcnt is in order).
     float* const stg = slots + wave * SLOT + STG;                   // dC as [sample][32]; H1 is idle until layer 3
@@ -954,7 +1073,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             const int par = (int)(round_no & 1);
             if (lane == 0) ens_vote[par][wave] = __any(nz) ? 1 : 0;
             ++round_no;
-            __syncthreads();
+            if constexpr (SPLIT) wg_barrier_lds(); else __syncthreads();
             const int any4 = ens_vote[par][0] | ens_vote[par][1] | ens_vote[par][2] | ens_vote[par][3];
             if (!any4) {
                 if (want_r && tvalid) {                             // grid_bwd_kernel reads the hand-off of every tile
@@ -990,7 +1109,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             h4[1] = ld4(wsb + ACT_H4 + 256 + lane * 4);
         }
         f32x4 rec = splat4(0.f);
-        if (want_g) rec = ld4(wsb + WSV + p * 4);
+        if constexpr (!SPLIT) { if (want_g) rec = ld4(wsb + WSV + p * 4); }
         unsigned mbits[5] = {mw.x & 255u, (mw.x >> 8) & 255u, (mw.x >> 16) & 255u, (mw.x >> 24) & 255u, mw.y & 255u};
         unsigned wsw = swz_base_even(lds0, 32, p, q);                  // swizzled-image lane base, ring buffer 0
         const unsigned swd = swz_odd_delta(p);
@@ -1019,15 +1138,27 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
             constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);      // input h_{i-1} of layers 4, 2, 1
             f32x4 dpre[2] = {mask4(dh[0], mbits[i], 0), mask4(dh[1], mbits[i], 4)};
+            if constexpr (SPLIT) {
+                // the dh / dpre tiles of this parity still hold layer i+2's operands: its owned products must have read them
+                if constexpr (i <= 2) sy_wait(SY_DW + i + 2, 4 * (int)(r_exec + 1));
+                // ... and the H1 tiles the previous tile's dC was staged in: the dW waves must have taken it
+                if constexpr (i == 3) { if (want_g) sy_wait(SY_STGDONE, 4 * (int)r_exec); }
+            }
             if (want_w) {
                 dep_tile<TH>(dep, dh[0]); dep_tile<TH + 1>(dep, dh[1]);
                 dep_tile<TP>(dep, dpre[0]); dep_tile<TP + 1>(dep, dpre[1]);
             }
             STAMP(6)    // layer deposits (+ tail of previous dX)
-            __syncthreads();            // deposits + slot fill visible; this layer's W^T chunk has landed
+            if constexpr (SPLIT) {
+                sy_signal(SY_DEP + i, lane);                                  // layer i's operands are in place
+                sy_wait(SY_RING, 4 * (int)(5 * r_exec + kk + 1));             // this layer's W^T chunk has landed (all quarters)
+                sy_wait(SY_RDONE, 4 * (int)(5 * r_exec + kk));                // every chain wave is done with the chunk before it
+            } else {
+                __syncthreads();        // deposits + slot fill visible; this layer's W^T chunk has landed
+            }
             STAMP(5)    // barrier wait
-            if constexpr (!SPLIT) { if constexpr (i > 0) prefetch(IC(i - 1), buf ^ 1); else prefetch(IC(4), buf ^ 1); }
-            if constexpr (i == 4) scatter_pending();                 // previous tile's atomics, behind this round's loads
+            if constexpr (i > 0) prefetch(IC(i - 1), buf ^ 1); else prefetch(IC(4), buf ^ 1);
+            if constexpr (i == 4 && !SPLIT) scatter_pending();       // previous tile's atomics, behind this round's loads
             if constexpr (i == 4) { STAMP(1) }      // deferred scatter
             if constexpr (i == 4) {
                 if (want_w) {                       // dWo, dbo on the VALU (n_out <= 4 rows: not worth an MFMA tile)
@@ -1071,6 +1202,11 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 dh[0] = dh[1] = splat4(0.f);
                 lin_lds_swz<2, 2, 32, 0>(dh, wb, swd, dpre);
             }
+            if constexpr (SPLIT) {
+                if constexpr (i > 0) sy_signal(SY_RDONE, lane);      // chunk read (layer 0's is read again in the tail)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's quarter of the next chunk has landed
+                sy_signal(SY_RING, lane);
+            }
         };
         bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
         rp ^= 1;                                                    // 5 chunks per executed round
@@ -1082,6 +1218,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             constexpr int OBP = (96 * 32 + 1024) * 4, OBT = OBP + 16 * 96 * 4;
             // coordinate q of sample p from the XYZ tile (feature i = q)
             float pc = 0.f;
+            if constexpr (SPLIT) sy_wait(SY_FILL, 4 * (int)(r_exec + 1));       // (the slot fill landed long ago)
             if constexpr (WW) {
                 if (q < 3) pc = *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(
                                     lds0 + RING_BYTES + (wave * SLOT + SL::Q * 256 + (p >> 2) * 64 + q * 4 + (p & 3)) * 4));
@@ -1096,21 +1233,38 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 for (int r = 0; r < 4; ++r) demb[t][r] *= ens_cosf(arg[r]);
             }
             if (want_w) {
-                __syncthreads();                                     // every wave is done reading EMB
-                dep_tile<SL::EMB + 0>(dep, demb[0]); dep_tile<SL::EMB + 1>(dep, demb[1]); dep_tile<SL::EMB + 2>(dep, demb[2]);
-                dep_tile<SL::EMB + 3>(dep, demb[3]); dep_tile<SL::EMB + 4>(dep, demb[4]); dep_tile<SL::EMB + 5>(dep, demb[5]);
-                __syncthreads();
-                if constexpr (!SPLIT) own_outer_a<2>(aBT, fb, SL::EMB, SL::Q, 1, 6, wave);           // dB^T
+                if constexpr (SPLIT) {
+                    // d_arg goes into the six tiles of h2 | h0 | h1 (contiguous, tiles 6..11): their last readers are the
+                    // owned products of layers 3, 1 and 2 -- no need to wait for layer 0's, which still read EMB.  The same
+                    // wait frees the H1 tiles, where this wave stages dC for the deferred scatter below.
+                    sy_wait(SY_DW + 1, 4 * (int)(r_exec + 1));
+                    dep_tile<SL::HX2 + 0>(dep, demb[0]); dep_tile<SL::HX2 + 1>(dep, demb[1]); dep_tile<SL::HX2 + 2>(dep, demb[2]);
+                    dep_tile<SL::HX2 + 3>(dep, demb[3]); dep_tile<SL::HX2 + 4>(dep, demb[4]); dep_tile<SL::HX2 + 5>(dep, demb[5]);
+                    sy_signal(SY_DARG, lane);
+                } else {
+                    __syncthreads();                                 // every wave is done reading EMB
+                    dep_tile<SL::EMB + 0>(dep, demb[0]); dep_tile<SL::EMB + 1>(dep, demb[1]); dep_tile<SL::EMB + 2>(dep, demb[2]);
+                    dep_tile<SL::EMB + 3>(dep, demb[3]); dep_tile<SL::EMB + 4>(dep, demb[4]); dep_tile<SL::EMB + 5>(dep, demb[5]);
+                    __syncthreads();
+                    own_outer_a<2>(aBT, fb, SL::EMB, SL::Q, 1, 6, wave);                             // dB^T
+                }
             }
             if (want_r) lin_lds_swz<1, 6, 96, OBP>(dpe, swz_base_even(ring0, 96, p, q), swd, demb);   // rows 0..2: dp (q == 0 lanes)
         }
+        if constexpr (SPLIT) sy_signal(SY_RDONE, lane);             // the layer-0 chunk (B, B^T ride in it) is no longer needed
         STAMP(9)        // embedding tail (cos recompute, dB^T, dp)
         if (want_r && tvalid) {         // hand-off to grid_bwd_kernel: dC (register layout) + embedding's position gradient
             *reinterpret_cast<f32x4*>(dgw + lane * 4) = dc[0];
             *reinterpret_cast<f32x4*>(dgw + 256 + lane * 4) = dc[1];
             *reinterpret_cast<f32x4*>(dgw + DG_DPE + lane * 4) = dpe[0];
         }
-        if (want_g && tvalid) {
+        if constexpr (SPLIT) {
+            if (want_g) {               // dC of this tile (zeros for a padding tile) -> [sample][32] in this wave's H1 tiles, for dW wave `wave`
+                *reinterpret_cast<f32x4*>(stg + p * 32 + 4 * q) = dc[0];
+                *reinterpret_cast<f32x4*>(stg + p * 32 + 16 + 4 * q) = dc[1];
+                sy_signal(SY_STG, lane);
+            }
+        } else if (want_g && tvalid) {
             // dC of this tile -> [sample][32] in this wave's H1 tiles (last read before the layer-0 barrier); the
             // 256-byte atomics per cell corner row are issued by scatter_pending() in the next round
             *reinterpret_cast<f32x4*>(stg + p * 32 + 4 * q) = dc[0];
@@ -1119,9 +1273,10 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             rec_prev = rec;
             pend = true;
         }
+        ++r_exec;
         STAMP(10)
     }
-    scatter_pending();
+    if constexpr (!SPLIT) scatter_pending();
     STAMP_FLUSH
 
     // ---- flush: stage the owned tiles into a packed-layout LDS image, then coalesced global atomics
@@ -1200,31 +1355,43 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
     for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
     const int64_t n_tiles = work_count(A);
     const int64_t stride = (int64_t)n_wg * 4;
-    unsigned round_no = 0, rp = 0;
-    // These waves also do the chain waves' bulk data movement: the W^T ring (one layer ahead) and the slot fills from the
-    // activation workspace -- their barriers (vmcnt(0) included) come late enough for the copies to have landed.
-    const float* __restrict__ pk = A.sc.packed[kind];
-    float* ring = smem;
-    auto prefetch = [&](auto ic, int buf) {
-        constexpr int i = decltype(ic)::value;
-        float* dst = ring + (buf ? RB : 0);
-        ring_load(dst, pk + L.oWT(i), 8 * L.K(i), ow, lane);
-        ring_load(dst + 32 * L.K(i), pk + L.oWcT(i), 256, ow, lane);
-        if constexpr (i == 0) {
-            ring_load(dst + 96 * 32 + 1024, pk + L.oBp(), 16 * 96 / 4, ow, lane);
-            ring_load(dst + 96 * 32 + 1024 + 16 * 96, pk + L.oBT(), 96, ow, lane);
-        }
+    unsigned round_no = 0;
+    // These waves also fill the slots from the activation workspace (the chain waves stream the W^T ring themselves) and run
+    // the feature-gradient scatter of the chain waves' tiles.
+    unsigned r_exec = 0;
+    // ---- the feature-gradient scatter of chain wave `ow`'s tiles runs here (see the hand-off counters): state across pieces
+    const DevGrid ggrid = A.ggrid[kind];
+    const bool want_g = ggrid.data != nullptr;
+    float sval[16];
+    int sri = 0, srx = 0, sry = 0, srz = 0;
+    ScatterSt sst;
+    sst.acc[0] = sst.acc[1] = sst.acc[2] = sst.acc[3] = 0.f; sst.cur = 0u; sst.open = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sval[i] = 0.f;
+    int64_t tile_prev = 0;
+    const unsigned stg_rd = lds0 + RING_BYTES + (ow * SLOT + SL::H1 * 256 + (lane & 31)) * 4;     // dC[pt][ch]: + pt * 128 bytes
+    // take the dC chain wave `ow` staged for its tile of the previous executed round (and that tile's cell records)
+    auto take_staged = [&](int rounds_done) {
+        sy_wait(SY_STG, 4 * rounds_done);
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt) sval[pt] = *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(stg_rd + pt * 128));
+        const f32x4 rec = ld4(A.act_ws + (tile_prev * ACT_SLOTS + (kind - 1)) * ACT_STRIDE + ACT_VOX + (lane & 15) * 4);
+        const float r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        sri = __builtin_bit_cast(int, r0); srx = __builtin_bit_cast(int, r1); sry = __builtin_bit_cast(int, r2); srz = __builtin_bit_cast(int, r3);
+        sst.acc[0] = sst.acc[1] = sst.acc[2] = sst.acc[3] = 0.f; sst.cur = 0u; sst.open = false;
     };
-    prefetch(IC(4), 0);
     auto own = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        constexpr int kk = 4 - i;
-        const int buf = (kk + rp) & 1;
         constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
         constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);
-        __syncthreads();                    // layer i's deposits are in place; its W^T chunk and the slot fills have landed
-        if constexpr (i > 0) prefetch(IC(i - 1), buf ^ 1); else prefetch(IC(4), buf ^ 1);
+        sy_wait(SY_DEP + i, 4 * (int)(r_exec + 1));                 // layer i's deposits are in place
+        if constexpr (i == 4) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's slot fill has landed
+            sy_signal(SY_FILL, lane);
+            sy_wait(SY_FILL, 4 * (int)(r_exec + 1));                // all four slots filled
+        }
 #ifdef ENS_EXP_NO_DW
+        sy_signal(SY_DW + i, lane);
         return;                             // timing experiment (wrong results): no owned-tile MFMAs
 #endif
         const int ybias = (ow < 2 ? TP : TH) + (ow & 1);
@@ -1239,16 +1406,32 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         } else {
             own_layer_a<CT / 2, 1>(aWc[i], TH, SL::C, CT, 2 * CT, aW4, TP, TX, 2, 4, aB[i], ybias, fb, ow);
         }
+        sy_signal(SY_DW + i, lane);                                  // (the operand reads have returned: lgkmcnt(0) inside)
+        // one 4-sample piece of the previous tile's scatter behind each of layers 4..1: the chain waves are not waiting for it
+        if (want_g && r_exec > 0) {
+            if constexpr (i == 4) {
+                take_staged((int)r_exec);
+                sy_signal(SY_STGDONE, lane);                         // the H1 tiles may take layer 3's deposits
+                scatter_piece<0>(sst, sval, sri, srx, sry, srz, ggrid, lane);
+            } else if constexpr (i == 3) {
+                scatter_piece<4>(sst, sval, sri, srx, sry, srz, ggrid, lane);
+            } else if constexpr (i == 2) {
+                scatter_piece<8>(sst, sval, sri, srx, sry, srz, ggrid, lane);
+            } else if constexpr (i == 1) {
+                scatter_piece<12>(sst, sval, sri, srx, sry, srz, ggrid, lane);
+                if (sst.open) scatter_flush(sst, ggrid, lane, 15, 0);
+            }
+        }
     };
     for (int64_t base = (int64_t)wg * 4; base < n_tiles; base += stride) {
         const int par = (int)(round_no & 1);
         ++round_no;
-        __syncthreads();                    // vote
+        wg_barrier_lds();                   // vote (the one workgroup barrier of a round)
         const int any4 = ens_vote[par][0] | ens_vote[par][1] | ens_vote[par][2] | ens_vote[par][3];
         if (!any4) continue;
+        const int64_t tr = base + ow;
+        const int64_t tile = work_tile(A, tr < n_tiles ? tr : n_tiles - 1);
         {   // slot `ow` <- the operands the forward parked for chain wave ow's tile of this round
-            const int64_t tr = base + ow;
-            const int64_t tile = work_tile(A, tr < n_tiles ? tr : n_tiles - 1);
             const float* __restrict__ wsb = A.act_ws + (tile * ACT_SLOTS + (kind - 1)) * ACT_STRIDE;
             float* myslot = slots + ow * SLOT;
 #pragma unroll
@@ -1257,10 +1440,18 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
                                                  (__attribute__((address_space(3))) void*)(myslot + t * 256), 16, 0, 0);
         }
         own(IC(4)); own(IC(3)); own(IC(2)); own(IC(1)); own(IC(0));
-        rp ^= 1;
-        __syncthreads();                    // chain waves are done with EMB ...
-        __syncthreads();                    // ... and have deposited d_arg there
-        own_outer_a<2>(aBT, fb, SL::EMB, SL::Q, 1, 6, ow);                                         // dB^T
+        sy_wait(SY_DARG, 4 * (int)(r_exec + 1));                     // the chain waves have deposited d_arg (tiles HX2..HX1)
+        own_outer_a<2>(aBT, fb, SL::HX2, SL::Q, 1, 6, ow);                                         // dB^T
+        tile_prev = tile;
+        ++r_exec;
+    }
+    if (want_g && r_exec > 0) {                                       // the last executed round's tile
+        take_staged((int)r_exec);
+        scatter_piece<0>(sst, sval, sri, srx, sry, srz, ggrid, lane);
+        scatter_piece<4>(sst, sval, sri, srx, sry, srz, ggrid, lane);
+        scatter_piece<8>(sst, sval, sri, srx, sry, srz, ggrid, lane);
+        scatter_piece<12>(sst, sval, sri, srx, sry, srz, ggrid, lane);
+        if (sst.open) scatter_flush(sst, ggrid, lane, 15, 0);
     }
     float* sacc = slots;
     __syncthreads();
@@ -1474,6 +1665,8 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(BwdArgs A) {
 // per SIMD.  Waves 0..3 run the dX chain of one tile each (xyz_role_saved<.., SPLIT>), waves 4..7 accumulate the owned
 // weight-gradient tiles (xyz_dw_loop) from the operands the chain waves deposit, one barrier phase behind.
 __global__ __launch_bounds__(512, 1) void decoder_bwd_split_kernel(BwdArgs A) {
+    if (threadIdx.x < SY_N) ens_sync[threadIdx.x] = 0;
+    __syncthreads();
     int role = 0;
 #pragma unroll
     for (int r = 1; r < 4; ++r) role = (r < A.n_roles && (int)blockIdx.x >= A.role_begin[r]) ? r : role;
