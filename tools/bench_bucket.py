@@ -31,3 +31,20 @@ for _ in range(n): PAR._allreduce_hip(leaves, None, True, flags)
 torch.cuda.synchronize()
 t = (time.perf_counter() - t0) / n
 print(f"bucket glue without collectives: {t * 1e6:.0f} us per step, bucket {nbytes / 1e6:.2f} MB, {len(leaves)} leaves")
+
+# ---- what the bucket would weigh at finer block granularities: count the touched g-voxel blocks of the
+#      actual gradients.  Per-link ring time for n_gpus = 8 over xGMI (153 GB/s per link): 2 * (n-1)/n * bytes / BW.
+print("bucket size by block granularity (grid part; +0.24 MB of decoder gradients):")
+for gsz in (8, 16, 32, 64):
+    total = 0
+    for k in kinds:
+        g = grids[E._lib.GRID_NAMES[k]].grad
+        C, V = g.shape[1], g.shape[2] * g.shape[3] * g.shape[4]
+        g2 = g.reshape(C, V)
+        nfull = V // gsz
+        touched = (g2[:, :nfull * gsz].reshape(C, nfull, gsz) != 0).any(dim=2).any(dim=0)
+        total += int(touched.sum()) * gsz * C * 4 + (V - nfull * gsz) * C * 4
+    nnz = sum(int((grids[E._lib.GRID_NAMES[k]].grad != 0).sum()) * 4 for k in kinds)
+    wire = 2 * 7 / 8 * total / 153e9
+    print(f"  {gsz:3d}-voxel blocks: {total / 1e6:6.2f} MB  (non-zero gradient entries: {nnz / 1e6:.2f} MB)  "
+          f"8-GPU ring all-reduce over one xGMI link ~ {wire * 1e6:5.0f} us; flag bytes {sum((grids[E._lib.GRID_NAMES[k]].numel() // 32 + gsz - 1) // gsz for k in kinds) / 1e3:.1f} KB")

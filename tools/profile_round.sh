@@ -1,15 +1,20 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): kernel-time stats of the default bench run (hipGraph replay) and of an eager
-# run, then HBM traffic counters in separate --pmc passes.  Everything lands in gpurun_out/prof_round/; the summaries
-# worth keeping are copied into profiles/ by hand.
+# Run on the GPU box (through gpurun): kernel-time stats of the bench's config-2 step (hipGraph replay) and of an eager
+# run, then HBM traffic / SQ counters in separate --pmc passes.  Everything lands in gpurun_out/prof_round/; the summaries
+# worth keeping are copied into profiles/ by hand.  All passes measure the default workload only (--no-secondary: the extra
+# config-4 measurement launches the same kernels on office0 / 5000 rays and would mix into the per-kernel means;
+# --no-kernel-events: the event passes include launches that walk every tile).
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/graph -o g -- python3 $R/bench.py --steps 100 --warmup 10 > $O/graph.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/eager -o e -- python3 $R/bench.py --steps 50 --warmup 10 --eager > $O/eager.log 2>&1
+ARGS="--no-secondary --no-cpu-baseline --no-kernel-events"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/graph -o g -- python3 $R/bench.py --steps 100 --warmup 10 $ARGS > $O/graph.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/eager -o e -- python3 $R/bench.py --steps 50 --warmup 10 --eager $ARGS > $O/eager.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   tag=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o p -- python3 $R/bench.py --steps 10 --warmup 3 --eager > $O/pmc_$tag.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o p -- python3 $R/bench.py --steps 10 --warmup 3 --eager $ARGS > $O/pmc_$tag.log 2>&1
 done
 python3 $R/tools/pmc_summary.py $O $O/pmc_summary.json > $O/pmc_summary.txt
-tail -1 $O/graph.log | cut -c1-200
+python3 $R/tools/timeline.py $(find $O/graph -name 'g_kernel_trace.csv' | head -1) > $O/timeline.txt
+cat $O/timeline.txt
+grep -h '"metric"' $O/graph.log | cut -c1-260
