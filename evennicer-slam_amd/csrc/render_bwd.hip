@@ -564,7 +564,11 @@ ENS_DEV void own_layer_a(f32x4 (&accA)[NA], int yA, int xA, int ncA, int ntA, f3
                          int ntB, float& accBias, int ybias, const unsigned (&fb)[4], int wave) {
     // operand fragments of the next slot are requested before the current slot's MFMAs are issued (two register sets),
     // so the LDS round trip of slot s+1 runs under the MFMAs of slot s
+#ifdef ENS_EXP_NOPIPE            // A/B aid: single fragment set (fewer registers, LDS latency of every slot exposed)
+    constexpr bool PIPE = false;
+#else
     constexpr bool PIPE = (NA + NB) <= 4;
+#endif
     f32x4 aA[2][NA], bA[2][NA], aB[2][NB], bB[2][NB], ab[2];
     auto load = [&](int sl, int set) {
 #pragma unroll
