@@ -22,6 +22,15 @@ ENS_DEV unsigned fwd_pos_bits(const f32x4& v) {
 // Write one register tile to the workspace in the backward's deposit layout: transpose through a wave-private
 // 1 KB LDS tile, then one coalesced 16-byte store per lane.
 ENS_DEV void ws_store_dep(float* __restrict__ ws_tile, const f32x4& x, float* stage, int lane, int p, int q) {
+#ifdef ENS_EXP_MFMA_TRANSPOSE
+    // A/B aid: the transposition as an MFMA against the identity -- D[sample][feature] = sum_k X[sample][k] I[k][feature]
+    // with the register tile as the A operand (step r, k-slot q carries feature 4q+r) and the matching rows of I as B.
+    // Exact (products with 1 and 0); 4 MFMAs per tile instead of an LDS round trip with two waits.
+    f32x4 t = splat4(0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t = MFMA16(x[r], (p == 4 * q + r) ? 1.f : 0.f, t);
+    *reinterpret_cast<f32x4*>(ws_tile + lane * 4) = t;
+#else
     // (storing component-major [r][lane] with plain dword stores and turning the tile in the backward's
     // global_load_lds by addressing was tried: forward -2.6 us, backward +10 us -- the strided 16-byte source runs cost
     // more than the LDS round trip here, which other waves hide.  Four scattered dword stores per tile straight into
@@ -35,6 +44,7 @@ ENS_DEV void ws_store_dep(float* __restrict__ ws_tile, const f32x4& x, float* st
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     *reinterpret_cast<f32x4*>(ws_tile + lane * 4) = v;
+#endif
 }
 
 ENS_DEV f32x4 sin4(f32x4 v) { return f32x4{ens_sinf(v[0]), ens_sinf(v[1]), ens_sinf(v[2]), ens_sinf(v[3])}; }
