@@ -54,6 +54,20 @@ def test_bad_arguments_return_error_codes():
     assert lib.enslam_step_finish_rays(0, None, None, None, None, 0, None, None, None, 0, 4, 32, None, None, None, None, None, None,
                                        None, None, None, st) == 0                                     # coarse: plain finish, nothing to do
     assert lib.enslam_bucket_unpack(0, None, 32, None, None, None, None, 73, None, None, 0, P(ro), st) == EUNSUPPORTED
+    # round 2: 64 samples per ray are a supported tile count (the padded second pass of hierarchical sampling), 80 are not;
+    # the Fourier parity entry
+    z64 = torch.zeros(4, 64, dtype=torch.float64, device=dev)
+    assert lib.enslam_render_fwd(3, 4, 64, P(ro), P(ro), P(z64), ctypes.byref(sc), P(out_d), P(out_d), P(out_c), None, None, 0, st) == EINVAL   # (empty scene, not EUNSUPPORTED)
+    assert lib.enslam_render_fwd(3, 4, 80, P(ro), P(ro), P(z64), ctypes.byref(sc), P(out_d), P(out_d), P(out_c), None, None, 0, st) == EUNSUPPORTED
+    x = torch.linspace(-3, 3, 7, device=dev)
+    so, co = torch.empty_like(x), torch.empty_like(x)
+    assert lib.enslam_fourier_sincos(-1, P(x), P(so), P(co), st) == EINVAL
+    assert lib.enslam_fourier_sincos(7, None, P(so), P(co), st) == EINVAL
+    assert lib.enslam_fourier_sincos(7, P(x), None, None, st) == EINVAL
+    assert lib.enslam_fourier_sincos(0, None, None, None, st) == 0
+    assert lib.enslam_fourier_sincos(7, P(x), P(so), None, st) == 0 and lib.enslam_fourier_sincos(7, P(x), None, P(co), st) == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(so, torch.sin(x), atol=2e-7) and torch.allclose(co, torch.cos(x), atol=2e-7)
     torch.cuda.synchronize()
     assert lib.enslam_abi_version() >= 1
     assert lib.enslam_activation_floats(0, 100, 48, 0) == 0                     # the coarse stage keeps no workspace
