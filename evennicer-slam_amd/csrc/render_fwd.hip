@@ -434,7 +434,20 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
             }
         }
         FST(sx, 4)  // workspace stores of h
+#ifdef ENS_EXP_PARTIAL_VMCNT
+        // A/B aid: wait for the ring chunk only.  vmcnt counts loads, stores and LDS-DMA together in issue order
+        // (MI355X_MICROARCH.md), so leaving the workspace stores issued AFTER this layer's prefetch in flight (2 h tiles;
+        // layer 4: 2 h4 tiles + the mask words) still guarantees that the older prefetch has landed.  Spill traffic only
+        // adds younger operations, i.e. waits longer.  Forward-only calls store nothing: full wait.
+        if (ws != nullptr && !wl) {
+            if constexpr (i < 4) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            __syncthreads();
+        }
+#else
         __syncthreads();                // next chunk landed; all waves done with this buffer
+#endif
         FST(sx, 5)  // barrier (+ wait for the next chunk)
     };
     layer(IC(0)); layer(IC(1)); layer(IC(2)); layer(IC(3)); layer(IC(4));
