@@ -95,9 +95,21 @@ class Renderer(object):
                                    "torch.max over an empty tensor raises here too)")
         n_lin, n_surf = self.N_samples, (self.N_surface if gt_depth is not None else 0)
         S = n_lin + n_surf
-        if z_given is None and S not in (16, 32, 48, 64):
-            raise NotImplementedError(f"N_samples + N_surface = {S}: kernels are built for 16, 32, 48 or 64 samples")
+        if z_given is None and S > 64:
+            raise NotImplementedError(f"N_samples + N_surface = {S}: the kernels composite at most 64 samples per ray")
         dev = rays_o.device
+        if z_given is None and S % 16 != 0 and N > 0:
+            # sample counts that are not whole 16-sample tiles: the sampler runs on its own and the render takes the distances
+            # as given, the last tile padded (the pad is evaluated but neither composited nor given gradient)
+            if loss is not None:
+                raise NotImplementedError("render_batch_ray_rgbd_loss needs N_samples + N_surface to be a multiple of 16")
+            with torch.no_grad():
+                t_r = torch.rand((N, n_lin), device=dev) if self.perturb > 0. else None
+                z = EF.sample_rays(rays_o, rays_d, gt_depth, self.bound, n_lin, n_surf, self.lindisp, t_r,
+                                   depth_max=self.depth_max_override if gt_depth is not None else None)
+                S_pad = -(-S // 16) * 16
+                z = torch.cat([z, z[:, -1:].expand(N, S_pad - S)], -1).contiguous()
+            return self._render(c, decoders, rays_d, rays_o, device, stage, gt_depth, None, z_given=z, s_valid=S)
         t_lin, t_surf = self._t_vals(dev, n_lin, self.N_surface)
         t_rand = torch.rand((N, n_lin), device=dev) if (self.perturb > 0. and z_given is None) else None
         kinds = EF.stage_kinds(stage)

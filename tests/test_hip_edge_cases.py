@@ -207,3 +207,33 @@ def test_backward_twice_with_retain_graph(tiny):
     assert float((model.color_decoder.pts_linears[0].weight.grad - w0).abs().max()) <= 1e-5 * float(w0.abs().max())
     for p_ in model.parameters():
         p_.grad = None
+
+
+def test_sample_counts_that_are_not_whole_tiles():
+    """N_samples + N_surface = 20 + 8 = 28 (padded to 32 inside) against the CPU oracle: outputs and gradients."""
+    import numpy as np
+    from oracle import render_oracle as R
+    from tests.hip_util import DEV, cfg_like, model_from_state, renderer_for
+    from tests.util import GRID_KEYS, load, rel_err, tiny_scene
+    s = load('tiny_scene')
+    bound = torch.from_numpy(s['bound'].copy())
+    model = model_from_state(s, bound)
+    renderer = renderer_for(bound, cfg=cfg_like(n_samples=20, n_surface=8))
+    grids = {k: torch.from_numpy(s[k].copy()).to(DEV).requires_grad_(True) for k in GRID_KEYS}
+    ro = torch.from_numpy(s['rays_o']).to(DEV).requires_grad_(True)
+    rd = torch.from_numpy(s['rays_d']).to(DEV).requires_grad_(True)
+    gd, gc = torch.from_numpy(s['gt_depth']).to(DEV), torch.from_numpy(s['gt_color']).to(DEV)
+    depth, var, color = renderer.render_batch_ray(grids, model, rd, ro, DEV, 'color', gt_depth=gd)
+    (torch.abs(gd - depth)[gd > 0].sum() + 0.2 * torch.abs(gc - color).sum()).backward()
+    params, ogrids, obound, _ = tiny_scene()
+    og = {k: v.requires_grad_(True) for k, v in ogrids.items()}
+    oro = torch.from_numpy(s['rays_o']).requires_grad_(True)
+    ord_ = torch.from_numpy(s['rays_d']).requires_grad_(True)
+    d0, v0, c0 = R.render_batch_ray(params, og, ord_, oro, 'color', obound, gt_depth=torch.from_numpy(s['gt_depth']),
+                                    n_samples=20, n_surface=8)
+    R.mapper_loss(d0, c0, torch.from_numpy(s['gt_depth']), torch.from_numpy(s['gt_color']), 'color').backward()
+    for got, ref in ((depth, d0), (var, v0), (color, c0)):
+        assert rel_err(got.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+    assert rel_err(rd.grad.cpu().numpy(), ord_.grad.numpy()) < 1e-3
+    for k in ('grid_middle', 'grid_fine', 'grid_color'):
+        assert rel_err(grids[k].grad.cpu().numpy(), og[k].grad.numpy()) < 1e-3, k
