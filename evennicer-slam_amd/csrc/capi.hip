@@ -30,16 +30,19 @@ bool build_job(int kind, const enslam_mlp_params& P, bool with_transposed, PackJ
         const XyzLay L{cdim(kind)};
         const int CD = cdim(kind), NO = nout(kind);
         const int kin[5] = {93, 32, 32, 125, 32};
+        // Weight images the kernels read as MFMA fragments are tile-major (4: lds_util.hpp) so that a ds_read_b128 group
+        // covers all 64 banks; the gradient accumulators (with_transposed == false: the unpack direction) stay row-major.
+        const int fs = with_transposed ? 4 : 0;
         add(j, P.B, L.oBT(), 93, 3, 93, 4, 1);                                  // BT[f][k] = B[k][f]
         for (int i = 0; i < 5; ++i) {
             if (i == 3) {
-                add(j, P.W[3], L.oW(3), 32, 93, 125, 128, 0);                     // embedding columns
-                add(j, P.W[3] ? P.W[3] + 93 : nullptr, L.oW(3) + 96, 32, 32, 125, 128, 0);   // h2 columns
+                add(j, P.W[3], L.oW(3), 32, 93, 125, 128, fs);                    // embedding columns
+                add(j, P.W[3] ? P.W[3] + 93 : nullptr, L.oW(3) + (fs ? 6 * 256 : 96), 32, 32, 125, 128, fs);   // h2 columns: column tiles 6, 7
             } else {
-                add(j, P.W[i], L.oW(i), 32, kin[i], kin[i], L.K(i), 0);
+                add(j, P.W[i], L.oW(i), 32, kin[i], kin[i], L.K(i), fs);
             }
             add(j, P.b[i], L.ob(i), 1, 32, 32, 32, 0);
-            add(j, P.Wc[i], L.oWc(i), 32, CD, CD, CD, 0);
+            add(j, P.Wc[i], L.oWc(i), 32, CD, CD, CD, fs);
             add(j, P.bc[i], L.obc(i), 1, 32, 32, 32, 0);
         }
         add(j, P.Wo, L.oWo(), NO, 32, 32, 32, 0);

@@ -232,14 +232,18 @@ ENS_DEV void append_active_tiles_wg(int* tiles, int* count, int64_t ray, int ntl
 // acc[tl][rt] += W[32 x 16*KT] (row-major, leading dim ld) * x[tl][0..KT)   for NTL point tiles.
 // All weight-fragment loads of the call are issued first (independent, distinct registers) and pinned there;
 // the MFMAs then alternate accumulators so that consecutive issues never wait on their own result.
-template <int KT, int NTL, int XS>
+// TM: W is one of the tile-major fragment images of the xyz decoders (lds_util.hpp: unit (rt, t) at rt*16*ld + t*256,
+// lane chunk at frag_off); the coarse decoder's images are plain row-major.
+template <int KT, int NTL, int XS, bool TM = false>
 ENS_DEV void linear32(f32x4 (&acc)[NTL][2], const float* __restrict__ W, int ld, const f32x4 (&x)[NTL][XS], int xoff,
                       int p, int q) {
     f32x4 a[KT][2];
+    const int v = (p >> 1) & 3;
+    const int fo = TM ? 64 * v + 16 * ((p & 1) + 2 * (p >> 3)) + 4 * (q ^ v) : p * ld + 4 * q;
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) a[t][rt] = ldw(W, (16 * rt + p) * ld + 16 * t + 4 * q);
+        for (int rt = 0; rt < 2; ++rt) a[t][rt] = ldw(W, fo + 16 * rt * ld + (TM ? 256 : 16) * t);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -37,6 +37,35 @@ ENS_DEV void lin_lds(f32x4 (&acc)[NR], unsigned base, const f32x4 (&x)[KT]) {
     }
 }
 
+// Forward weight images (W_i, Wc_i of the xyz decoders; 32 rows, LD = 16*KT columns) are stored TILE-MAJOR: for the row
+// tile rt and the column tile t the 16 x 16 block is one 1 KB unit at float offset rt*16*LD + t*256, and inside it row p
+// keeps its four 16-byte chunks together at 64*v + 16*u with v = (p >> 1) & 3 (which 256-byte bank row), u = (p & 1) +
+// 2 * (p >> 3) (which quarter of it), the chunks XOR-ed with v.  The 16 lanes of every ds_read_b128 group then cover all
+// 64 banks (a plain [row][LD] image puts them on 16: 4-way conflicts), and ONE lane base serves every LD because the tile
+// strides are compile-time immediates.  pack_kernel writes this layout (segment flag 4), ring_load copies it verbatim.
+ENS_DEV int frag_off(int p, int q) {                              // float offset of lane (p, q)'s chunk inside a 16 x 16 unit
+    const int v = (p >> 1) & 3, u = (p & 1) + 2 * (p >> 3);
+    return 64 * v + 16 * u + 4 * (q ^ v);
+}
+template <int NR, int KT, int LD, int OFF>
+ENS_DEV void lin_lds_tm(f32x4 (&acc)[NR], unsigned base, const f32x4 (&x)[KT]) {
+    f32x4 a[KT][NR];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt) a[t][rt] = lds4(base + OFF + (16 * rt * LD + 256 * t) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt) acc[rt] = MFMA16(a[t][rt][r], x[t][r], acc[rt]);
+        }
+    }
+}
+
 // Bank-conflict-free images (the backward's transposed matrices, rows of 32 or 96 floats): the 16-byte chunk c of row r
 // sits at chunk  c ^ ((r & 15) >> 1)  of its row (packed that way by pack_kernel, copied verbatim by ring_load).  A
 // plain [row][32] image puts the 16 lanes of one ds_read_b128 group on 4 bank groups (4-way conflict); with the XOR

@@ -704,15 +704,14 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
         STAMP(0)        // tile geometry + d_raw load + vote barrier
 
         // per-lane LDS bases of this round (opaque: see above)
-        unsigned w32 = lds0 + (p * 32 + 4 * q) * 4, w96 = lds0 + (p * 96 + 4 * q) * 4, w128 = lds0 + (p * 128 + 4 * q) * 4;
-        unsigned wcd = lds0 + (p * CD + 4 * q) * 4, wq = lds0 + q * 16;
+        unsigned wt = lds0 + frag_off(p, q) * 4, wq = lds0 + q * 16;            // forward images: tile-major (lds_util.hpp)
         unsigned dep = lds0 + RING_BYTES + (wave * SLOT + (p >> 2) * 64 + (p & 3) + 16 * q) * 4;
         unsigned fb[4];
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
         unsigned w32s = swz_base_even(lds0, 32, p, q);               // transposed (swizzled) images: lds_util.hpp
         const unsigned swd = swz_odd_delta(p);
-        opaque(w32); opaque(w96); opaque(w128); opaque(wcd); opaque(wq); opaque(dep); opaque(w32s);
+        opaque(wt); opaque(wq); opaque(dep); opaque(w32s);
 
         // ---- recompute the forward chain (weights of layer i from ring buffer i&1, next chunk in flight)
         const float pc = q == 0 ? (float)G.pw[0] : (q == 1 ? (float)G.pw[1] : (q == 2 ? (float)G.pw[2] : 0.f));
@@ -745,17 +744,17 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
             acc[0] = lds4(wq + OB);
             acc[1] = lds4(wq + OB + 64);
             if constexpr (i == 0) {
-                lin_lds<2, 6, 96, RO>(acc, w96, emb);
+                lin_lds_tm<2, 6, 96, RO>(acc, wt, emb);
             } else if constexpr (i == 3) {
-                lin_lds<2, 6, 128, RO>(acc, w128, emb);
-                lin_lds<2, 2, 128, RO + 96 * 4>(acc, w128, h[2]);
+                lin_lds_tm<2, 6, 128, RO>(acc, wt, emb);
+                lin_lds_tm<2, 2, 128, RO + 6 * 256 * 4>(acc, wt, h[2]);
             } else {
-                lin_lds<2, 2, 32, RO>(acc, w32, h[i - 1]);
+                lin_lds_tm<2, 2, 32, RO>(acc, wt, h[i - 1]);
             }
             mbits[i] = pos_bits(acc[0]) | (pos_bits(acc[1]) << 4);
             acc[0] = relu4(acc[0]) + lds4(wq + OBC);
             acc[1] = relu4(acc[1]) + lds4(wq + OBC + 64);
-            lin_lds<2, CT, CD, OC>(acc, wcd, c);
+            lin_lds_tm<2, CT, CD, OC>(acc, wt, c);
             h[i][0] = acc[0];
             h[i][1] = acc[1];
             if constexpr (i == 4) {

@@ -35,12 +35,16 @@ ENS_DEV void ws_store_dep(float* __restrict__ ws_tile, const f32x4& x, float* st
     // global_load_lds by addressing was tried: forward -2.6 us, backward +10 us -- the strided 16-byte source runs cost
     // more than the LDS round trip here, which other waves hide.  Four scattered dword stores per tile straight into
     // the deposit layout, without the LDS round trip: no gain either, 0.346 vs 0.339 ms per step)
-    float* d = stage + (p >> 2) * 64 + (p & 3) + 16 * q;
+    // The 16-byte chunk (4q + r) of sample group P = p >> 2 sits at chunk (4q + r) ^ P of its 64-float row: written plainly,
+    // the 32 lanes of a ds_write_b32 group would land on 8 banks (4-way); with the XOR they cover all 32, and the
+    // ds_read_b128 below (lane 16P + f reads chunk f ^ P) stays conflict-free.
+    const int P = p >> 2;
+    float* d = stage + P * 64 + (p & 3) + 16 * q;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) d[4 * r] = x[r];
+    for (int r = 0; r < 4; ++r) d[4 * (r ^ P)] = x[r];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + lane * 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (lane ^ (lane >> 4)) * 4);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     *reinterpret_cast<f32x4*>(ws_tile + lane * 4) = v;
@@ -63,12 +67,12 @@ ENS_DEV void xyz_layer(const float* __restrict__ pk, const f32x4 (&emb)[NTL][6],
         for (int tl = 0; tl < NTL; ++tl) acc[tl][rt] = b;
     }
     if constexpr (I == 0) {
-        linear32<6, NTL, 6>(acc, pk + L.oW(0), 96, emb, 0, p, q);
+        linear32<6, NTL, 6, true>(acc, pk + L.oW(0), 96, emb, 0, p, q);
     } else if constexpr (I == 3) {
-        linear32<6, NTL, 6>(acc, pk + L.oW(3), 128, emb, 0, p, q);
-        linear32<2, NTL, 2>(acc, pk + L.oW(3) + 96, 128, h, 0, p, q);
+        linear32<6, NTL, 6, true>(acc, pk + L.oW(3), 128, emb, 0, p, q);
+        linear32<2, NTL, 2, true>(acc, pk + L.oW(3) + 6 * 256, 128, h, 0, p, q);
     } else {
-        linear32<2, NTL, 2>(acc, pk + L.oW(I), 32, h, 0, p, q);
+        linear32<2, NTL, 2, true>(acc, pk + L.oW(I), 32, h, 0, p, q);
     }
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
@@ -81,7 +85,7 @@ ENS_DEV void xyz_layer(const float* __restrict__ pk, const f32x4 (&emb)[NTL][6],
 #pragma unroll
         for (int tl = 0; tl < NTL; ++tl) acc[tl][rt] = relu4(acc[tl][rt]) + bc;
     }
-    linear32<CT, NTL, CT>(acc, pk + L.oWc(I), CT * 16, c, 0, p, q);
+    linear32<CT, NTL, CT, true>(acc, pk + L.oWc(I), CT * 16, c, 0, p, q);
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
         h[tl][0] = acc[tl][0];
@@ -363,8 +367,8 @@ constexpr int fwd_ring_lds_bytes(int stage) { return (2 * fwd_ring_floats(stage)
 // layer 0 follows in the ring (nullptr: none).  NEXT_CD: its fc_c width.
 template <int CT, int C0, int RB, int NEXT_CD>
 ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict__ pk_next, float* ring, float pc,
-                          const f32x4 (&c)[CT], f32x4& o, float* ws, bool wl, float* stage, unsigned w32, unsigned w96,
-                          unsigned w128, unsigned wcd, unsigned wq, int wave, int lane, int p, int q, StampCtx& sx) {
+                          const f32x4 (&c)[CT], f32x4& o, float* ws, bool wl, float* stage, unsigned wt, unsigned wq, int wave, int lane, int p, int q,
+                          StampCtx& sx) {
     constexpr XyzLay L{CT * 16};
     constexpr int CD = CT * 16;
     f32x4 emb[6];
@@ -403,18 +407,18 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
         acc[0] = lds4(wq + OB);
         acc[1] = lds4(wq + OB + 64);
         if constexpr (i == 0) {
-            lin_lds<2, 6, 96, RO>(acc, w96, emb);
+            lin_lds_tm<2, 6, 96, RO>(acc, wt, emb);
         } else if constexpr (i == 3) {
-            lin_lds<2, 6, 128, RO>(acc, w128, emb);
-            lin_lds<2, 2, 128, RO + 96 * 4>(acc, w128, h[2]);
+            lin_lds_tm<2, 6, 128, RO>(acc, wt, emb);
+            lin_lds_tm<2, 2, 128, RO + 6 * 256 * 4>(acc, wt, h[2]);
         } else {
-            lin_lds<2, 2, 32, RO>(acc, w32, h[i - 1]);
+            lin_lds_tm<2, 2, 32, RO>(acc, wt, h[i - 1]);
         }
         const unsigned bits = fwd_pos_bits(acc[0]) | (fwd_pos_bits(acc[1]) << 4);
         if constexpr (i < 4) mb0 |= bits << (8 * i); else mb1 = bits;
         acc[0] = relu4(acc[0]) + lds4(wq + OBC);
         acc[1] = relu4(acc[1]) + lds4(wq + OBC + 64);
-        lin_lds<2, CT, CD, OC>(acc, wcd, c);
+        lin_lds_tm<2, CT, CD, OC>(acc, wt, c);
         h[i][0] = acc[0];
         h[i][1] = acc[1];
         FST(sx, 3)  // layer: prefetch issue, bias, fragment reads + MFMAs, relu
@@ -486,6 +490,14 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     const int role = SPLIT ? (int)((blockIdx.x >> 3) & 1) : 0;               // 0: occupancy decoders, 1: colour decoder
     const int64_t grp = SPLIT ? (int64_t)(blockIdx.x >> 4) * 8 + (blockIdx.x & 7) : (int64_t)blockIdx.x;
     if (grp * 4 >= n_tiles) return;                                            // (whole workgroup: padding of the split grid)
+#ifdef ENS_EXP_FWD_STAGGER
+    // A/B only: start the workgroups that share a CU a fraction of a layer apart (ENS_EXP_FWD_STAGGER units of 2048 cycles),
+    // under the two plausible placements of a one-round launch (ENS_EXP_FWD_STAGGER_MAP 0: CU-major, 1: consecutive on a CU).
+    {
+        const int ph = (ENS_EXP_FWD_STAGGER_MAP == 0 ? (int)(blockIdx.x >> 8) : (int)(blockIdx.x >> 3)) % 3;
+        for (int i = 0; i < ph * ENS_EXP_FWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     const bool wl = wli != 0;
     const int WSS = wl ? ACTL_STRIDE : ACT_STRIDE, WSV = wl ? ACTL_VOX : ACT_VOX;
     StampCtx sx;
@@ -515,9 +527,9 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     const float pc = q == 0 ? (float)pw[0] : (q == 1 ? (float)pw[1] : (q == 2 ? (float)pw[2] : 0.f));
 
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)fsm;
-    unsigned w32 = lds0 + (p * 32 + 4 * q) * 4, w64 = lds0 + (p * 64 + 4 * q) * 4, w96 = lds0 + (p * 96 + 4 * q) * 4;
-    unsigned w128 = lds0 + (p * 128 + 4 * q) * 4, wq = lds0 + q * 16;
-    opaque(w32); opaque(w64); opaque(w96); opaque(w128); opaque(wq);
+    // lane base of the tile-major weight images (lds_util.hpp) and of the bias rows
+    unsigned wt = lds0 + frag_off(p, q) * 4, wq = lds0 + q * 16;
+    opaque(wt); opaque(wq);
 
     float* wsb = (act_ws != nullptr && tvalid) ? act_ws + (tile * ACT_SLOTS) * (int64_t)WSS : nullptr;
     f32x4 occ = splat4(0.f), col = splat4(0.f);
@@ -533,7 +545,7 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
         __syncthreads();                                                                   // chunk 0 landed
         FST(sx, 5)
         mlp_xyz_ring<2, 0, RB, (STAGE >= 2 ? 64 : 0)>(sc.packed[1], STAGE >= 2 ? sc.packed[2] : nullptr, ring, pc, cm, occ, wsb,
-                                                       wl, stage, w32, w96, w128, w32, wq, wave, lane, p, q, sx);
+                                                       wl, stage, wt, wq, wave, lane, p, q, sx);
         if constexpr (STAGE >= 2) {
             f32x4 cf[4];
             {
@@ -546,8 +558,8 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
             FST(sx, 7)  // later gathers
             f32x4 of;
             mlp_xyz_ring<4, 5, RB, ((STAGE == 3 && !SPLIT) ? 32 : 0)>(sc.packed[2], (STAGE == 3 && !SPLIT) ? sc.packed[3] : nullptr,
-                                                                     ring, pc, cf, of, wsb ? wsb + WSS : nullptr, wl, stage, w32,
-                                                                     w96, w128, w64, wq, wave, lane, p, q, sx);
+                                                                     ring, pc, cf, of, wsb ? wsb + WSS : nullptr, wl, stage, wt,
+                                                                     wq, wave, lane, p, q, sx);
             occ[0] = of[0] + occ[0];                                                        // fine_occ + middle_occ
         }
     }
@@ -565,7 +577,7 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
                 FST(sx, 5)
             }
             mlp_xyz_ring<2, 10, RB, 0>(sc.packed[3], nullptr, ring, pc, cc, col, wsb ? wsb + 2 * WSS : nullptr, wl, stage,
-                                       w32, w96, w128, w32, wq, wave, lane, p, q, sx);
+                                       wt, wq, wave, lane, p, q, sx);
         }
     }
     if (q == 0 && tvalid) {                                                             // rows 0..3 live on q == 0 lanes

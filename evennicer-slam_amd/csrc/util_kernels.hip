@@ -601,7 +601,12 @@ ENS_DEV void pack_body(const PackJob& job, float* __restrict__ packed, int unpac
         const int r = e / s.cols, c = e - r * s.cols;
         float* src = s.src + ((s.transpose & 1) ? (int64_t)c * s.src_ld + r : (int64_t)r * s.src_ld + c);
         const int cs = (s.transpose & 2) ? ((((c >> 2) ^ ((r & 15) >> 1)) << 2) | (c & 3)) : c;   // lds_util.hpp: swizzled image
-        float* dst = (job.packed[s.dec] ? job.packed[s.dec] : packed) + s.off + r * s.dst_ld + cs;
+        int at = r * s.dst_ld + cs;
+        if (s.transpose & 4) {                                                                   // lds_util.hpp: tile-major image
+            const int pp = r & 15, v = (pp >> 1) & 3, u = (pp & 1) + 2 * (pp >> 3);
+            at = (r >> 4) * 16 * s.dst_ld + (c >> 4) * 256 + 64 * v + 16 * u + 4 * (((c >> 2) & 3) ^ v) + (c & 3);
+        }
+        float* dst = (job.packed[s.dec] ? job.packed[s.dec] : packed) + s.off + at;
         if (unpack) *src = *dst; else *dst = *src;
     }
 }
