@@ -1141,12 +1141,14 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
             constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);      // input h_{i-1} of layers 4, 2, 1
             f32x4 dpre[2] = {mask4(dh[0], mbits[i], 0), mask4(dh[1], mbits[i], 4)};
+            STAMP(2)    // (stamps build: the previous layer's dX results have arrived)
             if constexpr (SPLIT) {
                 // the dh / dpre tiles of this parity still hold layer i+2's operands: its owned products must have read them
                 if constexpr (i <= 2) sy_wait(SY_DW + i + 2, 4 * (int)(r_exec + 1));
                 // ... and the H1 tiles the previous tile's dC was staged in: the dW waves must have taken it
                 if constexpr (i == 3) { if (want_g) sy_wait(SY_STGDONE, 4 * (int)r_exec); }
             }
+            STAMP(4)    // (stamps build: waits for the dW waves' reads)
             if (want_w) {
                 dep_tile<TH>(dep, dh[0]); dep_tile<TH + 1>(dep, dh[1]);
                 dep_tile<TP>(dep, dpre[0]); dep_tile<TP + 1>(dep, dpre[1]);
@@ -1383,15 +1385,19 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         sri = __builtin_bit_cast(int, r0); srx = __builtin_bit_cast(int, r1); sry = __builtin_bit_cast(int, r2); srz = __builtin_bit_cast(int, r3);
         sst.acc[0] = sst.acc[1] = sst.acc[2] = sst.acc[3] = 0.f; sst.cur = 0u; sst.open = false;
     };
+    STAMP_DECL
+    STAMP_START
     auto own = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
         constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);
         sy_wait(SY_DEP + i, 4 * (int)(r_exec + 1));                 // layer i's deposits are in place
+        STAMP(2)        // (stamps build) wait for the chain waves' deposits
         if constexpr (i == 4) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's slot fill has landed
             sy_signal(SY_FILL, lane);
             sy_wait(SY_FILL, 4 * (int)(r_exec + 1));                // all four slots filled
+            STAMP(3)    // slot fill landed
         }
 #ifdef ENS_EXP_NO_DW
         sy_signal(SY_DW + i, lane);
@@ -1410,6 +1416,7 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
             own_layer_a<CT / 2, 1>(aWc[i], TH, SL::C, CT, 2 * CT, aW4, TP, TX, 2, 4, aB[i], ybias, fb, ow);
         }
         sy_signal(SY_DW + i, lane);                                  // (the operand reads have returned: lgkmcnt(0) inside)
+        STAMP(4)        // owned products
         // one 4-sample piece of the previous tile's scatter behind each of layers 4..1: the chain waves are not waiting for it
         if (want_g && r_exec > 0) {
             if constexpr (i == 4) {
@@ -1425,12 +1432,14 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
                 if (sst.open) scatter_flush(sst, ggrid, lane, 15, 0);
             }
         }
+        STAMP(5)        // scatter piece
     };
     for (int64_t base = (int64_t)wg * 4; base < n_tiles; base += stride) {
         const int par = (int)(round_no & 1);
         ++round_no;
         wg_barrier_lds();                   // vote (the one workgroup barrier of a round)
         const int any4 = ens_vote[par][0] | ens_vote[par][1] | ens_vote[par][2] | ens_vote[par][3];
+        STAMP(0)        // vote barrier
         if (!any4) continue;
         const int64_t tr = base + ow;
         const int64_t tile = work_tile(A, tr < n_tiles ? tr : n_tiles - 1);
@@ -1442,12 +1451,23 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsb + t * 256 + lane * 4),
                                                  (__attribute__((address_space(3))) void*)(myslot + t * 256), 16, 0, 0);
         }
+        STAMP(1)        // fill issue
         own(IC(4)); own(IC(3)); own(IC(2)); own(IC(1)); own(IC(0));
         sy_wait(SY_DARG, 4 * (int)(r_exec + 1));                     // the chain waves have deposited d_arg (tiles HX2..HX1)
+        STAMP(6)        // wait for d_arg
         own_outer_a<2>(aBT, fb, SL::HX2, SL::Q, 1, 6, ow);                                         // dB^T
         tile_prev = tile;
         ++r_exec;
+        STAMP(7)        // dB^T
     }
+#ifdef ENS_STAMPS
+    if (g_stamp_buf && lane == 0) {         // dW waves: second half of the stamp buffer (s_memrealtime span in the last slot)
+        unsigned long long rt1_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1_)::"memory");
+        st_acc[ENS_NSEG - 1] = rt1_ - st_rt0;
+        for (int k_ = 0; k_ < ENS_NSEG; ++k_) g_stamp_buf[((size_t)(gridDim.x + blockIdx.x) * 4 + ow) * ENS_NSEG + k_] = st_acc[k_];
+    }
+#endif
     if (want_g && r_exec > 0) {                                       // the last executed round's tile
         take_staged((int)r_exec);
         scatter_piece<0>(sst, sval, sri, srx, sry, srz, ggrid, lane);

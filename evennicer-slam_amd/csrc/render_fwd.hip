@@ -479,25 +479,29 @@ constexpr bool fwd_split_roles(int stage) { return stage == 3; }
 constexpr bool fwd_split_roles(int) { return false; }
 #endif
 
+#ifndef ENS_FWD_STAGGER
+#define ENS_FWD_STAGGER 2          // units of 2048 cycles; -DENS_FWD_STAGGER=0 switches the start offsets off
+#endif
 template <int STAGE>
 __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles, int tiles_per_ray,
                                                                  const float* __restrict__ rays_o,
                                                                  const float* __restrict__ rays_d,
                                                                  const double* __restrict__ z_vals, DevScene sc,
-                                                                 float* __restrict__ raw_out, float* __restrict__ act_ws, int wli) {
+                                                                 float* __restrict__ raw_out, float* __restrict__ act_ws, int wli, int stag_cus) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     constexpr bool SPLIT = fwd_split_roles(STAGE);
     const int role = SPLIT ? (int)((blockIdx.x >> 3) & 1) : 0;               // 0: occupancy decoders, 1: colour decoder
     const int64_t grp = SPLIT ? (int64_t)(blockIdx.x >> 4) * 8 + (blockIdx.x & 7) : (int64_t)blockIdx.x;
     if (grp * 4 >= n_tiles) return;                                            // (whole workgroup: padding of the split grid)
-#ifdef ENS_EXP_FWD_STAGGER
-    // A/B only: start the workgroups that share a CU a fraction of a layer apart (ENS_EXP_FWD_STAGGER units of 2048 cycles),
-    // under the two plausible placements of a one-round launch (ENS_EXP_FWD_STAGGER_MAP 0: CU-major, 1: consecutive on a CU).
-    {
-        const int ph = (ENS_EXP_FWD_STAGGER_MAP == 0 ? (int)(blockIdx.x >> 8) : (int)(blockIdx.x >> 3)) % 3;
-        for (int i = 0; i < ph * ENS_EXP_FWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+    // One-round launches (every workgroup resident at once, three per CU: the mapper's 1000 rays): the three workgroups of
+    // a CU start together and stay in phase -- all in their MFMA stretch, then all in their gather / sin / store stretch.
+    // Starting the second and third one ENS_FWD_STAGGER x 2048 cycles later (a third and two thirds of a layer's period)
+    // keeps them apart: 288.8 / 291.4 -> 282.0 / 284.5 us per step, same box.  stag_cus = 0: launch of several
+    // rounds, where a late start only wastes the slot.  Workgroups are placed CU-major, so blockIdx / CUs is the slot.
+    if (stag_cus > 0) {
+        const int ph = (int)(blockIdx.x / (unsigned)stag_cus) % 3;
+        for (int i = 0; i < ph * ENS_FWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
     }
-#endif
     const bool wl = wli != 0;
     const int WSS = wl ? ACTL_STRIDE : ACT_STRIDE, WSV = wl ? ACTL_VOX : ACT_VOX;
     StampCtx sx;
@@ -753,9 +757,16 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
         const int64_t groups = (n_units + 3) / 4;
         // colour stage: two roles per group of 4 tiles, interleaved in runs of 8 blocks (render_fwd_ring_kernel)
         const dim3 grid((unsigned)(fwd_split_roles(stage) ? ((groups + 7) / 8) * 16 : groups)), block(256);
-        if (stage == 1) render_fwd_ring_kernel<1><<<grid, block, fwd_ring_lds_bytes(1), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
-        else if (stage == 2) render_fwd_ring_kernel<2><<<grid, block, fwd_ring_lds_bytes(2), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
-        else render_fwd_ring_kernel<3><<<grid, block, fwd_ring_lds_bytes(3), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light);
+        static const int cus = [] {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+            return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }();
+        const int stag = (ENS_FWD_STAGGER > 0 && !fwd_split_roles(stage) && grid.x <= (unsigned)(3 * cus)) ? cus : 0;
+        if (stage == 1) render_fwd_ring_kernel<1><<<grid, block, fwd_ring_lds_bytes(1), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag);
+        else if (stage == 2) render_fwd_ring_kernel<2><<<grid, block, fwd_ring_lds_bytes(2), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag);
+        else render_fwd_ring_kernel<3><<<grid, block, fwd_ring_lds_bytes(3), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag);
         if (hipGetLastError() != hipSuccess) return -2;
         return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st, ls, wl);
     }

@@ -3,10 +3,10 @@
 #ifdef ENS_STAMPS
 #define ENS_NSEG 12
 static __device__ unsigned long long* g_stamp_buf = nullptr;      // one per translation unit (each has its own setter)
-#define STAMP_DECL unsigned long long st_acc[ENS_NSEG] = {}; unsigned long long st_prev = 0;
-#define STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP_DECL unsigned long long st_acc[ENS_NSEG] = {}; unsigned long long st_prev = 0; unsigned long long st_rt0 = 0;
+#define STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory"); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory"); __builtin_amdgcn_sched_barrier(0); }
 #define STAMP(k) { unsigned long long st_now; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); __builtin_amdgcn_sched_barrier(0); st_acc[k] += st_now - st_prev; st_prev = st_now; }
-#define STAMP_FLUSH { if (g_stamp_buf && lane == 0) { for (int k_ = 0; k_ < ENS_NSEG; ++k_) g_stamp_buf[((size_t)blockIdx.x * 4 + wave) * ENS_NSEG + k_] = st_acc[k_]; } }
+#define STAMP_FLUSH { { unsigned long long rt1_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1_)::"memory"); st_acc[ENS_NSEG - 1] = rt1_ - st_rt0; } if (g_stamp_buf && lane == 0) { for (int k_ = 0; k_ < ENS_NSEG; ++k_) g_stamp_buf[((size_t)blockIdx.x * 4 + wave) * ENS_NSEG + k_] = st_acc[k_]; } }
 #else
 #define STAMP_DECL
 #define STAMP_START

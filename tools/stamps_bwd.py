@@ -6,7 +6,7 @@ import numpy as np, torch, bench
 import evennicer_slam_amd as E
 import evennicer_slam_amd.functional as EF
 NSEG = 12
-names = ["d_raw+vote", "deferred scatter", "embedding", "fill issue + h4/mask loads", "deposits(fwd)", "barrier waits", "layer deposits(+prev dX)",
+names = ["d_raw+vote", "deferred scatter", "previous dX arrives", "fill issue + h4/mask loads", "wait for dW reads", "ring waits", "layer deposits",
          "owned dW MFMAs", "tail dX", "emb tail", "coord+scatter+rays", "-"]
 dev = torch.device('cuda', 0)
 lib = E._lib.lib()
@@ -17,7 +17,7 @@ grids = {k: v.to(dev).requires_grad_(True) for k, v in sc['grids'].items()}
 ro, rd, gd, gc = [t.to(dev) for t in rays]
 ro.requires_grad_(True); rd.requires_grad_(True)
 renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **bench.CAM))
-buf = torch.zeros(256 * 4 * NSEG, dtype=torch.int64, device=dev)
+buf = torch.zeros(2 * 256 * 4 * NSEG, dtype=torch.int64, device=dev)
 handle = ctypes.CDLL(E.LIB_PATH)
 assert handle.enslam_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
 for i in range(5):
@@ -25,12 +25,23 @@ for i in range(5):
     d, v, c = renderer.render_batch_ray(grids, model, rd, ro, dev, 'color', gt_depth=gd)
     E.losses.rgbd_loss(d, c, gd, gc, 0.2).backward()
 torch.cuda.synchronize()
-st = buf.cpu().numpy().reshape(256, 4, NSEG).astype(np.float64)
+both = buf.cpu().numpy().reshape(2, 256, 4, NSEG).astype(np.float64)
+st, sd = both[0], both[1]
 # role ranges as in ens_launch_decoder_bwd: 0.30 / 0.40 / 0.30 of 256 workgroups
 r0 = 75; r1 = r0 + 94          # split chosen by the launcher for 3000 tiles (see ens_launch_decoder_bwd)
 for name, sl in (("middle", slice(0, r0)), ("fine", slice(r0, r1)), ("color", slice(r1, 256))):
     s = st[sl].reshape(-1, NSEG)
-    tot = s.sum(1)
+    tot = s[:, :NSEG - 1].sum(1)
     print(f"role {name}: waves {s.shape[0]}, cycles per wave mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f}) = {tot.mean()/2.4e3:.0f} us @2.4GHz")
+    rt = s[:, NSEG - 1].mean(); cyc = s[:, :NSEG - 1].sum(1).mean()
+    print(f"    s_memrealtime (100 MHz) {rt:.0f} ticks = {rt / 100:.1f} us; s_memtime {cyc:.0f} ticks -> {cyc / max(rt, 1) * 100:.0f} MHz")
     for k in range(NSEG - 1):
         print(f"    {names[k]:28s} {s[:, k].mean():10.0f} cycles  {100 * s[:, k].mean() / tot.mean():5.1f} %")
+
+dnames = ["vote barrier", "fill issue", "wait for deposits", "slot fill landed", "owned products", "scatter piece", "wait for d_arg", "dB^T", "-", "-", "-", "-"]
+for name, sl in (("middle", slice(0, r0)), ("fine", slice(r0, r1)), ("color", slice(r1, 256))):
+    s = sd[sl].reshape(-1, NSEG)
+    tot = s.sum(1)
+    print(f"dW waves, role {name}: cycles per wave mean {tot.mean():.0f} (before the flush)")
+    for k in range(8):
+        print(f"    {dnames[k]:28s} {s[:, k].mean():10.0f} cycles  {100 * s[:, k].mean() / tot.mean():5.1f} %")
