@@ -480,7 +480,7 @@ constexpr bool fwd_split_roles(int) { return false; }
 #endif
 
 #ifndef ENS_FWD_STAGGER
-#define ENS_FWD_STAGGER 2          // units of 2048 cycles; -DENS_FWD_STAGGER=0 switches the start offsets off
+#define ENS_FWD_STAGGER 0          // units of 2048 cycles (A/B aid, see the kernel)
 #endif
 template <int STAGE>
 __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles, int tiles_per_ray,
@@ -493,11 +493,10 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     const int role = SPLIT ? (int)((blockIdx.x >> 3) & 1) : 0;               // 0: occupancy decoders, 1: colour decoder
     const int64_t grp = SPLIT ? (int64_t)(blockIdx.x >> 4) * 8 + (blockIdx.x & 7) : (int64_t)blockIdx.x;
     if (grp * 4 >= n_tiles) return;                                            // (whole workgroup: padding of the split grid)
-    // One-round launches (every workgroup resident at once, three per CU: the mapper's 1000 rays): the three workgroups of
-    // a CU start together and stay in phase -- all in their MFMA stretch, then all in their gather / sin / store stretch.
-    // Starting the second and third one ENS_FWD_STAGGER x 2048 cycles later (a third and two thirds of a layer's period)
-    // keeps them apart: 288.8 / 291.4 -> 282.0 / 284.5 us per step, same box.  stag_cus = 0: launch of several
-    // rounds, where a late start only wastes the slot.  Workgroups are placed CU-major, so blockIdx / CUs is the slot.
+    // A/B aid (-DENS_FWD_STAGGER=n, off by default): in a one-round launch (every workgroup resident at once, three per CU)
+    // start the second and third workgroup of a CU n x 2048 cycles later, to keep their MFMA and gather / sin / store
+    // stretches apart.  Measured per kernel on one box (tools/ab_kernels.sh): 82.6 us without, 85.6 / 85.8 / 86.9 us with
+    // n = 1 / 2 / 3 -- the late starters finish later by more than the others gain.
     if (stag_cus > 0) {
         const int ph = (int)(blockIdx.x / (unsigned)stag_cus) % 3;
         for (int i = 0; i < ph * ENS_FWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
