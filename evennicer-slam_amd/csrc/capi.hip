@@ -249,7 +249,7 @@ static bool work_list_of(int32_t* tiles, int32_t* count, WorkList& w) {
 }
 static int step_finish_impl(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
                             const uint8_t* const* need, int32_t n_dec, const int32_t* kinds, const float* const* packed_grads,
-                            const enslam_mlp_params* grads, const RayGradArgs* rg, void* stream) {
+                            const enslam_mlp_params* grads, const RayGradArgs* rg, void* stream, uint8_t* const* prev = nullptr) {
     if (n_dec < 0 || n_dec > 4 || n_conv < 0 || n_conv > 4) return ENSLAM_EINVAL;
     PackJob pj;
     clear_job(pj);
@@ -268,7 +268,7 @@ static int step_finish_impl(int32_t n_conv, const float* const* src, float* cons
         if (!need) return ENSLAM_EINVAL;
         for (int i = 0; i < n_conv; ++i)
             if (!need[i]) return ENSLAM_EINVAL;
-        if (!make_conv_job(n_conv, src, dst, n_voxels, need, nullptr, true, cj)) return ENSLAM_EINVAL;
+        if (!make_conv_job(n_conv, src, dst, n_voxels, need, need ? prev : nullptr, true, cj)) return ENSLAM_EINVAL;
     }
     return ens_launch_step(pj, true, cj, false, zj, nullptr, 0, rg, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
@@ -297,6 +297,32 @@ int enslam_step_finish_rays(int32_t n_conv, const float* const* src, float* cons
                            work_list ? &wl : nullptr))
         return ENSLAM_EINVAL;
     return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, &rg, stream);
+}
+int enslam_step_finish_rays_prev(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                                 const uint8_t* const* need, uint8_t* const* prev, int32_t n_dec, const int32_t* kinds,
+                                 const float* const* packed_grads, const enslam_mlp_params* grads, int32_t stage, int32_t n_rays,
+                                 int32_t n_samples, const float* rays_o, const float* rays_d, const double* z_vals,
+                                 const enslam_scene* scene, float* dgrid_ws, float* g_rays_o, float* g_rays_d,
+                                 const int32_t* work_list, const int32_t* work_count, void* stream) {
+    if (n_rays < 0) return ENSLAM_EINVAL;
+    if (prev != nullptr) {
+        if (!need || n_conv < 0 || n_conv > 4) return ENSLAM_EINVAL;
+        for (int i = 0; i < n_conv; ++i)
+            if (!need[i] || !prev[i]) return ENSLAM_EINVAL;
+    }
+    if (n_rays == 0 || stage == ENSLAM_STAGE_COARSE)
+        return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, nullptr, stream, prev);
+    if (!samples_ok(n_samples)) return ENSLAM_EUNSUPPORTED;
+    DevScene d;
+    if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
+    if (!rays_o || !rays_d || !z_vals || !dgrid_ws || !g_rays_o || !g_rays_d) return ENSLAM_EINVAL;
+    RayGradArgs rg;
+    WorkList wl;
+    if (!work_list_of(const_cast<int32_t*>(work_list), const_cast<int32_t*>(work_count), wl)) return ENSLAM_EINVAL;
+    if (!ens_ray_grad_args(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, dgrid_ws, g_rays_o, g_rays_d, rg,
+                           work_list ? &wl : nullptr))
+        return ENSLAM_EINVAL;
+    return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, &rg, stream, prev);
 }
 
 int enslam_grids_convert(int32_t n, const float* const* src, float* const* dst, const int64_t* n_voxels,

@@ -395,6 +395,17 @@ ENS_DEV void convert_body(const ConvJob& job, int to_vm, int b) {
             if (valid != nullptr && threadIdx.x == 0) valid[blk] = 1;
             return;
         }
+        // Gradient direction with a PERSISTENT destination (job.valid = the flags of the launch that wrote this very buffer
+        // last, or null): an untouched block that was untouched then as well still holds its zeros -- nothing to write.
+        // Under hipGraph replay the dense gradient of a grid is the same memory every step, so the 48 MB zero-fill of the
+        // untouched blocks shrinks to the blocks that were touched one step earlier; the flags move to job.valid on the way.
+        uint8_t* prev = job.valid[g];
+        const bool was = prev != nullptr && prev[blk] != 0;
+        if (prev != nullptr) {
+            if (!needed && !was) return;
+            __syncthreads();                                 // (block-uniform) every thread has read prev[blk]
+            if (threadIdx.x == 0 && was != needed) prev[blk] = needed ? 1 : 0;
+        }
         if (!needed) {                                       // untouched block of a gradient: zeros, nothing read
             const int64_t v0 = blk * 64, V = job.V[g];
             float* dst = job.dst[g];

@@ -36,7 +36,7 @@ def _ptr(t):
 # in the graph's private memory pool and only hold data once that graph has been replayed; every replay rewrites them
 # with the values its inputs had at the START of the replay.  They are therefore tagged with the capture they were made
 # in and are invisible to everything outside that capture (an eager render after replays re-packs from the live tensors).
-_capture = {'epoch': 0, 'active': 0, 'raw_writes': None}
+_capture = {'epoch': 0, 'active': 0, 'raw_writes': None, 'init_zero': None}
 
 
 def _capturing():
@@ -57,12 +57,18 @@ def begin_capture():
     _capture['epoch'] += 1
     _capture['active'] = _capture['epoch']
     _capture['raw_writes'] = []
+    _capture['init_zero'] = []
 
 
 def end_capture():
     """-> the tensors that kernels of the captured step write behind torch's back (note_raw_write)."""
     log, _capture['raw_writes'] = _capture['raw_writes'] or [], None
     _capture['active'] = 0
+    # persistent gradient tensors of the captured step and their block flags (see _RenderFn.backward): the protocol starts
+    # from all-zero memory; filled here, eagerly, once -- a fill inside the capture would run at every replay
+    init, _capture['init_zero'] = _capture['init_zero'] or [], None
+    for storage in init:
+        torch.empty(0, dtype=torch.uint8, device=storage.device).set_(storage).zero_()
     seen, out = set(), []
     for t in log:
         if id(t) not in seen:
@@ -836,10 +842,22 @@ class _RenderFn(torch.autograd.Function):
         nc = len(conv)
         srcs, dsts, vs = (ctypes.c_void_p * max(nc, 1))(), (ctypes.c_void_p * max(nc, 1))(), (ctypes.c_int64 * max(nc, 1))()
         need_ptrs = (ctypes.c_void_p * max(nc, 1))()
+        # Under hipGraph capture the dense gradient of a grid is the same memory at every replay: the finish launch then only
+        # rewrites the blocks touched now or one replay earlier (enslam_step_finish_rays_prev) instead of zero-filling the
+        # ~85 % of the tensor no ray came near.  The buffers start zeroed by end_capture(); only their STORAGES are kept
+        # there (a second reference to the tensor itself would make AccumulateGrad clone the 16 MB instead of adopting it).
+        persistent = _capturing() and _capture['init_zero'] is not None and nc > 0
+        prev_ptrs = (ctypes.c_void_p * max(nc, 1))() if persistent else None
+        prev_keep = []
         for j, (i, k) in enumerate(conv):
             g = torch.empty(ctx.grid_shapes[i], dtype=torch.float32, device=dev)
             grid_out[k] = g
             srcs[j], dsts[j], vs[j], need_ptrs[j] = g_grids_vm[k], g.data_ptr(), sizes[i] // 32, flags[i].data_ptr()
+            if persistent:
+                pv = torch.empty(flags[i].numel(), dtype=torch.uint8, device=dev)
+                prev_ptrs[j] = pv.data_ptr()
+                prev_keep.append(pv)
+                _capture['init_zero'] += [g.untyped_storage(), pv.untyped_storage()]
         for k in plan.kinds:
             out.append(grid_out.get(k))
         pm = iter(ctx.param_meta)
@@ -857,7 +875,12 @@ class _RenderFn(torch.autograd.Function):
                 views_by_kind[k] = views
                 kind_arr[j], pk_arr[j] = k, g_packed[k]
                 structs[j] = _fill_params_struct(k, views)
-        if ray_pending:
+        if persistent:
+            L.check(lib.enslam_step_finish_rays_prev(nc, srcs, dsts, vs, need_ptrs, prev_ptrs, npk, kind_arr, pk_arr, structs,
+                                                     L.STAGE[plan.stage], N if ray_pending else 0, S, _ptr(ro), _ptr(rd), _ptr(z),
+                                                     ctypes.byref(sc), _ptr(dgw), p_ro, p_rd, _ptr(work), _ptr(wcount), st),
+                    "enslam_step_finish_rays_prev")
+        elif ray_pending:
             L.check(lib.enslam_step_finish_rays(nc, srcs, dsts, vs, need_ptrs, npk, kind_arr, pk_arr, structs, L.STAGE[plan.stage],
                                                 N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc), _ptr(dgw), p_ro, p_rd,
                                                 _ptr(work), _ptr(wcount), st), "enslam_step_finish_rays")

@@ -201,6 +201,19 @@ int enslam_step_finish_rays(int32_t n_conv, const float *const *src, float *cons
                             int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                             const double *z_vals, const enslam_scene *scene, float *dgrid_ws, float *g_rays_o,
                             float *g_rays_d, const int32_t *work_list, const int32_t *work_count, void *stream);
+/* enslam_step_finish_rays into PERSISTENT gradient tensors: dst[i] is the same memory from call to call (the dense
+ * gradient of a grid inside a captured hipGraph step) and prev[i] (uint8 per 64-voxel block, as need[i]; all zero and
+ * dst[i] all zero before the first call) holds the blocks the previous call wrote.  Blocks touched neither then nor now
+ * keep their zeros and are not written; the others are written / cleared as in enslam_step_finish_rays, and need[i] is
+ * copied to prev[i] on the way.  The result in dst is identical; the 48 MB zero-fill of room0's three dense gradients
+ * becomes ~6 MB.  prev NULL: enslam_step_finish_rays.  Replaces nothing in the reference: autograd allocates a fresh dense
+ * gradient per backward there (Mapper.py:573-575 then reads three mostly-zero 16 MB tensors). */
+int enslam_step_finish_rays_prev(int32_t n_conv, const float *const *src, float *const *dst, const int64_t *n_voxels,
+                                 const uint8_t *const *need, uint8_t *const *prev, int32_t n_dec, const int32_t *kinds,
+                                 const float *const *packed_grads, const enslam_mlp_params *grads, int32_t stage,
+                                 int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                                 const double *z_vals, const enslam_scene *scene, float *dgrid_ws, float *g_rays_o,
+                                 float *g_rays_d, const int32_t *work_list, const int32_t *work_count, void *stream);
 
 /* Sample distances along rays (mark_scene / mark_flags non-NULL: also does enslam_mark_blocks' work for stage mark_stage
  * on the samples it has just placed -- one launch less per render call).

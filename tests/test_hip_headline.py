@@ -163,6 +163,56 @@ def test_graphed_step_matches_eager(room0):
     assert abs(l2 - loss_e) > 1e-6 * abs(loss_e)
 
 
+def test_persistent_dense_gradients_under_replay(room0):
+    """Under capture the dense grid gradients are the same memory at every replay and the finish launch only rewrites
+    the blocks touched now or one replay earlier (enslam_step_finish_rays_prev).  Replays with DIFFERENT rays must leave
+    exactly what an eager step on those rays produces: zeros where no ray came near -- also where the previous replay's
+    rays did -- and the same values elsewhere."""
+    import gc
+    import bench
+    import evennicer_slam_amd.functional as EF
+    from evennicer_slam_amd.graph import GraphedStep
+    sc, g, model, grids, renderer, rays = room0
+    leaves = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+    eager = {k: v.clone().requires_grad_(True) for k, v in grids.items()}   # (own leaves: the replayed step's .grad stay attached)
+    static = [t.clone() for t in (rays['rays_o'], rays['rays_d'], rays['gt_depth'], rays['gt_color'])]
+
+    def run(lv, ro, rd, gd, gcol):
+        EF.clear_caches()
+        for p in model.parameters():
+            p.grad = None
+        for t in lv.values():
+            t.grad = None
+        loss, depth, var, color = renderer.render_batch_ray_rgbd_loss(lv, model, rd, ro, 'cuda:0', 'color', gd, gcol, 0.2)
+        loss.backward()
+        return loss
+
+    gc.collect()
+    gs = GraphedStep(lambda: run(leaves, *static))
+    names = [k for k in leaves if k != 'grid_coarse']
+    seen_change = False
+    last_nz = None
+    for seed in (11, 12, 13, 11):
+        new = [t.to('cuda:0') for t in bench.make_rays(sc, 1000, seed)]
+        for dst, src in zip(static, new):
+            dst.copy_(src)
+        loss_g = gs.replay().item()
+        torch.cuda.synchronize()
+        got = {k: leaves[k].grad.clone() for k in names}
+        loss_e = run(eager, *new).item()
+        assert abs(loss_g - loss_e) < 1e-6 * abs(loss_e)
+        nz = {}
+        for k in names:
+            want = eager[k].grad
+            nz[k] = want != 0
+            assert torch.equal(got[k] != 0, nz[k]), k                      # the zero pattern, element by element
+            assert rel_err(got[k].cpu().numpy(), want.cpu().numpy()) < 1e-5, k
+        if last_nz is not None:
+            seen_change = seen_change or any(bool((last_nz[k] & ~nz[k]).any()) for k in names)
+        last_nz = nz
+    assert seen_change                                                     # some voxels went from touched back to zero
+
+
 def test_fused_rgbd_loss_matches_torch(room0):
     """losses.rgbd_loss == Mapper.py:553-562 (torch formulation), values and gradients."""
     import evennicer_slam_amd as E
