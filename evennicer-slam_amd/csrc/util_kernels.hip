@@ -403,8 +403,13 @@ ENS_DEV void convert_body(const ConvJob& job, int to_vm, int b) {
         const bool was = prev != nullptr && prev[blk] != 0;
         if (prev != nullptr) {
             if (!needed && !was) return;
-            __syncthreads();                                 // (block-uniform) every thread has read prev[blk]
-            if (threadIdx.x == 0 && was != needed) prev[blk] = needed ? 1 : 0;
+            __syncthreads();                                 // (block-uniform) every thread has read prev[blk] and need[blk]
+            if (threadIdx.x == 0) {
+                if (was != needed) prev[blk] = needed ? 1 : 0;
+                // the flag has served its step (marked by the sampler, read by the prepare launch and here): cleared, so
+                // that a captured step can keep its flags in memory that no fill node re-zeroes; readers use `prev` from now on
+                if (needed) const_cast<uint8_t*>(need)[blk] = 0;
+            }
         }
         if (!needed) {                                       // untouched block of a gradient: zeros, nothing read
             const int64_t v0 = blk * 64, V = job.V[g];

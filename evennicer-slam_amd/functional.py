@@ -169,8 +169,15 @@ class _ZeroArena:
     """One zero-filled allocation per render call, handed out in aligned typed slices (block flags, validity
     bitmaps, packed-decoder buffers): one fill node in the step's graph instead of one per consumer."""
 
-    def __init__(self, device, nbytes):
-        self.buf = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    def __init__(self, device, nbytes, persistent=False):
+        # persistent (inside a captured training step, see _RenderFn.forward): no fill node -- the memory is the same at
+        # every replay, zeroed once by end_capture(), and every slice handed out is back to zero (or wholly rewritten) when
+        # the step ends
+        if persistent:
+            self.buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+            _capture['init_zero'].append(self.buf.untyped_storage())
+        else:
+            self.buf = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=device)
         self.off = 0
 
     def take(self, n, dtype):
@@ -359,15 +366,21 @@ class _GridCache:
                 self._store(grids[i], out[i], None)
         return out
 
-    def get_many_sparse(self, grids, need, arena=None, defer=False):
+    def get_many_sparse(self, grids, need, arena=None, defer=False, fresh=False):
         """Voxel-major copies in which (at least) the 64-voxel blocks flagged in need[i] (uint8 tensors) are valid.
-        Every entry carries a `valid` bitmap; one launch converts the blocks that are needed and not yet valid."""
+        Every entry carries a `valid` bitmap; one launch converts the blocks that are needed and not yet valid.
+        fresh: no bitmap and no cache entry -- every flagged block is converted by this call's launch (a captured
+        training step: the grids change between replays, and a bitmap would have to be cleared at every replay)."""
         n = len(grids)
         srcs, dsts, vs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)()
         needs, valids, out, keep = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), [], []
         for i, g in enumerate(grids):
-            e = self._lookup(g, True)
-            if e is not None:
+            e = None if fresh else self._lookup(g, True)
+            if fresh:
+                _check_grid(g)
+                V = g.shape[2] * g.shape[3] * g.shape[4]
+                vm, valid = torch.empty((V, 32), dtype=torch.float32, device=g.device), None
+            elif e is not None:
                 vm, valid = e.vm, e.valid
             else:
                 _check_grid(g)
@@ -380,7 +393,7 @@ class _GridCache:
             src = src if src.is_contiguous() else src.contiguous()
             keep.append(src)
             srcs[i], dsts[i], vs[i] = src.data_ptr(), vm.data_ptr(), vm.shape[0]
-            needs[i], valids[i] = need[i].data_ptr(), valid.data_ptr()
+            needs[i], valids[i] = need[i].data_ptr(), (valid.data_ptr() if valid is not None else None)
             out.append(vm)
         if defer:                    # the caller launches (enslam_step_prepare); `keep` pins the sources until then
             return out, (n, srcs, dsts, vs, needs, valids, keep)
@@ -572,8 +585,18 @@ class _Accumulators:
         self.n_grid = offs[nk]
         self.n_flat = offs[-1] - self.n_grid
         self.gbuf = torch.empty(max(self.n_grid, 1), dtype=torch.float32, device=dev)
-        self.zbuf = torch.empty(max(self.n_flat, 1), dtype=torch.float32, device=dev)
+        # flat part + 16 bytes the same launch clears: the work-list counter (int32) and the fused loss (float64) of a
+        # captured training step live here instead of in a zero-filled arena
+        self.tail = (self.n_flat + 1) & ~1
+        self.n_zero = self.tail + 4
+        self.zbuf = torch.empty(self.n_zero, dtype=torch.float32, device=dev)
         self.clean = False          # set by the launch that cleared them; a backward consumes it
+
+    def counter(self):
+        return self.zbuf[self.tail:self.tail + 1].view(torch.int32)
+
+    def loss_slot(self):
+        return self.zbuf[self.tail + 2:self.tail + 4].view(torch.float64)
 
     def zero_args(self, plan, flags):
         """(n, dsts, n_voxels, need flags) of the grid accumulators for enslam_zero_blocks / enslam_step_prepare."""
@@ -623,7 +646,13 @@ class _RenderFn(torch.autograd.Function):
         static = [(i, k) for i, k in enumerate(plan.kinds) if k not in vmg and not ctx.needs_input_grad[5 + i]]
         dense = [(i, k) for i, k in enumerate(plan.kinds) if k not in vmg and ctx.needs_input_grad[5 + i]]
         nblk = [(dims[k][0] * dims[k][1] * dims[k][2] + 63) // 64 for _, k in dense]
-        arena = _ZeroArena(dev, 2 * sum(nblk) + 4 * sum(lib.enslam_packed_floats(k) for k in plan.kinds) + 256 + 32)
+        # A captured training step (fused render + loss: its backward always follows) needs no zero-fill node at all: the
+        # block flags are cleared by the finish launch that consumes them (enslam_step_finish_rays_prev), the packed
+        # decoders' padding stays zero, the conversion runs without a validity bitmap and the two accumulating scalars sit
+        # in the flat buffer the prepare launch clears.  Everywhere else: one zero-filled arena per call.
+        cap = bool(_capturing() and _capture['init_zero'] is not None and plan.loss is not None and plan.z_given is None
+                   and any(ctx.needs_input_grad[5:5 + nk]))
+        arena = _ZeroArena(dev, 2 * sum(nblk) + 4 * sum(lib.enslam_packed_floats(k) for k in plan.kinds) + 256 + 32, persistent=cap)
         flags = [None] * nk
         grids_vm, packed = {k: vmg[k].vm for k in vmg}, {}
         state = plan.state
@@ -655,7 +684,7 @@ class _RenderFn(torch.autograd.Function):
         conv_args = None
         if dense:
             dense_grids = [grids[i] for i, _ in dense]
-            vms, conv_args = _grid_cache.get_many_sparse(dense_grids, [flags[i] for i, _ in dense], arena, defer=True)
+            vms, conv_args = _grid_cache.get_many_sparse(dense_grids, [flags[i] for i, _ in dense], arena, defer=True, fresh=cap)
             for (i, k), vm in zip(dense, vms):
                 grids_vm[k] = vm
         po, items = nk, []
@@ -673,7 +702,7 @@ class _RenderFn(torch.autograd.Function):
         if nd_ or nc_ or accum is not None:
             L.check(lib.enslam_step_prepare(nd_, kinds_, structs_, ptrs_, nc_, srcs_, dsts_, vs_, needs_, valids_, nz_, zd_, zv_, zn_,
                                             _ptr(accum.zbuf) if accum is not None else None,
-                                            accum.n_flat if accum is not None else 0, st), "enslam_step_prepare")
+                                            accum.n_zero if accum is not None else 0, st), "enslam_step_prepare")
             if accum is not None:
                 accum.clean = True
         pack_commit()
@@ -697,14 +726,14 @@ class _RenderFn(torch.autograd.Function):
         work = wcount = None
         if act is not None and USE_WORK_LIST and any(ctx.needs_input_grad) and SV is None:
             work = torch.empty(N * (S // 16), dtype=torch.int32, device=dev)
-            wcount = arena.take(1, torch.int32)
+            wcount = accum.counter() if cap else arena.take(1, torch.int32)
         if plan.loss is None:
             L.check(lib.enslam_render_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                           _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, st),
                     "enslam_render_fwd")
         else:
             lgd, lgc, lw = plan.loss
-            loss = arena.take(1, torch.float64)
+            loss = accum.loss_slot() if cap else arena.take(1, torch.float64)
             # the compositing launch also leaves d(loss)/d(raw) for a unit loss gradient: the backward starts at the decoders
             d_raw_unit = torch.empty((N * S, 4), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
             L.check(lib.enslam_render_loss_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
@@ -729,6 +758,7 @@ class _RenderFn(torch.autograd.Function):
         state.work = (wcount, N * (S // 16))
         ctx.work_filled = plan.loss is not None and work is not None and d_raw_unit is not None      # (by the forward)
         ctx.grid_shapes = [tuple(g.shape) for g in grids]
+        ctx.grid_ids = [id(g) for g in grids]
         ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
         if loss is not None:
             ctx.mark_non_differentiable(depth, var, rgb)
@@ -857,6 +887,7 @@ class _RenderFn(torch.autograd.Function):
                 pv = torch.empty(flags[i].numel(), dtype=torch.uint8, device=dev)
                 prev_ptrs[j] = pv.data_ptr()
                 prev_keep.append(pv)
+                plan.state.flags[ctx.grid_ids[i]] = pv      # the launch moves the flags there (last_block_flags)
                 _capture['init_zero'] += [g.untyped_storage(), pv.untyped_storage()]
         for k in plan.kinds:
             out.append(grid_out.get(k))

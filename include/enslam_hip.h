@@ -205,7 +205,8 @@ int enslam_step_finish_rays(int32_t n_conv, const float *const *src, float *cons
  * gradient of a grid inside a captured hipGraph step) and prev[i] (uint8 per 64-voxel block, as need[i]; all zero and
  * dst[i] all zero before the first call) holds the blocks the previous call wrote.  Blocks touched neither then nor now
  * keep their zeros and are not written; the others are written / cleared as in enslam_step_finish_rays, and need[i] is
- * copied to prev[i] on the way.  The result in dst is identical; the 48 MB zero-fill of room0's three dense gradients
+ * MOVED to prev[i] on the way (need[i] is all zero afterwards: a captured step keeps its flags in memory that nothing
+ * re-zeroes between replays; read the touched blocks from prev[i]).  The result in dst is identical; the 48 MB zero-fill of room0's three dense gradients
  * becomes ~6 MB.  prev NULL: enslam_step_finish_rays.  Replaces nothing in the reference: autograd allocates a fresh dense
  * gradient per backward there (Mapper.py:573-575 then reads three mostly-zero 16 MB tensors). */
 int enslam_step_finish_rays_prev(int32_t n_conv, const float *const *src, float *const *dst, const int64_t *n_voxels,
