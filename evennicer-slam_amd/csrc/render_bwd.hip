@@ -523,13 +523,24 @@ ENS_DEV void wg_barrier_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// deposit tile T (byte offset T*1024 behind dep = slot base + ((p>>2)*64 + (p&3) + 16q)*4)
-template <int T>
-ENS_DEV void dep_tile(unsigned dep, const f32x4& x) {
+// Deposit tiles are SWIZZLED (as the forward's workspace tiles, which global_load_lds copies verbatim): the 16-byte chunk
+// f = 4q + r (feature f, samples 4P..4P+3) of sample group P = p >> 2 sits at chunk f ^ P of its 64-float row.  Plainly
+// laid out, the 32 lanes of a ds_write_b32 group land on 8 banks (4-way conflict: 4.6 M conflict cycles per launch, a
+// third of the kernel's LDS time); with the XOR they cover all 32, and the fragment read of lane L = 16P + f -- chunk
+// f ^ P, i.e. byte (L ^ (L >> 4)) * 16 of the tile -- stays conflict-free.
+// dep[r] = slot base + (P*64 + (p&3) + 16q + 4*(r ^ P)) * 4: one lane base per register component, tile T at +T*1024.
+ENS_DEV void dep_bases(unsigned (&dep)[4], unsigned slot_base, int p, int q) {
+    const int P = p >> 2;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) lds_st1(dep + T * 1024 + 16 * r, x[r]);
+    for (int r = 0; r < 4; ++r) { dep[r] = slot_base + (unsigned)(P * 64 + (p & 3) + 16 * q + 4 * (r ^ P)) * 4u; opaque(dep[r]); }
 }
-// owned outer products with integer addressing: fb[sl] = slot sl base + lane*16
+ENS_DEV unsigned frag_lane_off(int lane) { return (unsigned)(lane ^ (lane >> 4)) * 16u; }      // byte offset of lane's fragment in a tile
+template <int T>
+ENS_DEV void dep_tile(const unsigned (&dep)[4], const f32x4& x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds_st1(dep[r] + T * 1024, x[r]);
+}
+// owned outer products with integer addressing: fb[sl] = slot sl base + frag_lane_off(lane)
 template <int NJ>
 ENS_DEV void own_outer_a(f32x4 (&acc)[NJ], const unsigned (&fb)[4], int ytile0, int xtile0, int nc, int ntiles, int wave) {
     // tiles t >= ntiles (only the 6-tile dB^T matrix has them) read tile 0 and are discarded by the caller's
@@ -705,13 +716,14 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
 
         // per-lane LDS bases of this round (opaque: see above)
         unsigned wt = lds0 + frag_off(p, q) * 4, wq = lds0 + q * 16;            // forward images: tile-major (lds_util.hpp)
-        unsigned dep = lds0 + RING_BYTES + (wave * SLOT + (p >> 2) * 64 + (p & 3) + 16 * q) * 4;
+        unsigned dep[4];
+        dep_bases(dep, lds0 + RING_BYTES + wave * SLOT * 4, p, q);
         unsigned fb[4];
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
+        for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + sl * SLOT * 4 + frag_lane_off(lane); opaque(fb[sl]); }
         unsigned w32s = swz_base_even(lds0, 32, p, q);               // transposed (swizzled) images: lds_util.hpp
         const unsigned swd = swz_odd_delta(p);
-        opaque(wt); opaque(wq); opaque(dep); opaque(w32s);
+        opaque(wt); opaque(wq); opaque(w32s);
 
         // ---- recompute the forward chain (weights of layer i from ring buffer i&1, next chunk in flight)
         const float pc = q == 0 ? (float)G.pw[0] : (q == 1 ? (float)G.pw[1] : (q == 2 ? (float)G.pw[2] : 0.f));
@@ -1090,11 +1102,11 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         }
         STAMP(0)        // d_raw load + vote barrier
 
-        unsigned dep = lds0 + RING_BYTES + (wave * SLOT + (p >> 2) * 64 + (p & 3) + 16 * q) * 4;
+        unsigned dep[4];
+        dep_bases(dep, lds0 + RING_BYTES + wave * SLOT * 4, p, q);
         unsigned fb[4];
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
-        opaque(dep);
+        for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + sl * SLOT * 4 + frag_lane_off(lane); opaque(fb[sl]); }
 
         // ---- forward activations from the workspace: deposit tiles straight into this wave's LDS slot (async),
         //      h4 and the ReLU masks into registers
@@ -1226,9 +1238,9 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             if constexpr (SPLIT) sy_wait(SY_FILL, 4 * (int)(r_exec + 1));       // (the slot fill landed long ago)
             if constexpr (WW) {
                 if (q < 3) pc = *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(
-                                    lds0 + RING_BYTES + (wave * SLOT + SL::Q * 256 + (p >> 2) * 64 + q * 4 + (p & 3)) * 4));
+                                    lds0 + RING_BYTES + (wave * SLOT + SL::Q * 256 + (p >> 2) * 64 + (q ^ (p >> 2)) * 4 + (p & 3)) * 4));
             } else {
-                if (q < 3) pc = wsb[WSQ + (p >> 2) * 64 + q * 4 + (p & 3)];               // same tile, straight from the workspace
+                if (q < 3) pc = wsb[WSQ + (p >> 2) * 64 + (q ^ (p >> 2)) * 4 + (p & 3)];  // same tile (swizzled chunk), straight from the workspace
             }
 #pragma unroll
             for (int t = 0; t < 6; ++t) {                               // cos(arg) recomputed: cheaper than carrying it
@@ -1357,7 +1369,7 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
     aBT[0] = aBT[1] = splat4(0.f);
     unsigned fb[4];
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + (sl * SLOT + lane * 4) * 4; opaque(fb[sl]); }
+    for (int sl = 0; sl < 4; ++sl) { fb[sl] = lds0 + RING_BYTES + sl * SLOT * 4 + frag_lane_off(lane); opaque(fb[sl]); }
     const int64_t n_tiles = work_count(A);
     const int64_t stride = (int64_t)n_wg * 4;
     unsigned round_no = 0;

@@ -29,7 +29,7 @@ ENS_DEV void ws_store_dep(float* __restrict__ ws_tile, const f32x4& x, float* st
     f32x4 t = splat4(0.f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) t = MFMA16(x[r], (p == 4 * q + r) ? 1.f : 0.f, t);
-    *reinterpret_cast<f32x4*>(ws_tile + lane * 4) = t;
+    *reinterpret_cast<f32x4*>(ws_tile + (lane ^ (lane >> 4)) * 4) = t;          // (swizzled tile, as below)
 #else
     // (storing component-major [r][lane] with plain dword stores and turning the tile in the backward's
     // global_load_lds by addressing was tried: forward -2.6 us, backward +10 us -- the strided 16-byte source runs cost
@@ -37,14 +37,15 @@ ENS_DEV void ws_store_dep(float* __restrict__ ws_tile, const f32x4& x, float* st
     // the deposit layout, without the LDS round trip: no gain either, 0.346 vs 0.339 ms per step)
     // The 16-byte chunk (4q + r) of sample group P = p >> 2 sits at chunk (4q + r) ^ P of its 64-float row: written plainly,
     // the 32 lanes of a ds_write_b32 group would land on 8 banks (4-way); with the XOR they cover all 32, and the
-    // ds_read_b128 below (lane 16P + f reads chunk f ^ P) stays conflict-free.
+    // plain ds_read_b128 below hands lane L the fragment of lane L ^ (L >> 4): the workspace tile is stored SWIZZLED, which is
+    // how the backward's slots want it (render_bwd.hip, dep_bases: global_load_lds copies the tile verbatim).
     const int P = p >> 2;
     float* d = stage + P * 64 + (p & 3) + 16 * q;
 #pragma unroll
     for (int r = 0; r < 4; ++r) d[4 * (r ^ P)] = x[r];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (lane ^ (lane >> 4)) * 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + lane * 4);     // the tile goes to the workspace swizzled, as the backward reads it
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     *reinterpret_cast<f32x4*>(ws_tile + lane * 4) = v;
