@@ -966,6 +966,14 @@ struct XyzSlotsS {                     // slot = workspace block order, then the
     static constexpr int TILES = 23 + CT;
 };
 constexpr int RB_SAVED = 96 * 32 + 1024 + 16 * 96 + 96 * 4;           // layer-0 chunk: W0^T | Wc0^T | B (padded) | B^T
+// Weight area of the saved-activation kernels (floats).  The W^T | Wc^T chunks of layers 4, 2 and 1 (2048 floats each) are
+// RESIDENT: loaded once per workgroup, read by every round without any hand-off.  Layers 3 (5120 floats) and 0 (6016) share
+// ONE streaming buffer: layer 0's chunk is requested once every chain wave has read layer 3's (two layers ahead of its use),
+// layer 3's at the start of a round.  Same LDS as the former 2-buffer ring (+512 bytes), 2 chunk hand-offs per round
+// instead of 5, 44 KB instead of 69 KB of L2 -> LDS traffic per round.
+constexpr int WRES_SAVED = 3 * 2048;
+constexpr int WAREA_SAVED = WRES_SAVED + RB_SAVED;
+constexpr int wres_off(int i) { return i == 4 ? 0 : (i == 2 ? 2048 : (i == 1 ? 4096 : WRES_SAVED)); }   // layer -> float offset
 
 // WW = false: no decoder-parameter gradients (tracker iterations; mapper stages that optimise no decoder): no
 // deposits, no owned dW tiles, no accumulators, no slot fill -- under 256 registers, two workgroups per CU.
@@ -980,9 +988,8 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     using SL = XyzSlotsS<CT>;
     constexpr int SLOT = WW ? SL::TILES * 256 : 512;               // floats (light variant: the 2-tile scatter staging only)
     constexpr int STG = WW ? SL::H1 * 256 : 0;
-    constexpr int RB = RB_SAVED;
-    static_assert(RB_SAVED >= 128 * 32 + 1024, "ring buffer must hold the largest W^T|Wc^T chunk");
-    constexpr int RING_BYTES = 2 * RB * 4;
+    static_assert(RB_SAVED >= 128 * 32 + 1024, "the streaming buffer must hold the largest W^T|Wc^T chunk");
+    constexpr int RING_BYTES = WAREA_SAVED * 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
     const float* __restrict__ pk = A.sc.packed[kind];
     float* gpk = A.gpacked[kind];
@@ -990,14 +997,14 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     const bool want_g = A.ggrid[kind].data != nullptr, want_r = A.g_ro != nullptr;
     const bool want_c = want_g || want_r;
     float* ring = smem;
-    float* slots = smem + 2 * RB;
+    float* slots = smem + WAREA_SAVED;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)smem;
     const int slot_idx = kind - 1;                                  // decoder slot in the workspaces
 
-    // backward layer i's chunk (W_i^T | Wc_i^T [| B | B^T for layer 0]) into ring buffer `buf`
-    auto prefetch = [&](auto ic, int buf) {
+    // backward layer i's chunk (W_i^T | Wc_i^T [| B | B^T for layer 0]) into its place (wres_off)
+    auto prefetch = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        float* dst = ring + (buf ? RB : 0);
+        float* dst = ring + wres_off(i);
         ring_load(dst, pk + L.oWT(i), 8 * L.K(i), wave, lane);
         ring_load(dst + 32 * L.K(i), pk + L.oWcT(i), 256, wave, lane);
         if constexpr (i == 0) {
@@ -1029,12 +1036,9 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     const int64_t stride = (int64_t)n_wg * 4;
     STAMP_DECL
     STAMP_START
-    prefetch(IC(4), 0);                                             // (the chain waves stream the W^T ring; SPLIT: the dW waves fill the slots)
-    if constexpr (SPLIT) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sy_signal(SY_RING, lane);                                   // chunk 0 (layer 4 of the first executed round)
-    }
-    unsigned round_no = 0, rp = 0;                                  // rp: ring buffer of this round's first chunk
+    prefetch(IC(4)); prefetch(IC(2)); prefetch(IC(1));              // resident chunks (SPLIT: the dW waves fill the slots)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // landed before the first round's vote barrier lets anyone read them
+    unsigned round_no = 0;
     unsigned r_exec = 0;                                            // executed (not skipped) rounds so far: targets of the hand-off counters
     // The feature-gradient scatter of a tile is deferred into the next executed round (after its first barrier): the
     // ~30 atomics of a tile then drain under that round's MFMAs instead of in front of its loads (vmcnt is in order).
@@ -1101,6 +1105,9 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             }
         }
         STAMP(0)        // d_raw load + vote barrier
+        // layer 3's chunk into the streaming buffer: every wave is past the previous round's tail (its last reader) -- the
+        // vote barrier says so -- and layer 4 runs on resident weights while it lands
+        prefetch(IC(3));
 
         unsigned dep[4];
         dep_bases(dep, lds0 + RING_BYTES + wave * SLOT * 4, p, q);
@@ -1146,9 +1153,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         unsigned ring0 = 0;                                         // byte address of the layer-0 ring buffer (tail)
         auto bwd_layer = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            constexpr int kk = 4 - i;                                // chunk number inside the round
-            const int buf = (kk + rp) & 1;
-            const unsigned wb = wsw + (buf ? RB * 4 : 0);
+            const unsigned wb = wsw + wres_off(i) * 4;
             constexpr int OCT = 32 * L.K(i) * 4;                      // W_i^T [K][32] | Wc_i^T [32][32]
             constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
             constexpr int TX = i == 4 ? SL::HX3 : (i == 2 ? SL::HX1 : SL::HX0);      // input h_{i-1} of layers 4, 2, 1
@@ -1168,13 +1173,14 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             STAMP(6)    // layer deposits (+ tail of previous dX)
             if constexpr (SPLIT) {
                 sy_signal(SY_DEP + i, lane);                                  // layer i's operands are in place
-                sy_wait(SY_RING, 4 * (int)(5 * r_exec + kk + 1));             // this layer's W^T chunk has landed (all quarters)
-                sy_wait(SY_RDONE, 4 * (int)(5 * r_exec + kk));                // every chain wave is done with the chunk before it
+                // streamed chunks only (two per executed round): all four quarters have landed
+                if constexpr (i == 3) sy_wait(SY_RING, 4 * (int)(2 * r_exec + 1));
+                if constexpr (i == 0) sy_wait(SY_RING, 4 * (int)(2 * r_exec + 2));
             } else {
-                __syncthreads();        // deposits + slot fill visible; this layer's W^T chunk has landed
+                __syncthreads();        // deposits + slot fill visible; a streamed chunk requested before the previous barrier has landed
+                if constexpr (i == 2) prefetch(IC(0));   // every wave is past layer 3: its chunk gives way to layer 0's
             }
             STAMP(5)    // barrier wait
-            if constexpr (i > 0) prefetch(IC(i - 1), buf ^ 1); else prefetch(IC(4), buf ^ 1);
             if constexpr (i == 4 && !SPLIT) scatter_pending();       // previous tile's atomics, behind this round's loads
             if constexpr (i == 4) { STAMP(1) }      // deferred scatter
             if constexpr (i == 4) {
@@ -1209,7 +1215,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             }
             if (want_c) lin_lds_swz<2, 2, 32, OCT>(dc, wb, swd, dh);                      // dC += Wc_i^T dh_i
             if constexpr (i == 0) {
-                ring0 = lds0 + (buf ? RB * 4 : 0);
+                ring0 = lds0 + WRES_SAVED * 4;
                 if (want_r || want_w) lin_lds_swz<6, 2, 32, 0>(demb, wb, swd, dpre);
             } else if constexpr (i == 3) {
                 if (want_r || want_w) lin_lds_swz<6, 2, 32, 0>(demb, wb, swd, dpre);  // rows 0..95 of W3^T: embedding part
@@ -1220,13 +1226,18 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
                 lin_lds_swz<2, 2, 32, 0>(dh, wb, swd, dpre);
             }
             if constexpr (SPLIT) {
-                if constexpr (i > 0) sy_signal(SY_RDONE, lane);      // chunk read (layer 0's is read again in the tail)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's quarter of the next chunk has landed
-                sy_signal(SY_RING, lane);
+                if constexpr (i == 4 || i == 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's quarter of the streamed chunk requested a layer ago has landed
+                    sy_signal(SY_RING, lane);
+                }
+                if constexpr (i == 3) sy_signal(SY_RDONE, lane);     // layer 3's chunk read (lgkmcnt(0) inside)
+                if constexpr (i == 2) {                              // ... by every chain wave: layer 0's chunk may replace it
+                    sy_wait(SY_RDONE, 4 * (int)(2 * r_exec + 1));
+                    prefetch(IC(0));
+                }
             }
         };
         bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
-        rp ^= 1;                                                    // 5 chunks per executed round
         STAMP(8)        // dX chain of the last layer
         // ---- embedding: d_arg = d_emb * cos(arg);  dB^T += d_arg (x) p ;  dp += B d_arg.  B and B^T ride in the
         //      layer-0 ring chunk; the sample coordinates come from the XYZ tile of the slot.
@@ -1350,11 +1361,10 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
     constexpr int GF = L.fwd_floats();
     using SL = XyzSlotsS<CT>;
     constexpr int SLOT = SL::TILES * 256;
-    constexpr int RB = RB_SAVED;
-    constexpr int RING_BYTES = 2 * RB * 4;
+    constexpr int RING_BYTES = WAREA_SAVED * 4;
     const int lane = threadIdx.x & 63, ow = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 4, p = lane & 15, q = lane >> 4;
     float* gpk = A.gpacked[kind];
-    float* slots = smem + 2 * RB;
+    float* slots = smem + WAREA_SAVED;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)smem;
     f32x4 aWc[5][CT / 2], aW0[3], aW1[1], aW2[1], aW3[4], aW4[1], aBT[2];
     float aB[5];
@@ -1729,11 +1739,11 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_light_kernel(BwdArgs A) {
         default: break;
     }
 }
-constexpr int lds_bytes_light() { return (2 * RB_SAVED + 4 * 512) * 4; }
+constexpr int lds_bytes_light() { return (WAREA_SAVED + 4 * 512) * 4; }
 
 // deposit slots of the 4 waves; the packed-layout flush image aliases them at the end of the kernel
 constexpr int lds_bytes_xyz(int ct) { return (cmax(XyzLay{ct * 16}.fwd_floats(), 4 * (23 + ct) * 256) + 2 * ring_floats(ct)) * 4; }
-constexpr int lds_bytes_xyz_saved(int ct) { return (cmax(XyzLay{ct * 16}.fwd_floats(), 4 * (23 + ct) * 256) + 2 * RB_SAVED) * 4; }
+constexpr int lds_bytes_xyz_saved(int ct) { return (cmax(XyzLay{ct * 16}.fwd_floats(), 4 * (23 + ct) * 256) + WAREA_SAVED) * 4; }
 constexpr int lds_bytes_feat() { return cmax(FeatLay{}.fwd_floats(), 4 * 11 * 256) * 4; }
 
 int device_cus() {
