@@ -113,3 +113,48 @@ def test_mark_blocks_covers_the_samplers_marks():
     for k in (1, 2, 3):
         assert torch.equal(own[k], in_sampler[id(grids[L.GRID_NAMES[k]])]), L.GRID_NAMES[k]
         assert int(own[k].sum()) > 0
+
+
+def test_step_finish_rays_prev_persistent_destination():
+    """enslam_step_finish_rays_prev by hand: three calls into the SAME dense gradient with different block flags give, each time,
+    exactly what enslam_step_finish writes into a fresh tensor; the flags move to `prev` (the live flags end all-zero); blocks
+    untouched twice in a row are not written at all (a sentinel planted there survives)."""
+    import evennicer_slam_amd as E
+    import evennicer_slam_amd.functional as EF
+    from tests.hip_util import DEV
+    L = E._lib
+    lib = L.lib()
+    P, st = EF._ptr, EF._stream()
+    D, H, W = 12, 20, 28                                       # 6720 voxels = 105 blocks of 64
+    V = D * H * W
+    nblk = (V + 63) // 64
+    gen = torch.Generator().manual_seed(5)
+    vm = torch.randn((V, 32), generator=gen).to(DEV)           # a voxel-major gradient accumulator (values everywhere)
+    dense = torch.zeros((1, 32, D, H, W), dtype=torch.float32, device=DEV)
+    prev = torch.zeros(nblk, dtype=torch.uint8, device=DEV)
+    arr = lambda *ptrs: (ctypes.c_void_p * len(ptrs))(*ptrs)
+    nvox = (ctypes.c_int64 * 1)(V)
+    masks = [torch.rand(nblk, generator=gen) < 0.3 for _ in range(3)]
+    masks[2][:8] = False
+    masks[1][:8] = False                                       # blocks 0..7: untouched in calls 2 and 3
+    for it, m in enumerate(masks):
+        flags = m.to(torch.uint8).to(DEV)
+        want = torch.empty_like(dense)
+        L.check(lib.enslam_step_finish(1, arr(vm.data_ptr()), arr(want.data_ptr()), nvox, arr(flags.data_ptr()), 0, None, None, None, st),
+                "enslam_step_finish")
+        if it == 2:
+            dense.view(32, V)[:, :8 * 64] = 123.0              # untouched now and in the previous call: must not be written
+        live = flags.clone()
+        L.check(lib.enslam_step_finish_rays_prev(1, arr(vm.data_ptr()), arr(dense.data_ptr()), nvox, arr(live.data_ptr()),
+                                                 arr(prev.data_ptr()), 0, None, None, None, 3, 0, 48, None, None, None, None, None,
+                                                 None, None, None, None, st), "enslam_step_finish_rays_prev")
+        torch.cuda.synchronize()
+        assert torch.equal(prev, flags) and int(live.sum()) == 0
+        got = dense.clone()
+        if it == 2:
+            assert bool((got.view(32, V)[:, :8 * 64] == 123.0).all())
+            got.view(32, V)[:, :8 * 64] = 0.0
+        assert torch.equal(got, want), it
+    # prev without flags is refused
+    assert lib.enslam_step_finish_rays_prev(1, arr(vm.data_ptr()), arr(dense.data_ptr()), nvox, None, arr(prev.data_ptr()), 0, None,
+                                            None, None, 3, 0, 48, None, None, None, None, None, None, None, None, None, st) == -1
