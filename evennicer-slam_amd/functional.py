@@ -172,15 +172,22 @@ class _ZeroArena:
     def __init__(self, device, nbytes, persistent=False):
         # persistent (inside a captured training step, see _RenderFn.forward): no fill node -- the memory is the same at
         # every replay, zeroed once by end_capture(), and every slice handed out is back to zero (or wholly rewritten) when
-        # the step ends
-        if persistent:
-            self.buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
-            _capture['init_zero'].append(self.buf.untyped_storage())
-        else:
-            self.buf = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        # the step ends.  Allocated at the first take(): a call that needs nothing zeroed (tracker iterations on a cached
+        # map) gets no fill node either.
+        self.device, self.nbytes, self.persistent = device, max(int(nbytes), 16), persistent
+        self.buf = None
         self.off = 0
 
+    def _alloc(self):
+        if self.persistent:
+            self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
+            _capture['init_zero'].append(self.buf.untyped_storage())
+        else:
+            self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
+
     def take(self, n, dtype):
+        if self.buf is None:
+            self._alloc()
         nb = n * torch.empty((), dtype=dtype).element_size()
         off = (self.off + 15) & ~15
         if off + nb > self.buf.numel():
@@ -726,14 +733,14 @@ class _RenderFn(torch.autograd.Function):
         work = wcount = None
         if act is not None and USE_WORK_LIST and any(ctx.needs_input_grad) and SV is None:
             work = torch.empty(N * (S // 16), dtype=torch.int32, device=dev)
-            wcount = accum.counter() if cap else arena.take(1, torch.int32)
+            wcount = accum.counter() if accum is not None else arena.take(1, torch.int32)    # (cleared by the prepare launch)
         if plan.loss is None:
             L.check(lib.enslam_render_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                           _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, st),
                     "enslam_render_fwd")
         else:
             lgd, lgc, lw = plan.loss
-            loss = accum.loss_slot() if cap else arena.take(1, torch.float64)
+            loss = accum.loss_slot() if accum is not None else arena.take(1, torch.float64)
             # the compositing launch also leaves d(loss)/d(raw) for a unit loss gradient: the backward starts at the decoders
             d_raw_unit = torch.empty((N * S, 4), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
             L.check(lib.enslam_render_loss_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
