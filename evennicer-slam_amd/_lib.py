@@ -83,6 +83,8 @@ _SIGS = {
                                                     POINTER(c_void_p), c_int32, POINTER(c_int32), POINTER(c_void_p), POINTER(MlpParams),
                                                     c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene), c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "enslam_gather_pixels": (ctypes.c_int, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "enslam_ray_grad_bwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene), c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
     "enslam_zero_blocks": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), c_void_p,

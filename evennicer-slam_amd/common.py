@@ -27,12 +27,16 @@ def select_uv(i, j, n, depth, color, device='cuda:0'):
 def get_sample_uv(H0, H1, W0, W1, n, depth, color, device='cuda:0'):
     # (integer-valued with unit step: the same values whichever device computes them; made on the device so that a
     # captured iteration performs no host-to-device copy)
-    cols = torch.linspace(W0, W1 - 1, W1 - W0, device=device)
-    rows = torch.linspace(H0, H1 - 1, H1 - H0, device=device)
     # the reference materialises the window's meshgrid and indexes it (common.py:137-141); indexing the two axes gives
     # the same values without the 2 x H x W temporaries.  Same single RNG draw as select_uv.
     ww = W1 - W0
     idx = torch.randint((H1 - H0) * ww, (n,), device=device)
+    if idx.is_cuda:
+        from . import functional as EF          # (lazy: this module has no other dependency on the HIP library)
+        if EF.gather_pixels_ok(idx, depth, color):
+            return EF.gather_pixels(idx, H0, W0, ww, depth, color)     # one launch instead of eight
+    cols = torch.linspace(W0, W1 - 1, W1 - W0, device=device)
+    rows = torch.linspace(H0, H1 - 1, H1 - H0, device=device)
     col, row = idx % ww, idx // ww
     d = depth[H0:H1, W0:W1][row, col]
     c = color[H0:H1, W0:W1][row, col]

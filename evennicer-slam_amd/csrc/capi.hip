@@ -376,6 +376,15 @@ int enslam_tracker_loss_bwd(int32_t n, const double* depth, const double* uncert
     return ens_launch_tracker_loss(n, depth, uncertainty, color, gt_depth, gt_color, w_color, g_loss, nullptr, g_depth,
                                    g_color, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
+int enslam_gather_pixels(int32_t n, const int64_t* pixel_index, int32_t h0, int32_t w0, int32_t window_w, int32_t image_w,
+                         int32_t image_h, const float* depth, const void* color, int32_t color_is_f64, float* pix_i, float* pix_j,
+                         float* depth_out, void* color_out, void* stream) {
+    if (n < 0 || h0 < 0 || w0 < 0 || window_w <= 0 || w0 + window_w > image_w || image_h <= h0) return ENSLAM_EINVAL;
+    if (n == 0) return ENSLAM_OK;
+    if (!pixel_index || !depth || !color || !pix_i || !pix_j || !depth_out || !color_out) return ENSLAM_EINVAL;
+    return ens_launch_gather_pixels(n, pixel_index, h0, w0, window_w, image_w, depth, color, color_is_f64 != 0, pix_i, pix_j,
+                                    depth_out, color_out, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
 int enslam_pose_rays_fwd(int32_t n, const float* camera_tensor, const float* pix_i, const float* pix_j, float fx,
                          float fy, float cx, float cy, float* rays_o, float* rays_d, void* stream) {
     if (n < 0 || !camera_tensor || (n > 0 && (!pix_i || !pix_j || !rays_o || !rays_d))) return ENSLAM_EINVAL;

@@ -99,6 +99,8 @@ int ens_launch_ray_grad_bwd(int stage, int ntl, int n_rays, const float* ro, con
 int ens_launch_tracker_loss(int n, const double* depth, const double* unc, const float* color, const float* gd,
                             const float* gc, float w, const double* g_loss, double* loss, double* g_depth, float* g_color,
                             hipStream_t st);
+int ens_launch_gather_pixels(int n, const int64_t* idx, int H0, int W0, int ww, int Wimg, const float* depth, const void* color,
+                             int color_f64, float* oi, float* oj, float* od, void* oc, hipStream_t st);
 int ens_launch_pose_rays(int n, const float* ct, const float* pi, const float* pj, float fx, float fy, float cx, float cy,
                          const float* g_ro, const float* g_rd, float* ro, float* rd, float* g_ct, hipStream_t st);
 int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_vm, const ConvJob& zj, float* flat,

@@ -811,6 +811,34 @@ int ens_launch_tracker_loss(int n, const double* depth, const double* unc, const
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// common.get_sample_uv / select_uv (common.py:125-141) behind the single torch.randint draw: pixel k of the window
+// [H0, H0+hh) x [W0, W0+ww) -> its column / row as floats (the reference indexes a linspace meshgrid of integers) and its depth
+// and colour samples.  Replaces 2 linspace + 2 index-arithmetic + 4 indexing launches per sampled frame.
+template <typename C>
+__global__ __launch_bounds__(256) void gather_pixels_kernel(int n, const int64_t* __restrict__ idx, int H0, int W0, int ww, int Wimg,
+                                                            const float* __restrict__ depth, const C* __restrict__ color,
+                                                            float* __restrict__ oi, float* __restrict__ oj, float* __restrict__ od,
+                                                            C* __restrict__ oc) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int64_t k = idx[t];
+    const int row = (int)(k / ww), col = (int)(k - (int64_t)row * ww);
+    const int64_t at = (int64_t)(H0 + row) * Wimg + (W0 + col);
+    oi[t] = (float)(W0 + col);
+    oj[t] = (float)(H0 + row);
+    od[t] = depth[at];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) oc[(int64_t)t * 3 + a] = color[at * 3 + a];
+}
+int ens_launch_gather_pixels(int n, const int64_t* idx, int H0, int W0, int ww, int Wimg, const float* depth, const void* color,
+                             int color_f64, float* oi, float* oj, float* od, void* oc, hipStream_t st) {
+    if (n <= 0) return 0;
+    const dim3 grid((n + 255) / 256), block(256);
+    if (color_f64) gather_pixels_kernel<double><<<grid, block, 0, st>>>(n, idx, H0, W0, ww, Wimg, depth, (const double*)color, oi, oj, od, (double*)oc);
+    else gather_pixels_kernel<float><<<grid, block, 0, st>>>(n, idx, H0, W0, ww, Wimg, depth, (const float*)color, oi, oj, od, (float*)oc);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int ens_launch_pose_rays(int n, const float* ct, const float* pi, const float* pj, float fx, float fy, float cx, float cy,
                          const float* g_ro, const float* g_rd, float* ro, float* rd, float* g_ct, hipStream_t st) {
     if (g_ct == nullptr) {

@@ -987,6 +987,29 @@ def voxel_index(points, bound, shape):
     return outs
 
 
+def gather_pixels(idx, H0, W0, ww, depth, color):
+    """(pix_i, pix_j, depth samples, colour samples) of the window pixels `idx` (int64 [n], row-major inside the window that
+    starts at (H0, W0) and is ww wide): what common.get_sample_uv computes with 2 linspace + 2 index-arithmetic + 4 indexing
+    launches, in one (enslam_gather_pixels).  depth float32 [H, W], color float32 / float64 [H, W, 3], all on the GPU."""
+    n = int(idx.shape[0])
+    dev = idx.device
+    depth, color, idx = depth.contiguous(), color.contiguous(), idx.contiguous()
+    oi = torch.empty(n, dtype=torch.float32, device=dev)
+    oj = torch.empty(n, dtype=torch.float32, device=dev)
+    od = torch.empty(n, dtype=torch.float32, device=dev)
+    oc = torch.empty((n, 3), dtype=color.dtype, device=dev)
+    L.check(L.lib().enslam_gather_pixels(n, _ptr(idx), int(H0), int(W0), int(ww), int(depth.shape[1]), int(depth.shape[0]), _ptr(depth),
+                                         _ptr(color), int(color.dtype == torch.float64), _ptr(oi), _ptr(oj), _ptr(od), _ptr(oc),
+                                         _stream()), "enslam_gather_pixels")
+    return oi, oj, od, oc
+
+
+def gather_pixels_ok(idx, depth, color):
+    return (idx.is_cuda and depth.is_cuda and color.is_cuda and idx.dtype == torch.int64 and depth.dtype == torch.float32
+            and depth.dim() == 2 and color.dim() == 3 and color.shape[2] == 3 and tuple(color.shape[:2]) == tuple(depth.shape)
+            and color.dtype in (torch.float32, torch.float64) and not depth.requires_grad and not color.requires_grad)
+
+
 def fourier_sincos(x):
     """Parity helper: (sin, cos) float32 of float32 arguments as the embedding kernels evaluate them."""
     _require_hip(x, "x")

@@ -59,14 +59,9 @@ def rays_from_camera_tensor(camera_tensor, i, j, fx, fy, cx, cy):
 def get_samples_from_camera_tensor(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, camera_tensor, depth, color, device):
     """`common.get_samples` with the camera tensor in place of c2w: n random pixels of the window (the same single
     torch.randint draw), their depth / colour samples and their rays."""
-    cols = torch.linspace(W0, W1 - 1, W1 - W0, device=device)
-    rows = torch.linspace(H0, H1 - 1, H1 - H0, device=device)
-    ww = W1 - W0
-    idx = torch.randint((H1 - H0) * ww, (n,), device=device)
-    col, row = idx % ww, idx // ww
-    d = depth[H0:H1, W0:W1][row, col]
-    c = color[H0:H1, W0:W1][row, col]
-    rays_o, rays_d = rays_from_camera_tensor(camera_tensor, cols[col], rows[row], fx, fy, cx, cy)
+    from .common import get_sample_uv           # (same draw; one fused launch for the pixel samples on the GPU)
+    i, j, d, c = get_sample_uv(H0, H1, W0, W1, n, depth, color, device=device)
+    rays_o, rays_d = rays_from_camera_tensor(camera_tensor, i, j, fx, fy, cx, cy)
     return rays_o, rays_d, d, c
 
 

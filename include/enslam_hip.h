@@ -136,6 +136,14 @@ int enslam_zero_blocks(int32_t n, float *const *dst, const int64_t *n_voxels, co
  *   (colour term when color/gt_color are given); the uncertainty carries no gradient (:179). */
 int enslam_pose_rays_fwd(int32_t n, const float *camera_tensor, const float *pix_i, const float *pix_j, float fx,
                          float fy, float cx, float cy, float *rays_o, float *rays_d, void *stream);
+/* Pixel samples of a frame behind the caller's single torch.randint draw (common.py:125-141, get_sample_uv / select_uv):
+ * pixel_index int64 [n] in [0, window_h * window_w) of the window starting at (h0, w0) of an image_h x image_w frame ->
+ * pix_i (column) / pix_j (row) float32 [n], depth_out float32 [n] from depth float32 [image_h, image_w], color_out [n,3] from
+ * color [image_h, image_w, 3] (float32, or float64 with color_is_f64: the dataset readers hand out float64 colours).  The
+ * caller keeps indices inside the window (they come from randint(window_h * window_w)); nothing is range-checked on the device. */
+int enslam_gather_pixels(int32_t n, const int64_t *pixel_index, int32_t h0, int32_t w0, int32_t window_w, int32_t image_w,
+                         int32_t image_h, const float *depth, const void *color, int32_t color_is_f64, float *pix_i,
+                         float *pix_j, float *depth_out, void *color_out, void *stream);
 int enslam_pose_rays_bwd(int32_t n, const float *camera_tensor, const float *pix_i, const float *pix_j, float fx,
                          float fy, float cx, float cy, const float *g_rays_o, const float *g_rays_d,
                          float *g_camera_tensor, void *stream);

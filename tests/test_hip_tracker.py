@@ -90,3 +90,25 @@ def test_fused_pose_rays_and_loss_match_torch_route():
     assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())
     assert float((depth.grad - d2.grad).abs().max()) <= 1e-9 * float(d2.grad.abs().max())
     assert torch.equal(color.grad, c2.grad)
+
+
+@pytest.mark.parametrize("cdtype", [torch.float32, torch.float64])
+def test_get_sample_uv_fused_gather_is_bit_exact(cdtype):
+    """common.get_sample_uv on GPU tensors (one enslam_gather_pixels launch behind the torch.randint draw) returns exactly what
+    the reference's formulation returns -- meshgrid of the window, select_uv (common.py:125-141) -- for the same generator
+    state: pixel coordinates, depth and colour samples bit for bit, float32 and float64 colours, an off-origin window."""
+    import evennicer_slam_amd.common as C
+    H, W, n = 60, 84, 500
+    H0, H1, W0, W1 = 7, 55, 5, 80
+    g = torch.Generator().manual_seed(3)
+    depth = (torch.rand(H, W, generator=g) * 4).cuda()
+    color = torch.rand(H, W, 3, generator=g).to(cdtype).cuda()
+    torch.manual_seed(1234)
+    i, j, d, c = C.get_sample_uv(H0, H1, W0, W1, n, depth, color, device='cuda:0')
+    torch.manual_seed(1234)
+    dd, cc = depth[H0:H1, W0:W1], color[H0:H1, W0:W1]
+    ii, jj = torch.meshgrid(torch.linspace(W0, W1 - 1, W1 - W0).cuda(), torch.linspace(H0, H1 - 1, H1 - H0).cuda(), indexing='ij')
+    ii, jj = ii.t(), jj.t()
+    ri, rj, rd, rc = C.select_uv(ii, jj, n, dd, cc, device='cuda:0')
+    assert i.dtype == ri.dtype and c.dtype == rc.dtype == cdtype and d.dtype == rd.dtype
+    assert torch.equal(i, ri) and torch.equal(j, rj) and torch.equal(d, rd) and torch.equal(c, rc)
