@@ -488,7 +488,8 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
                                                                  const float* __restrict__ rays_o,
                                                                  const float* __restrict__ rays_d,
                                                                  const double* __restrict__ z_vals, DevScene sc,
-                                                                 float* __restrict__ raw_out, float* __restrict__ act_ws, int wli, int stag_cus) {
+                                                                 float* __restrict__ raw_out, float* __restrict__ act_ws, int wli, int stag_cus,
+                                                                 const double* __restrict__ points, int64_t n_points, int apply_mask) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     constexpr bool SPLIT = fwd_split_roles(STAGE);
     const int role = SPLIT ? (int)((blockIdx.x >> 3) & 1) : 0;               // 0: occupancy decoders, 1: colour decoder
@@ -520,7 +521,11 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     else ring_load(ring, sc.packed[3] + XyzLay{32}.oW(0), (XyzLay{32}.oW(1) - XyzLay{32}.oW(0)) / 4, wave, lane);
 
     double pw[3];
-    {
+    if (points != nullptr) {                                   // eval_points: the samples are given (n_tiles = ceil(n_points / 16))
+        const int64_t pi = sidx < n_points ? sidx : n_points - 1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pw[a] = points[pi * 3 + a];
+    } else {
         const double z = z_vals[sidx];
 #pragma unroll
         for (int a = 0; a < 3; ++a) pw[a] = (double)rays_o[ray * 3 + a] + (double)rays_d[ray * 3 + a] * z;
@@ -584,8 +589,8 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
                                        wt, wq, wave, lane, p, q, sx);
         }
     }
-    if (q == 0 && tvalid) {                                                             // rows 0..3 live on q == 0 lanes
-        const float o = inb ? occ[0] : 100.f;                                           // Renderer.py:58
+    if (q == 0 && tvalid && (points == nullptr || sidx < n_points)) {                   // rows 0..3 live on q == 0 lanes
+        const float o = (inb || (points != nullptr && !apply_mask)) ? occ[0] : 100.f;   // Renderer.py:58
         if (!SPLIT) {
             *reinterpret_cast<f32x4*>(raw_out + sidx * 4) = f32x4{col[0], col[1], col[2], o};
         } else if (role == 0) {
@@ -731,18 +736,22 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
                           double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st,
                           const LossSpec* ls, const WorkList* wl) {
-    // Ray mode with raw requested and a moderate ray count: tile-per-wave decoders + separate compositing (more
-    // waves in flight).  Large batches (full-image renders) already fill the chip with one wave per ray.
+    // Ray mode with raw requested: tile-per-wave decoders through the LDS weight ring + separate compositing.  (Round 1 sent
+    // batches above 32768 rays to the one-wave-per-ray kernel; since the ring kernel lost its LDS bank conflicts it is the
+    // faster one at every size: render_img 680 x 1200 55.9 -> 50.8 ms.  ENSLAM_TILE_MODE_MAX_RAYS restores a limit.)
     int tpr = 0;
     static const int64_t tile_mode_max = [] {                 // tuning aid: ENSLAM_TILE_MODE_MAX_RAYS
         const char* e = getenv("ENSLAM_TILE_MODE_MAX_RAYS");
-        return e ? (int64_t)atoll(e) : (int64_t)32768;
+        return e ? (int64_t)atoll(e) : ((int64_t)1 << 40);
     }();
     if (pts == nullptr && raw != nullptr && n_units <= tile_mode_max) {
         tpr = ntl;
         n_units *= ntl;
         ntl = 1;
     }
+    // explicit points (eval_points): the same ring kernel over ceil(n_points / 16) tiles, no compositing
+    const bool pts_ring = pts != nullptr && raw != nullptr && stage >= 1 && stage <= 3 && n_points <= tile_mode_max * 48;
+    if (pts_ring) { tpr = 1; n_units = (n_points + 15) / 16; }
     if (ls != nullptr && tpr == 0) return -1;                 // the fused loss rides in the separate compositing launch
     int rc;
     if (tpr > 0 && stage >= 1 && stage <= 3) {
@@ -764,10 +773,11 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
             return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }();
         const int stag = (ENS_FWD_STAGGER > 0 && !fwd_split_roles(stage) && grid.x <= (unsigned)(3 * cus)) ? cus : 0;
-        if (stage == 1) render_fwd_ring_kernel<1><<<grid, block, fwd_ring_lds_bytes(1), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag);
-        else if (stage == 2) render_fwd_ring_kernel<2><<<grid, block, fwd_ring_lds_bytes(2), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag);
-        else render_fwd_ring_kernel<3><<<grid, block, fwd_ring_lds_bytes(3), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag);
+        if (stage == 1) render_fwd_ring_kernel<1><<<grid, block, fwd_ring_lds_bytes(1), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag, pts, n_points, apply_mask);
+        else if (stage == 2) render_fwd_ring_kernel<2><<<grid, block, fwd_ring_lds_bytes(2), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag, pts, n_points, apply_mask);
+        else render_fwd_ring_kernel<3><<<grid, block, fwd_ring_lds_bytes(3), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag, pts, n_points, apply_mask);
         if (hipGetLastError() != hipSuccess) return -2;
+        if (pts_ring) return 0;
         return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st, ls, wl);
     }
     switch (stage) {
