@@ -493,7 +493,8 @@ __shared__ int ens_vote[2][4];      // per-round activity flags of the 4 waves (
 //   SY_DEP+i   chain waves have deposited dh_i / dpre_i of layer i                    (+4 per executed round)
 //   SY_DW+i    dW waves have read everything layer i's owned products need          (+4 per executed round)
 //   SY_DARG    chain waves have deposited d_arg (tiles HX2..HX1 of their slot)      (+4 per executed round)
-//   SY_FILL    dW waves' slot fills from the activation workspace have landed       (+4 per executed round)
+//   SY_FILLA   the first part of the dW waves' slot fills has landed: h3 and the grid features, all layer 4 needs (+4 per executed round)
+//   SY_FILL    ... and the rest (embedding, h0..h2, coordinates)                     (+4 per executed round)
 //   SY_RING    W^T ring chunks landed (the chain waves stream the ring themselves)   (+4 per chunk)
 //   SY_RDONE   chain waves have read a ring chunk (its buffer may be refilled)       (+4 per chunk)
 //   SY_STG     chain waves have staged dC of their tile for the scatter              (+4 per executed round)
@@ -503,7 +504,7 @@ __shared__ int ens_vote[2][4];      // per-round activity flags of the 4 waves (
 // LDS operations of one wave execute in issue order, so a counter increment issued after a wave's writes (reads) is seen
 // only after them.  Every wait is bounded (ENS_SPIN_LIMIT polls): a protocol error ends in wrong numbers, which the
 // parity tests catch, never in a hung GPU.
-enum { SY_DEP = 0, SY_DW = 5, SY_DARG = 10, SY_FILL = 11, SY_RING = 12, SY_RDONE = 13, SY_STG = 14, SY_STGDONE = 15, SY_N = 16 };
+enum { SY_DEP = 0, SY_DW = 5, SY_DARG = 10, SY_FILL = 11, SY_RING = 12, SY_RDONE = 13, SY_STG = 14, SY_STGDONE = 15, SY_FILLA = 16, SY_N = 17 };
 __shared__ int ens_sync[SY_N];
 constexpr int ENS_SPIN_LIMIT = 1 << 21;
 ENS_DEV void sy_signal(int idx, int lane) {
@@ -1416,11 +1417,14 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         sy_wait(SY_DEP + i, 4 * (int)(r_exec + 1));                 // layer i's deposits are in place
         STAMP(2)        // (stamps build) wait for the chain waves' deposits
         if constexpr (i == 4) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's slot fill has landed
-            sy_signal(SY_FILL, lane);
-            sy_wait(SY_FILL, 4 * (int)(r_exec + 1));                // all four slots filled
+            // layer 4 reads h3 and the grid features only: they were requested first, and vmcnt counts in issue order -- wait
+            // until just the 13 later tiles (embedding, h0..h2, coordinates) are still in flight
+            asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            sy_signal(SY_FILLA, lane);
+            sy_wait(SY_FILLA, 4 * (int)(r_exec + 1));               // ... in all four slots
             STAMP(3)    // slot fill landed
         }
+        if constexpr (i == 3) sy_wait(SY_FILL, 4 * (int)(r_exec + 1));    // the rest of all four slots
 #ifdef ENS_EXP_NO_DW
         sy_signal(SY_DW + i, lane);
         return;                             // timing experiment (wrong results): no owned-tile MFMAs
@@ -1438,6 +1442,10 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
             own_layer_a<CT / 2, 1>(aWc[i], TH, SL::C, CT, 2 * CT, aW4, TP, TX, 2, 4, aB[i], ybias, fb, ow);
         }
         sy_signal(SY_DW + i, lane);                                  // (the operand reads have returned: lgkmcnt(0) inside)
+        if constexpr (i == 4) {              // the rest of this wave's fill has had a layer's time to land; nothing younger is in flight yet
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sy_signal(SY_FILL, lane);
+        }
         STAMP(4)        // owned products
         // one 4-sample piece of the previous tile's scatter behind each of layers 4..1: the chain waves are not waiting for it
         if (want_g && r_exec > 0) {
@@ -1468,10 +1476,16 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         {   // slot `ow` <- the operands the forward parked for chain wave ow's tile of this round
             const float* __restrict__ wsb = A.act_ws + (tile * ACT_SLOTS + (kind - 1)) * ACT_STRIDE;
             float* myslot = slots + ow * SLOT;
-#pragma unroll
-            for (int t = 0; t < SL::FILL; ++t)
+            static_assert(SL::HX3 == 12 && SL::C == 14 && SL::FILL - (2 + CT) == 13, "fill order / vmcnt(13) in own(4)");
+            auto fill_tile = [&](int t) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsb + t * 256 + lane * 4),
                                                  (__attribute__((address_space(3))) void*)(myslot + t * 256), 16, 0, 0);
+            };
+#pragma unroll
+            for (int t = SL::HX3; t < SL::C + CT; ++t) fill_tile(t);        // h3 | grid features: layer 4's operands first
+#pragma unroll
+            for (int t = 0; t < SL::HX3; ++t) fill_tile(t);                 // embedding, h2, h0, h1
+            fill_tile(SL::Q);                                               // coordinates
         }
         STAMP(1)        // fill issue
         own(IC(4)); own(IC(3)); own(IC(2)); own(IC(1)); own(IC(0));
