@@ -495,8 +495,9 @@ __shared__ int ens_vote[2][4];      // per-round activity flags of the 4 waves (
 //   SY_DARG    chain waves have deposited d_arg (tiles HX2..HX1 of their slot)      (+4 per executed round)
 //   SY_FILLA   the first part of the dW waves' slot fills has landed: h3 and the grid features, all layer 4 needs (+4 per executed round)
 //   SY_FILL    ... and the rest (embedding, h0..h2, coordinates)                     (+4 per executed round)
-//   SY_RING    W^T ring chunks landed (the chain waves stream the ring themselves)   (+4 per chunk)
-//   SY_RDONE   chain waves have read a ring chunk (its buffer may be refilled)       (+4 per chunk)
+//   SY_RING    a streamed W^T chunk has landed: layer 3's, then layer 0's (layers 4, 2, 1 are resident; the chain waves
+//              request the chunks themselves, a quarter each)                          (+4 per chunk, 2 chunks per executed round)
+//   SY_RDONE   chain waves have read the streamed chunk (the buffer may take the next) (+4 per chunk)
 //   SY_STG     chain waves have staged dC of their tile for the scatter              (+4 per executed round)
 //   SY_STGDONE dW waves have taken the staged dC of the previous round into registers (+4 per executed round after the first)
 // The feature-gradient scatter (8 k of the chain wave's 43 k cycles per round, branchy scalar code with float atomics) runs
