@@ -654,7 +654,6 @@ int enslam_decoder_bwd_scaled(int32_t stage, int32_t n_rays, int32_t n_samples, 
     DevScene d;
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
     if (!rays_o || !rays_d || !z_vals || !d_raw || !grad_grids || !grad_packed) return ENSLAM_EINVAL;
-    if (act_ws != nullptr && g_rays_o != nullptr && dgrid_ws == nullptr && stage != ENSLAM_STAGE_COARSE) return ENSLAM_EINVAL;
     if (act_ws != nullptr && act_light)                  // the light workspace cannot serve parameter gradients
         for (int k = 1; k < 4; ++k)
             if (grad_packed[k] != nullptr) return ENSLAM_EINVAL;

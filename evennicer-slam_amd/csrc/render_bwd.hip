@@ -1089,7 +1089,11 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         bool nz = false;
 #pragma unroll
         for (int j = 0; j < NE; ++j) nz = nz || dj[j] != 0.f;
-        float* dgw = want_r ? A.dgrid_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * DG_STRIDE : nullptr;
+        // ray gradients: handed off per tile to the ray-gradient launch (dgrid_ws given), or -- dgrid_ws NULL -- computed here at
+        // the end of the round from the registers that would have been handed off (no 3 KB store + load per tile and decoder,
+        // no ray-gradient role in the finish launch)
+        const bool handoff = want_r && A.dgrid_ws != nullptr;
+        float* dgw = handoff ? A.dgrid_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * DG_STRIDE : nullptr;
         {   // skip the round when nothing flows into any of its 4 tiles (one barrier; waves stay in lockstep)
             const int par = (int)(round_no & 1);
             if (lane == 0) ens_vote[par][wave] = __any(nz) ? 1 : 0;
@@ -1097,7 +1101,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             if constexpr (SPLIT) wg_barrier_lds(); else __syncthreads();
             const int any4 = ens_vote[par][0] | ens_vote[par][1] | ens_vote[par][2] | ens_vote[par][3];
             if (!any4) {
-                if (want_r && tvalid) {                             // grid_bwd_kernel reads the hand-off of every tile
+                if (handoff && tvalid) {                            // grid_bwd_kernel reads the hand-off of every tile
                     *reinterpret_cast<f32x4*>(dgw + lane * 4) = splat4(0.f);
                     *reinterpret_cast<f32x4*>(dgw + 256 + lane * 4) = splat4(0.f);
                     *reinterpret_cast<f32x4*>(dgw + DG_DPE + lane * 4) = splat4(0.f);
@@ -1283,7 +1287,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         }
         if constexpr (SPLIT) sy_signal(SY_RDONE, lane);             // the layer-0 chunk (B, B^T ride in it) is no longer needed
         STAMP(9)        // embedding tail (cos recompute, dB^T, dp)
-        if (want_r && tvalid) {         // hand-off to grid_bwd_kernel: dC (register layout) + embedding's position gradient
+        if (handoff && tvalid) {        // hand-off to grid_bwd_kernel: dC (register layout) + embedding's position gradient
             *reinterpret_cast<f32x4*>(dgw + lane * 4) = dc[0];
             *reinterpret_cast<f32x4*>(dgw + 256 + lane * 4) = dc[1];
             *reinterpret_cast<f32x4*>(dgw + DG_DPE + lane * 4) = dpe[0];
@@ -1302,6 +1306,18 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             wave_lds_fence();
             rec_prev = rec;
             pend = true;
+        }
+        if (want_r && !handoff && tvalid) {                         // ray_grad_unit (raygrad.hpp) on this tile, in place
+            const TileGeo G = tile_geo((int64_t)tile, A.ntl, 16 * A.ntl, A.ro, A.rd, A.z, p);
+            const Vox v = make_vox(G.pw, A.sc.lo, A.sc.hi, A.sc.grid[kind]);
+            float gx, gy, gz;
+            coord_grad_partial(v, A.sc.grid[kind], q, dc[0], dc[1], gx, gy, gz);
+            gx += __shfl_xor(gx, 16); gx += __shfl_xor(gx, 32);
+            gy += __shfl_xor(gy, 16); gy += __shfl_xor(gy, 32);
+            gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
+            float dpx = gx * v.gx + dpe[0][0], dpy = gy * v.gy + dpe[0][1], dpz = gz * v.gz + dpe[0][2];
+            if (q != 0) { dpx = dpy = dpz = 0.f; }
+            add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
         }
         ++r_exec;
         STAMP(10)

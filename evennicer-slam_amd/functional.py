@@ -856,8 +856,15 @@ class _RenderFn(torch.autograd.Function):
             d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
             L.check(lib.enslam_composite_bwd_list(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(gD), _ptr(gV), _ptr(gC),
                                                   _ptr(d_raw), _ptr(work), _ptr(wcount), st), "enslam_composite_bwd")
+        # Ray gradients of the saved-activation path: handed to the ray-gradient role of the finish launch through dgw when
+        # that launch exists anyway (grid gradients to transpose back, decoder gradients to unpack: in-kernel ray gradients
+        # cost the mapper step's backward 15 us to save 11 in the finish launch), else computed by the decoder kernel itself at
+        # the end of each round -- a tracker iteration (fixed map and decoders) then has no finish launch at all: 104 -> 100 us.
+        # ENSLAM_INLINE_RAY_GRAD = 1 / 0 forces one or the other.
+        finish_needed = any((need_grid[k] and k not in plan.vm) or need_par[k] for k in plan.kinds)
+        inline_rays = (not finish_needed) if INLINE_RAY_GRAD is None else INLINE_RAY_GRAD
         dgw = None
-        if act is not None and need_rays:
+        if act is not None and need_rays and not inline_rays:
             dgw = torch.empty(lib.enslam_grid_handoff_floats(L.STAGE[plan.stage], N, S), dtype=torch.float32, device=dev)
         ev = plan.state.profile.get('decoder_bwd')
         if ev is not None:                      # bench.py: HIP events around the dominant kernel, on this stream
@@ -933,6 +940,7 @@ class _RenderFn(torch.autograd.Function):
 # stage) when their total stays under this limit; above it the backward recomputes them (slower, no extra memory).
 ACT_WORKSPACE_LIMIT_BYTES = 8 << 30
 
+INLINE_RAY_GRAD = {'1': True, '0': False}.get(os.environ.get('ENSLAM_INLINE_RAY_GRAD', ''), None)     # None: decided per call
 USE_WORK_LIST = os.environ.get('ENSLAM_WORK_LIST', '1') == '1'     # backward walks only the tiles with non-zero d_raw
 
 

@@ -309,8 +309,10 @@ int enslam_composite_loss_bwd(int32_t n_rays, int32_t n_samples, const float *ra
  * enslam_composite_bwd: backward of raw2outputs_nerf_color (common.py:284-296): d(depth,var,rgb) -> d_raw [N*S,4].
  * enslam_decoder_bwd  : everything upstream of raw (decoders, gather, points), consuming d_raw.  With act_ws and
  *   (from the size query above) it reads the saved activations and cell records and leaves what the ray gradients
- *   need in dgrid_ws: follow it with enslam_ray_grad_bwd (enslam_render_bwd does).  With act_ws NULL everything,
- *   ray gradients included, is recomputed in the one kernel and enslam_ray_grad_bwd must not be called.
+ *   need in dgrid_ws: follow it with enslam_ray_grad_bwd (enslam_render_bwd does).  With act_ws given and dgrid_ws NULL
+ *   the kernel computes the ray gradients itself at the end of each round (costs the kernel ~10 %; worth it when nothing
+ *   else would need a launch after it, e.g. tracker iterations on a fixed map).  With act_ws NULL everything, ray
+ *   gradients included, is recomputed in the one kernel.  In both of these cases enslam_ray_grad_bwd must not be called.
  * enslam_ray_grad_bwd : ray gradients of the saved-activation path (fp64 sample geometry, corner re-gather,
  *   coordinate gradient, per-ray reduction) from dgrid_ws, added into g_rays_o / g_rays_d. */
 int enslam_composite_bwd(int32_t n_rays, int32_t n_samples, const float *raw, const double *z_vals,
