@@ -415,8 +415,10 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
         } else {
             lin_lds_tm<2, 2, 32, RO>(acc, wt, h[i - 1]);
         }
-        const unsigned bits = fwd_pos_bits(acc[0]) | (fwd_pos_bits(acc[1]) << 4);
-        if constexpr (i < 4) mb0 |= bits << (8 * i); else mb1 = bits;
+        if (ws != nullptr) {                 // ReLU masks for the backward (forward-only calls skip the 8 % of vector work)
+            const unsigned bits = fwd_pos_bits(acc[0]) | (fwd_pos_bits(acc[1]) << 4);
+            if constexpr (i < 4) mb0 |= bits << (8 * i); else mb1 = bits;
+        }
         acc[0] = relu4(acc[0]) + lds4(wq + OBC);
         acc[1] = relu4(acc[1]) + lds4(wq + OBC + 64);
         lin_lds_tm<2, CT, CD, OC>(acc, wt, c);
