@@ -153,6 +153,41 @@ ENS_DEV Vox make_vox(const double pw[3], const double* lo, const double* hi, con
     return v;
 }
 
+// make_vox for callers that look ONE point up in several grids over the same bound (the forward: middle, fine, colour):
+// the float64 normalisation and the float64 gradient scale -- six float64 divisions -- once per point, the per-grid
+// unnormalise / clip / floor in float32 per grid.  Term for term the arithmetic of axis_coord (bit-identical results).
+struct VoxNorm {
+    float pn[3];          // normalised coordinate in [-1, 1], float32 of the float64 value
+    float gs[3];          // (float)(2 / (hi - lo))
+};
+ENS_DEV VoxNorm vox_norm(const double pw[3], const double* lo, const double* hi) {
+    VoxNorm n;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        n.pn[a] = (float)(((pw[a] - lo[a]) / (hi[a] - lo[a])) * 2.0 - 1.0);
+        n.gs[a] = (float)(2.0 / (hi[a] - lo[a]));
+    }
+    return n;
+}
+ENS_DEV void axis_coord_n(float pn, float gs, int size, int& i0, float& fr, float& gmul) {
+    float c = ((pn + 1.f) / 2.f) * (float)(size - 1);
+    const float mx = (float)(size - 1);
+    float g = (float)(size - 1) / 2.f;
+    if (c <= 0.f) { c = 0.f; g = 0.f; }
+    else if (c >= mx) { c = mx; g = 0.f; }
+    const float fl = floorf(c);
+    i0 = (int)fl;
+    fr = c - fl;
+    gmul = g * gs;
+}
+ENS_DEV Vox make_vox_n(const VoxNorm& n, const DevGrid& g) {
+    Vox v;
+    axis_coord_n(n.pn[0], n.gs[0], g.W, v.ix, v.fx, v.gx);
+    axis_coord_n(n.pn[1], n.gs[1], g.H, v.iy, v.fy, v.gy);
+    axis_coord_n(n.pn[2], n.gs[2], g.D, v.iz, v.fz, v.gz);
+    return v;
+}
+
 // corner k = 4*dz + 2*dy + dx (ATen order tnw,tne,tsw,tse,bnw,bne,bsw,bse); weight = (wx*wy)*wz.
 // A corner beyond the last voxel has weight exactly 0 (fraction is 0 there); its index is clamped so
 // the load stays in bounds, and the weight is forced to 0 as ATen skips it.

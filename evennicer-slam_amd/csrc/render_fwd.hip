@@ -536,6 +536,7 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
 #pragma unroll
     for (int a = 0; a < 3; ++a) inb = inb && (pw[a] < sc.hi[a]) && (pw[a] > sc.lo[a]);
     const float pc = q == 0 ? (float)pw[0] : (q == 1 ? (float)pw[1] : (q == 2 ? (float)pw[2] : 0.f));
+    const VoxNorm vn = vox_norm(pw, sc.lo, sc.hi);             // shared by the middle, fine and colour grids (one bound)
 
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)fsm;
     // lane base of the tile-major weight images (lds_util.hpp) and of the bias rows
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     if (role == 0) {
         f32x4 cm[2];
         {
-            const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[1]);
+            const Vox v = make_vox_n(vn, sc.grid[1]);
             gather8(v, sc.grid[1], q, cm[0], cm[1]);
             if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + WSV + p * 4) = vox_record(v, sc.grid[1]);
         }
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
         if constexpr (STAGE >= 2) {
             f32x4 cf[4];
             {
-                const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[2]);
+                const Vox v = make_vox_n(vn, sc.grid[2]);
                 gather8(v, sc.grid[2], q, cf[0], cf[1]);
                 if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + WSS + WSV + p * 4) = vox_record(v, sc.grid[2]);
             }
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
         if (role == 1 || !SPLIT) {
             f32x4 cc[2];
             {
-                const Vox v = make_vox(pw, sc.lo, sc.hi, sc.grid[3]);
+                const Vox v = make_vox_n(vn, sc.grid[3]);
                 gather8(v, sc.grid[3], q, cc[0], cc[1]);
                 if (wsb != nullptr && q == 0) *reinterpret_cast<f32x4*>(wsb + 2 * WSS + WSV + p * 4) = vox_record(v, sc.grid[3]);
             }
