@@ -86,6 +86,7 @@ bool to_dev_scene(const enslam_scene* s, DevScene& d) {
     for (int a = 0; a < 3; ++a) {
         d.lo[a] = s->bound[2 * a]; d.hi[a] = s->bound[2 * a + 1];
         d.clo[a] = s->coarse_bound[2 * a]; d.chi[a] = s->coarse_bound[2 * a + 1];
+        d.gs[a] = (float)(2.0 / (d.hi[a] - d.lo[a]));      // IEEE double division, as the kernels' own (axis_coord)
     }
     for (int k = 0; k < 4; ++k) {
         d.grid[k] = DevGrid{s->grids[k].data, s->grids[k].D, s->grids[k].H, s->grids[k].W};

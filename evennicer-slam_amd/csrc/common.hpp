@@ -108,6 +108,7 @@ struct DevGrid {
 struct DevScene {
     double lo[3], hi[3];      // Renderer.bound
     double clo[3], chi[3];    // coarse decoder bound
+    float gs[3];              // (float)(2 / (hi - lo)): the gradient scale of the normalisation, divided once on the host
     DevGrid grid[4];
     const float* packed[4];
 };
@@ -160,12 +161,12 @@ struct VoxNorm {
     float pn[3];          // normalised coordinate in [-1, 1], float32 of the float64 value
     float gs[3];          // (float)(2 / (hi - lo))
 };
-ENS_DEV VoxNorm vox_norm(const double pw[3], const double* lo, const double* hi) {
+ENS_DEV VoxNorm vox_norm(const double pw[3], const double* lo, const double* hi, const float* gs) {
     VoxNorm n;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         n.pn[a] = (float)(((pw[a] - lo[a]) / (hi[a] - lo[a])) * 2.0 - 1.0);
-        n.gs[a] = (float)(2.0 / (hi[a] - lo[a]));
+        n.gs[a] = gs[a];
     }
     return n;
 }

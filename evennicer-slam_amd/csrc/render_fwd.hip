@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
 #pragma unroll
     for (int a = 0; a < 3; ++a) inb = inb && (pw[a] < sc.hi[a]) && (pw[a] > sc.lo[a]);
     const float pc = q == 0 ? (float)pw[0] : (q == 1 ? (float)pw[1] : (q == 2 ? (float)pw[2] : 0.f));
-    const VoxNorm vn = vox_norm(pw, sc.lo, sc.hi);             // shared by the middle, fine and colour grids (one bound)
+    const VoxNorm vn = vox_norm(pw, sc.lo, sc.hi, sc.gs);             // shared by the middle, fine and colour grids (one bound)
 
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)fsm;
     // lane base of the tile-major weight images (lds_util.hpp) and of the bias rows
