@@ -391,6 +391,7 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
     }
     FST(sx, 2)      // workspace stores of emb / c / coordinates
     f32x4 h[5][2];
+    f32x4 wo_a0 = splat4(0.f), wo_a1 = splat4(0.f), wo_b = splat4(0.f);
     unsigned mb0 = 0u, mb1 = 0u;
     auto layer = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -399,7 +400,8 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
         constexpr int OB = RO + 32 * K * 4, OC = OB + 32 * 4, OBC = OC + 32 * CD * 4;
         float* nxt = ring + (((C0 + i + 1) & 1) ? RB : 0);
         if constexpr (i < 4) {
-            ring_load(nxt, pk + L.oW(i + 1), (L.oW(i + 2) - L.oW(i + 1)) / 4, wave, lane);
+            // (layer 4's chunk brings the output layer along: Wo [16][32] | bo [16] follow it in the packed decoder)
+            ring_load(nxt, pk + L.oW(i + 1), (L.oW(i + 2) - L.oW(i + 1) + (i == 3 ? 528 : 0)) / 4, wave, lane);
         } else if constexpr (NEXT_CD > 0) {
             constexpr XyzLay LN{NEXT_CD};
             ring_load(nxt, pk_next + LN.oW(0), (LN.oW(1) - LN.oW(0)) / 4, wave, lane);
@@ -424,6 +426,13 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
         lin_lds_tm<2, CT, CD, OC>(acc, wt, c);
         h[i][0] = acc[0];
         h[i][1] = acc[1];
+        if constexpr (i == 4) {             // output-layer fragments out of the same ring slot, before the barrier that frees it
+            constexpr int OWO = RO + (L.oW(5) - L.oW(4)) * 4;
+            const unsigned wr = (unsigned)(p * 32 + 4 * q) * 4u;
+            wo_a0 = lds4(wq - (unsigned)q * 16u + wr + OWO);
+            wo_a1 = lds4(wq - (unsigned)q * 16u + wr + OWO + 64);
+            wo_b = lds4(wq + OWO + 512 * 4);
+        }
         FST(sx, 3)  // layer: prefetch issue, bias, fragment reads + MFMAs, relu
         if (ws != nullptr) {
             constexpr int T = i == 2 ? 6 : (i == 0 ? 8 : (i == 1 ? 10 : 12));
@@ -458,13 +467,13 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
         FST(sx, 5)  // barrier (+ wait for the next chunk)
     };
     layer(IC(0)); layer(IC(1)); layer(IC(2)); layer(IC(3)); layer(IC(4));
-    // output layer (tiny): weights straight from global
-    f32x4 oo[1], hh[1][2];
-    hh[0][0] = h[4][0];
-    hh[0][1] = h[4][1];
-    out_layer<1>(oo, pk + L.oWo(), pk + L.obo(), hh, p, q);
-    o = oo[0];
-    FST(sx, 6)      // output layer (weights from global)
+    // output layer (tiny): its weights rode in layer 4's ring chunk (from global they cost 2 k cycles of load latency per decoder)
+    o = wo_b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o = MFMA16(wo_a0[r], h[4][0][r], o);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o = MFMA16(wo_a1[r], h[4][1][r], o);
+    FST(sx, 6)      // output layer
 }
 
 // In the colour stage the launch is split into two ROLES of workgroups: the occupancy decoders (middle + fine, 588 MFMAs
