@@ -373,12 +373,16 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
     constexpr XyzLay L{CT * 16};
     constexpr int CD = CT * 16;
     f32x4 emb[6];
+    // B^T [96][4] sits right in front of layer 0's chunk in the packed decoder and rides in with it (ring slot of chunk C0:
+    // [B^T | W0 | b0 | Wc0 | bc0]): six LDS reads instead of six global loads in front of the embedding MFMAs
+    constexpr int RO0 = (C0 & 1) ? RB * 4 : 0;
+    const unsigned bt = wq - (unsigned)q * 16u + RO0 + (unsigned)(p * 4 + q) * 4u;
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
-        const float a = pk[L.oBT() + (16 * t + p) * 4 + q];
+        const float a = *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(bt + 16 * t * 16));
         emb[t] = sin4(MFMA16(a, pc, splat4(0.f)));
     }
-    FST(sx, 1)      // embedding: B^T loads, MFMA, sin
+    FST(sx, 1)      // embedding: B^T reads, MFMA, sin
     if (ws != nullptr) {
         if (!wl) {
 #pragma unroll
@@ -395,7 +399,7 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
     unsigned mb0 = 0u, mb1 = 0u;
     auto layer = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        constexpr int RO = ((C0 + i) & 1) ? RB * 4 : 0;
+        constexpr int RO = (((C0 + i) & 1) ? RB * 4 : 0) + (i == 0 ? 384 * 4 : 0);      // (layer 0: behind B^T)
         constexpr int K = L.K(i);
         constexpr int OB = RO + 32 * K * 4, OC = OB + 32 * 4, OBC = OC + 32 * CD * 4;
         float* nxt = ring + (((C0 + i + 1) & 1) ? RB : 0);
@@ -404,7 +408,7 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
             ring_load(nxt, pk + L.oW(i + 1), (L.oW(i + 2) - L.oW(i + 1) + (i == 3 ? 528 : 0)) / 4, wave, lane);
         } else if constexpr (NEXT_CD > 0) {
             constexpr XyzLay LN{NEXT_CD};
-            ring_load(nxt, pk_next + LN.oW(0), (LN.oW(1) - LN.oW(0)) / 4, wave, lane);
+            ring_load(nxt, pk_next, LN.oW(1) / 4, wave, lane);                       // B^T | chunk 0 of the next decoder
         }
         f32x4 acc[2];
         acc[0] = lds4(wq + OB);
@@ -528,8 +532,8 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     const int64_t ray = tile / tiles_per_ray;
     const int64_t sidx = tile * 16 + p;
 
-    if (role == 0) ring_load(ring, sc.packed[1] + XyzLay{32}.oW(0), (XyzLay{32}.oW(1) - XyzLay{32}.oW(0)) / 4, wave, lane);   // chunk 0
-    else ring_load(ring, sc.packed[3] + XyzLay{32}.oW(0), (XyzLay{32}.oW(1) - XyzLay{32}.oW(0)) / 4, wave, lane);
+    if (role == 0) ring_load(ring, sc.packed[1], XyzLay{32}.oW(1) / 4, wave, lane);   // B^T | chunk 0
+    else ring_load(ring, sc.packed[3], XyzLay{32}.oW(1) / 4, wave, lane);
 
     double pw[3];
     if (points != nullptr) {                                   // eval_points: the samples are given (n_tiles = ceil(n_points / 16))
