@@ -1034,6 +1034,12 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         for (int f = 0; f < 8; ++f) aWo[j][f] = 0.f;
     }
 
+    // Wo^T fragments of the output layer's backward: the same two values every round.  Left in the loop they were two global
+    // loads per round, each followed by a vmcnt(0) (which also drains the chunk prefetch and the next round's d_raw) in
+    // front of the round's first MFMAs.
+    float woT[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) woT[rt] = pk[L.oWoT() + (16 * rt + p) * 4 + q];
     const int64_t n_tiles = work_count(A);                          // (work items; all tiles without a work list)
     const int64_t stride = (int64_t)n_wg * 4;
     STAMP_DECL
@@ -1150,7 +1156,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             const float dq = NOUT == 4 ? (q == 0 ? draw[0] : (q == 1 ? draw[1] : (q == 2 ? draw[2] : 0.f)))
                                        : (q == 0 ? draw[3] : 0.f);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) dh[rt] = MFMA16(pk[L.oWoT() + (16 * rt + p) * 4 + q], dq, dh[rt]);
+            for (int rt = 0; rt < 2; ++rt) dh[rt] = MFMA16(woT[rt], dq, dh[rt]);
         }
         f32x4 dc[2] = {splat4(0.f), splat4(0.f)};
         f32x4 demb[6];
