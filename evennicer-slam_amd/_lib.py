@@ -120,6 +120,14 @@ _SIGS = {
     "enslam_decoder_bwd_scaled": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
                                                  c_void_p, c_void_p, c_void_p, c_int32, c_void_p, POINTER(Grid), POINTER(c_void_p),
                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "enslam_bwd_partial_floats": (c_size_t, [ctypes.c_int]),
+    "enslam_decoder_bwd_partials": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
+                                                   c_void_p, c_void_p, c_void_p, c_int32, c_void_p, POINTER(Grid), POINTER(c_void_p),
+                                                   POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "enslam_step_finish_partials": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),
+                                                   POINTER(c_void_p), c_int32, POINTER(c_int32), POINTER(c_void_p), POINTER(c_void_p),
+                                                   POINTER(MlpParams), c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                                   POINTER(Scene), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "enslam_rgbd_loss_fwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,
                                             c_void_p]),
     "enslam_rgbd_loss_bwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,

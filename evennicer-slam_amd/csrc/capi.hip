@@ -18,7 +18,7 @@ void add(PackJob& j, float* src, int off, int rows, int cols, int src_ld, int ds
 }
 void clear_job(PackJob& j) {
     j.n = 0;
-    for (int i = 0; i < 4; ++i) j.packed[i] = nullptr;
+    for (int i = 0; i < 4; ++i) { j.packed[i] = nullptr; j.part[i] = nullptr; j.part_stride[i] = 0; }
 }
 
 // Build the segment table of one decoder.  `with_transposed` adds the backward-only copies.
@@ -129,6 +129,11 @@ size_t enslam_packed_grad_floats(int kind) {
     if (is_xyz(kind)) return (size_t)XyzLay{cdim(kind)}.fwd_floats();
     if (kind == ENSLAM_MLP_COARSE) return (size_t)FeatLay{}.fwd_floats();
     return 0;
+}
+
+size_t enslam_bwd_partial_floats(int kind) {
+    const size_t gf = enslam_packed_grad_floats(kind);
+    return gf == 0 ? 0 : 16 + (size_t)ens_bwd_max_workgroups() * gf;
 }
 
 int enslam_pack_mlp(int kind, const enslam_mlp_params* params, float* packed, void* stream) {
@@ -250,7 +255,8 @@ static bool work_list_of(int32_t* tiles, int32_t* count, WorkList& w) {
 }
 static int step_finish_impl(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
                             const uint8_t* const* need, int32_t n_dec, const int32_t* kinds, const float* const* packed_grads,
-                            const enslam_mlp_params* grads, const RayGradArgs* rg, void* stream, uint8_t* const* prev = nullptr) {
+                            const enslam_mlp_params* grads, const RayGradArgs* rg, void* stream, uint8_t* const* prev = nullptr,
+                            const float* const* partials = nullptr) {
     if (n_dec < 0 || n_dec > 4 || n_conv < 0 || n_conv > 4) return ENSLAM_EINVAL;
     PackJob pj;
     clear_job(pj);
@@ -259,6 +265,10 @@ static int step_finish_impl(int32_t n_conv, const float* const* src, float* cons
         if (!packed_grads[i] || (!is_xyz(kinds[i]) && kinds[i] != ENSLAM_MLP_COARSE)) return ENSLAM_EINVAL;
         g_seg_dec = i;
         pj.packed[i] = const_cast<float*>(packed_grads[i]);
+        if (partials != nullptr && partials[i] != nullptr) {
+            pj.part[i] = partials[i];
+            pj.part_stride[i] = (int)enslam_packed_grad_floats(kinds[i]);
+        }
         build_job(kinds[i], grads[i], false, pj, true);
     }
     g_seg_dec = 0;
@@ -324,6 +334,33 @@ int enslam_step_finish_rays_prev(int32_t n_conv, const float* const* src, float*
                            work_list ? &wl : nullptr))
         return ENSLAM_EINVAL;
     return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, &rg, stream, prev);
+}
+
+int enslam_step_finish_partials(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                                const uint8_t* const* need, uint8_t* const* prev, int32_t n_dec, const int32_t* kinds,
+                                const float* const* packed_grads, const float* const* grad_partials, const enslam_mlp_params* grads,
+                                int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                                const double* z_vals, const enslam_scene* scene, float* dgrid_ws, float* g_rays_o, float* g_rays_d,
+                                const int32_t* work_list, const int32_t* work_count, void* stream) {
+    if (n_rays < 0) return ENSLAM_EINVAL;
+    if (prev != nullptr) {
+        if (!need || n_conv < 0 || n_conv > 4) return ENSLAM_EINVAL;
+        for (int i = 0; i < n_conv; ++i)
+            if (!need[i] || !prev[i]) return ENSLAM_EINVAL;
+    }
+    if (n_rays == 0 || stage == ENSLAM_STAGE_COARSE || dgrid_ws == nullptr)
+        return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, nullptr, stream, prev, grad_partials);
+    if (!samples_ok(n_samples)) return ENSLAM_EUNSUPPORTED;
+    DevScene d;
+    if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
+    if (!rays_o || !rays_d || !z_vals || !g_rays_o || !g_rays_d) return ENSLAM_EINVAL;
+    RayGradArgs rg;
+    WorkList wl;
+    if (!work_list_of(const_cast<int32_t*>(work_list), const_cast<int32_t*>(work_count), wl)) return ENSLAM_EINVAL;
+    if (!ens_ray_grad_args(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, dgrid_ws, g_rays_o, g_rays_d, rg,
+                           work_list ? &wl : nullptr))
+        return ENSLAM_EINVAL;
+    return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, &rg, stream, prev, grad_partials);
 }
 
 int enslam_grids_convert(int32_t n, const float* const* src, float* const* dst, const int64_t* n_voxels,
@@ -649,6 +686,14 @@ int enslam_decoder_bwd_scaled(int32_t stage, int32_t n_rays, int32_t n_samples, 
                               const float* act_ws, int32_t act_light, float* dgrid_ws, const enslam_grid* grad_grids,
                               float* const* grad_packed, float* g_rays_o, float* g_rays_d, const int32_t* work_list,
                               const int32_t* work_count, void* stream) {
+    return enslam_decoder_bwd_partials(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, d_raw, d_raw_scale, act_ws, act_light,
+                                       dgrid_ws, grad_grids, grad_packed, nullptr, g_rays_o, g_rays_d, work_list, work_count, stream);
+}
+int enslam_decoder_bwd_partials(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                                const double* z_vals, const enslam_scene* scene, const float* d_raw, const double* d_raw_scale,
+                                const float* act_ws, int32_t act_light, float* dgrid_ws, const enslam_grid* grad_grids,
+                                float* const* grad_packed, float* const* grad_partial, float* g_rays_o, float* g_rays_d,
+                                const int32_t* work_list, const int32_t* work_count, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (!samples_ok(n_samples)) return ENSLAM_EUNSUPPORTED;
@@ -668,7 +713,8 @@ int enslam_decoder_bwd_scaled(int32_t stage, int32_t n_rays, int32_t n_samples, 
     WorkList wl;
     if (!work_list_of(const_cast<int32_t*>(work_list), const_cast<int32_t*>(work_count), wl)) return ENSLAM_EINVAL;
     return ens_launch_decoder_bwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, d_raw, act_ws, act_light != 0, dgrid_ws, gg,
-                                  grad_packed, g_rays_o, g_rays_d, (hipStream_t)stream, d_raw_scale, work_list ? &wl : nullptr);
+                                  grad_packed, g_rays_o, g_rays_d, (hipStream_t)stream, d_raw_scale, work_list ? &wl : nullptr,
+                                  grad_partial);
 }
 
 int enslam_ray_grad_bwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,

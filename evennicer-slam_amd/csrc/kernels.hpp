@@ -35,6 +35,8 @@ struct PackSeg {
 struct PackJob {
     PackSeg seg[ENS_MAX_SEGS];
     float* packed[4];                        // packed buffers of the decoders of this job
+    const float* part[4];                    // unpack only: per-workgroup partial images to sum instead of packed[] (flush_image,
+    int part_stride[4];                      // render_bwd.hip): [16-float header, word 0 = rows | rows x part_stride floats]
     int n;
 };
 struct AdamJob {                 // masked Adam over up to 4 voxel-major grids in one launch (Mapper.py:328-361,573-602)
@@ -141,4 +143,6 @@ int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* 
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
                            const DevScene& sc, const float* d_raw, const float* act_ws, int act_light, float* dgrid_ws,
                            const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,
-                           hipStream_t st, const double* draw_scale = nullptr, const WorkList* wl = nullptr);
+                           hipStream_t st, const double* draw_scale = nullptr, const WorkList* wl = nullptr,
+                           float* const* grad_partial = nullptr);
+int ens_bwd_max_workgroups();      // upper bound of the workgroups of one decoder role (rows of a partial buffer)

@@ -124,6 +124,25 @@ ENS_DEV void wave_lds_fence() {
 
 ENS_DEV void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// End of a decoder role: the workgroup's packed-layout gradient image (GF floats in LDS) leaves the kernel either as float
+// atomics into the one accumulator all workgroups share, or -- gpart given -- as plain 16-byte stores into this workgroup's
+// own row of a partial buffer [16-float header | n_wg rows of GF floats] (header word 0 = n_wg, written by workgroup 0 of
+// the role), which the finish launch sums while it unpacks (pack_body, util_kernels.hip).  Round 3: all 256 workgroups
+// reach this point within a few microseconds of each other, and their 17.6 MB of atomics on the same 53 k addresses ran at
+// the chip-wide memory-side atomic rate (1.3 TB/s): 10-13 us at the tail of the kernel (tools/stamps_bwd.py, budget).
+ENS_DEV void flush_image(const float* sacc, int GF, float* gpk, float* gpart, int wg, int n_wg, int nthr) {
+    if (gpart != nullptr) {
+        if (wg == 0 && threadIdx.x == 0) reinterpret_cast<int*>(gpart)[0] = n_wg;
+        f32x4* row = reinterpret_cast<f32x4*>(gpart + 16 + (int64_t)wg * GF);
+        for (int e = threadIdx.x; e < GF / 4; e += nthr) row[e] = *reinterpret_cast<const f32x4*>(sacc + 4 * e);
+        return;
+    }
+    for (int e = threadIdx.x; e < GF; e += nthr) {
+        const float vsum = sacc[e];
+        if (vsum != 0.f) atomicAdd(gpk + e, vsum);
+    }
+}
+
 // ---- owner-computes weight gradients ----------------------------------------------------------
 // The 4 waves of a workgroup work in lockstep on 4 sample tiles.  Each wave deposits its tile's operands
 // in its own LDS slot; after a barrier every wave accumulates the dW output tiles IT OWNS (tile index
@@ -453,6 +472,7 @@ struct BwdArgs {
     DevScene sc;
     DevGrid ggrid[4];        // gradient accumulators (data may be null)
     float* gpacked[4];       // packed-layout gradient accumulators (may be null)
+    float* gpart[4];         // per-workgroup partial images of the packed-layout gradients (null: float atomics into gpacked)
     float* g_ro;
     float* g_rd;
     int role_begin[5];       // workgroup ranges of the roles (decoder kinds) of this launch
@@ -948,10 +968,7 @@ ENS_DEV void xyz_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem)
             if (lane == 0) lds_add(sacc + L.obo() + j, bsum);
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < GF; e += 256) {
-            const float vsum = sacc[e];
-            if (vsum != 0.f) atomicAdd(gpk + e, vsum);
-        }
+        flush_image(sacc, GF, gpk, A.gpart[kind], wg, n_wg, 256);
     }
 }
 
@@ -1046,6 +1063,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     STAMP_START
     prefetch(IC(4)); prefetch(IC(2)); prefetch(IC(1));              // resident chunks (SPLIT: the dW waves fill the slots)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // landed before the first round's vote barrier lets anyone read them
+    TL(1)
     unsigned round_no = 0;
     unsigned r_exec = 0;                                            // executed (not skipped) rounds so far: targets of the hand-off counters
     // The feature-gradient scatter of a tile is deferred into the next executed round (after its first barrier): the
@@ -1325,19 +1343,27 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             if (q != 0) { dpx = dpy = dpz = 0.f; }
             add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
         }
+        TL(2 + (r_exec < 7 ? r_exec : 7))
         ++r_exec;
         STAMP(10)
     }
     if constexpr (!SPLIT) scatter_pending();
     STAMP_FLUSH
+    TL(10)
 
     // ---- flush: stage the owned tiles into a packed-layout LDS image, then coalesced global atomics
     if (want_w) {
         float* sacc = slots;
         const int nthr = SPLIT ? 512 : 256;
-        __syncthreads();
-        for (int e = threadIdx.x; e < GF; e += nthr) sacc[e] = 0.f;
-        __syncthreads();
+        // The three barriers of the flush order LDS traffic only (wg_barrier_lds): a __syncthreads() here made every wave wait
+        // for the acknowledges of the float atomics of its last scatter (~3 us, tools/stamps_bwd.py budget).  With partial
+        // images only the output layer's rows are summed in LDS (lds_add) and need clearing; the padding of the image is never
+        // read by the finish launch.
+        const bool part = A.gpart[kind] != nullptr;
+        wg_barrier_lds();
+        if (part) { for (int e = L.oWo() + threadIdx.x; e < GF; e += nthr) sacc[e] = 0.f; }
+        else { for (int e = threadIdx.x; e < GF; e += nthr) sacc[e] = 0.f; }
+        wg_barrier_lds();
         if constexpr (!SPLIT) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -1368,12 +1394,10 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
             float bsum = wave_sum(aBo[j]);
             if (lane == 0) lds_add(sacc + L.obo() + j, bsum);
         }
-        __syncthreads();
-        for (int e = threadIdx.x; e < GF; e += nthr) {
-            const float vsum = sacc[e];
-            if (vsum != 0.f) atomicAdd(gpk + e, vsum);
-        }
+        wg_barrier_lds();
+        flush_image(sacc, GF, gpk, A.gpart[kind], wg, n_wg, nthr);
     }
+    TL(12)
 }
 
 // The dW half of decoder_bwd_split_kernel (waves 4..7): the owned weight-gradient tiles of xyz_role_saved, one barrier
@@ -1433,6 +1457,7 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
     };
     STAMP_DECL
     STAMP_START
+    TL(1)
     auto own = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int TH = (i & 1) ? SL::H1 : SL::H0, TP = (i & 1) ? SL::P1 : SL::P0;
@@ -1516,9 +1541,11 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         STAMP(6)        // wait for d_arg
         own_outer_a<2>(aBT, fb, SL::HX2, SL::Q, 1, 6, ow);                                         // dB^T
         tile_prev = tile;
+        TL(2 + (r_exec < 7 ? r_exec : 7))
         ++r_exec;
         STAMP(7)        // dB^T
     }
+    TL(10)
 #ifdef ENS_STAMPS
     if (g_stamp_buf && lane == 0) {         // dW waves: second half of the stamp buffer (s_memrealtime span in the last slot)
         unsigned long long rt1_;
@@ -1535,10 +1562,14 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         scatter_piece<12>(sst, sval, sri, srx, sry, srz, ggrid, lane);
         if (sst.open) scatter_flush(sst, ggrid, lane, 15, 0);
     }
+    TL(11)
+    // (the barriers of the flush order LDS traffic only: the atomics just issued drain behind them, see xyz_role_saved)
     float* sacc = slots;
-    __syncthreads();
-    for (int e = threadIdx.x; e < GF; e += 512) sacc[e] = 0.f;
-    __syncthreads();
+    const bool part = A.gpart[kind] != nullptr;
+    wg_barrier_lds();
+    if (part) { for (int e = L.oWo() + threadIdx.x; e < GF; e += 512) sacc[e] = 0.f; }
+    else { for (int e = threadIdx.x; e < GF; e += 512) sacc[e] = 0.f; }
+    wg_barrier_lds();
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
 #pragma unroll
@@ -1555,11 +1586,9 @@ ENS_DEV void xyz_dw_loop(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
 #pragma unroll
     for (int j = 0; j < 2; ++j)
         if (ow + 4 * j < 6) stage_tile(sacc + L.oBT(), 4, 0, 1, ow + 4 * j, aBT[j], 93, 3, p, q);
-    __syncthreads();
-    for (int e = threadIdx.x; e < GF; e += 512) {
-        const float vsum = sacc[e];
-        if (vsum != 0.f) atomicAdd(gpk + e, vsum);
-    }
+    wg_barrier_lds();
+    flush_image(sacc, GF, gpk, A.gpart[kind], wg, n_wg, 512);
+    TL(12)
 }
 
 // Ray-gradient side of the backward for the saved-activation path: one wave per (16-sample tile, decoder slot)
@@ -1718,10 +1747,7 @@ ENS_DEV void feat_role(const BwdArgs& A, int wg, int n_wg, float* smem) {
         if (wave < 2) stage_tile(sacc + L.oWo(), 32, 0, 2, wave, aWo[0], 1, 32, p, q);
         if (wave == 2) stage_bias(sacc + L.obo(), 0, aBo, 1, p, q);
         __syncthreads();
-        for (int e = threadIdx.x; e < GF; e += 256) {
-            const float vsum = sacc[e];
-            if (vsum != 0.f) atomicAdd(gpk + e, vsum);
-        }
+        flush_image(sacc, GF, gpk, A.gpart[0], wg, n_wg, 256);
     }
 }
 
@@ -1747,6 +1773,7 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(BwdArgs A) {
 // per SIMD.  Waves 0..3 run the dX chain of one tile each (xyz_role_saved<.., SPLIT>), waves 4..7 accumulate the owned
 // weight-gradient tiles (xyz_dw_loop) from the operands the chain waves deposit, one barrier phase behind.
 __global__ __launch_bounds__(512, 1) void decoder_bwd_split_kernel(BwdArgs A) {
+    TL(0)           // (stamps build) kernel entry
     if (threadIdx.x < SY_N) ens_sync[threadIdx.x] = 0;
     __syncthreads();
     int role = 0;
@@ -1796,6 +1823,8 @@ int device_cus() {
 
 }  // namespace
 
+int ens_bwd_max_workgroups() { return device_cus(); }
+
 #ifdef ENS_STAMPS
 extern "C" int enslam_debug_set_stamp_buffer(void* p) {
     unsigned long long* v = (unsigned long long*)p;
@@ -1819,7 +1848,7 @@ int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* 
 int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z,
                            const DevScene& sc, const float* d_raw, const float* act_ws, int act_light, float* dgrid_ws,
                            const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,
-                           hipStream_t st, const double* draw_scale, const WorkList* wl) {
+                           hipStream_t st, const double* draw_scale, const WorkList* wl, float* const* grad_partial) {
     if (n_rays <= 0) return 0;
     BwdArgs A;
     A.act_light = act_light;
@@ -1847,7 +1876,7 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         case 0: case 1: case 2: case 3: break;
         default: return -1;
     }
-    for (int k = 0; k < 4; ++k) { A.ggrid[k] = DevGrid{nullptr, 0, 0, 0}; A.gpacked[k] = nullptr; }
+    for (int k = 0; k < 4; ++k) { A.ggrid[k] = DevGrid{nullptr, 0, 0, 0}; A.gpacked[k] = nullptr; A.gpart[k] = nullptr; }
     int lds = 0, lds_saved = 0;
     // drop roles with nothing to produce
     int kk[3], n2 = 0;
@@ -1858,6 +1887,7 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         if (!any) continue;
         A.ggrid[k] = grad_grids[k];
         A.gpacked[k] = grad_packed[k];
+        A.gpart[k] = (grad_partial != nullptr && grad_packed[k] != nullptr) ? grad_partial[k] : nullptr;
         kk[n2] = k; cc[n2] = cost[i]; csum += cost[i]; ++n2;
         const int need = k == 0 ? lds_bytes_feat() : lds_bytes_xyz(k == 2 ? 4 : 2);
         lds = need > lds ? need : lds;
@@ -1924,7 +1954,7 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
             for (int i = 0; i < 3; ++i) cached[i] = split[i];
         }
         BwdArgs B = A;
-        for (int k = 0; k < 4; ++k) { B.ggrid[k] = DevGrid{nullptr, 0, 0, 0}; B.gpacked[k] = nullptr; }
+        for (int k = 0; k < 4; ++k) { B.ggrid[k] = DevGrid{nullptr, 0, 0, 0}; B.gpacked[k] = nullptr; B.gpart[k] = nullptr; }
         B.n_roles = n;
         int begin = 0;
         for (int i = 0; i < n; ++i) {
@@ -1932,6 +1962,7 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
             B.role_begin[i] = begin;
             B.ggrid[ks[i]] = A.ggrid[ks[i]];
             B.gpacked[ks[i]] = A.gpacked[ks[i]];
+            B.gpart[ks[i]] = A.gpart[ks[i]];
             begin += split[i];
         }
         B.role_begin[n] = total;

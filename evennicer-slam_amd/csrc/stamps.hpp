@@ -7,11 +7,15 @@ static __device__ unsigned long long* g_stamp_buf = nullptr;      // one per tra
 #define STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory"); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory"); __builtin_amdgcn_sched_barrier(0); }
 #define STAMP(k) { unsigned long long st_now; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); __builtin_amdgcn_sched_barrier(0); st_acc[k] += st_now - st_prev; st_prev = st_now; }
 #define STAMP_FLUSH { { unsigned long long rt1_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1_)::"memory"); st_acc[ENS_NSEG - 1] = rt1_ - st_rt0; } if (g_stamp_buf && lane == 0) { for (int k_ = 0; k_ < ENS_NSEG; ++k_) g_stamp_buf[((size_t)blockIdx.x * 4 + wave) * ENS_NSEG + k_] = st_acc[k_]; } }
+// absolute s_memrealtime (100 MHz) marks of a wave's lane 0: [workgroup][wave 0..7][16 slots] behind the per-segment totals
+#define ENS_TL_BASE (2 * 256 * 4 * ENS_NSEG)
+#define TL(slot) { if (g_stamp_buf && (threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); g_stamp_buf[ENS_TL_BASE + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = t_; } }
 #else
 #define STAMP_DECL
 #define STAMP_START
 #define STAMP(k)
 #define STAMP_FLUSH
+#define TL(slot)
 #endif
 
 // the same through a context object handed to device functions (forward kernel)

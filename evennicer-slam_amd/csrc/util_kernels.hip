@@ -630,22 +630,63 @@ __global__ __launch_bounds__(256) void pack_kernel(PackJob job, float* __restric
     pack_body(job, packed, unpack, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
+// Unpack direction of a decoder whose gradient arrives as per-workgroup partial images (flush_image, render_bwd.hip:
+// [16-float header, word 0 = rows | rows x part_stride floats]): the workgroup takes the 64-element groups y, y + ny, ... of
+// segment `seg`; wave w sums the rows w, w + 4, ... of its group (a row's 64 elements are 256 contiguous bytes; eight
+// independent loads in flight per lane), the four partial sums meet in LDS and wave 0 writes the parameter-shaped gradient.
+// One group per workgroup when ny = 64 (the largest segment has 4096 elements): ~20 rows per wave instead of the ~85
+// dependent-latency steps per lane of a one-thread-per-element sum (finish launch 27 -> 44 us with that form).
+ENS_DEV void unpack_partial_body(const PackJob& job, int seg, int y, int ny) {
+    __shared__ float red[4][64];
+    const PackSeg s = job.seg[seg];
+    const float* pp0 = job.part[s.dec];
+    if (pp0 == nullptr) { pack_body(job, nullptr, 1, seg, y, ny); return; }     // (block-uniform)
+    const int n = s.rows * s.cols, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rows = reinterpret_cast<const int*>(pp0)[0];
+    const int64_t stride = job.part_stride[s.dec];
+    for (int g = y; g * 64 < n; g += ny) {
+        const int e = g * 64 + lane;
+        float acc = 0.f;
+        float* src = nullptr;
+        if (e < n) {
+            const int r = e / s.cols, c = e - r * s.cols;
+            src = s.src + ((s.transpose & 1) ? (int64_t)c * s.src_ld + r : (int64_t)r * s.src_ld + c);
+            const float* pp = pp0 + 16 + s.off + r * s.dst_ld + c;          // gradient images are plain row-major (build_job, fs = 0)
+            int r0 = w;
+            float a[8];
+            for (; r0 + 28 < rows; r0 += 32) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = pp[(int64_t)(r0 + 4 * j) * stride];
+                acc += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+            }
+            for (; r0 < rows; r0 += 4) acc += pp[(int64_t)r0 * stride];
+        }
+        red[w][lane] = acc;
+        __syncthreads();
+        if (w == 0 && e < n) *src = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        __syncthreads();
+    }
+}
+
 // The independent small jobs around a render call in ONE launch (each was a 4-6 us kernel of its own): workgroup
 // ranges [decoder (un)packing | grid layout conversion | accumulator clearing].  Before the forward: pack the decoders,
 // convert the touched blocks to voxel-major, clear the gradient accumulators.  After the backward: transposed-back
 // grid gradients and unpacked decoder gradients.
 __global__ __launch_bounds__(256) void step_kernel(PackJob pj, int unpack, ConvJob cj, int to_vm, ConvJob zj,
                                                    float* __restrict__ flat, int64_t n_flat, int nb_ray, int nb_pack, int nb_conv,
-                                                   int nb_zero, RayGradArgs rg) {
+                                                   int nb_zero, RayGradArgs rg, int pack_ny) {
     // Workgroups are dispatched in blockIdx order: the ray-gradient units (latency-bound: float64 geometry, a dependent
     // corner re-gather, a coordinate-gradient reduction; 16 us as a launch of its own) come FIRST so that they run under
     // the bandwidth-bound roles (zero-fill / transposed-back gradients) instead of behind them.
-    const int b = blockIdx.x;
+    const int b = blockIdx.x;       // (dealing the partial-image sums and the ray units alternately: finish 28 -> 31 us)
     if (b < nb_ray) {                       // ray gradients: one wave per (tile, decoder slot), four per workgroup
         const int64_t unit = (int64_t)b * 4 + (threadIdx.x >> 6);
         if (unit < (int64_t)rg.n_rays * rg.ntl * rg.n_slots) ray_grad_unit(rg, unit, (int)(threadIdx.x & 63));
     }
-    else if (b < nb_ray + nb_pack) pack_body(pj, nullptr, unpack, (b - nb_ray) >> 2, (b - nb_ray) & 3, 4);
+    else if (b < nb_ray + nb_pack) {
+        if (pack_ny == 4) pack_body(pj, nullptr, unpack, (b - nb_ray) >> 2, (b - nb_ray) & 3, 4);
+        else unpack_partial_body(pj, (b - nb_ray) / pack_ny, (b - nb_ray) % pack_ny, pack_ny);     // partial images to sum
+    }
     else if (b < nb_ray + nb_pack + nb_conv) convert_body(cj, to_vm, b - nb_ray - nb_pack);
     else zero_body(zj, flat, n_flat, b - nb_ray - nb_pack - nb_conv);
 }
@@ -674,7 +715,10 @@ int ens_launch_convert(const ConvJob& job, bool to_vm, hipStream_t st) {
 
 int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_vm, const ConvJob& zj, float* flat,
                     int64_t n_flat, const RayGradArgs* rg, hipStream_t st) {
-    const int nb_pack = pj.n * 4, nb_conv = cj.n > 0 ? cj.block_begin[cj.n] : 0;
+    bool any_part = false;
+    for (int i = 0; i < 4; ++i) any_part = any_part || (unpack && pj.part[i] != nullptr);
+    const int pack_ny = any_part ? 64 : 4;
+    const int nb_pack = pj.n * pack_ny, nb_conv = cj.n > 0 ? cj.block_begin[cj.n] : 0;
     const int64_t nb_zero = (zj.n > 0 ? zj.block_begin[zj.n] : 0) + (flat != nullptr && n_flat > 0 ? (n_flat + 2047) / 2048 : 0);
     RayGradArgs r;
     if (rg != nullptr) r = *rg; else { r.n_rays = 0; r.ntl = 0; r.n_slots = 0; }
@@ -684,7 +728,7 @@ int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_v
     if (nb > 0x7fffffff) return -1;
     if (nb_ray > 0x7fffffff) return -1;
     step_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(pj, unpack ? 1 : 0, cj, to_vm ? 1 : 0, zj, flat, flat ? n_flat : 0,
-                                                          (int)nb_ray, nb_pack, nb_conv, (int)nb_zero, r);
+                                                          (int)nb_ray, nb_pack, nb_conv, (int)nb_zero, r, pack_ny);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -819,10 +819,16 @@ class _RenderFn(torch.autograd.Function):
             n, dsts, vs, need_ptrs = accum.zero_args(plan, flags)
             L.check(lib.enslam_zero_blocks(n, dsts, vs, need_ptrs, _ptr(zbuf), n_flat, st), "enslam_zero_blocks")
         accum.clean = False
+        # decoder-parameter gradients leave the backward kernel as per-workgroup partial images (summed by the finish launch)
+        # instead of 4.4 M float atomics at its tail; ENSLAM_DW_PARTIALS=0 restores the atomics (A/B aid)
+        gpart, part_keep = (ctypes.c_void_p * 4)(), {}
         for i, k in enumerate(plan.kinds):
             if need_par[k]:
                 g_packed[k] = zbase + 4 * offs[nk + i]
                 gpk[k] = g_packed[k]
+                if USE_DW_PARTIALS:
+                    part_keep[k] = torch.empty(lib.enslam_bwd_partial_floats(k), dtype=torch.float32, device=dev)
+                    gpart[k] = part_keep[k].data_ptr()
         g_ro = g_rd = None
         p_ro = p_rd = ctypes.c_void_p(0)
         if need_rays:
@@ -870,9 +876,9 @@ class _RenderFn(torch.autograd.Function):
         if ev is not None:                      # bench.py: HIP events around the dominant kernel, on this stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        L.check(lib.enslam_decoder_bwd_scaled(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                              _ptr(d_raw), _ptr(d_scale), _ptr(act), ctx.act_light, _ptr(dgw), gg, gpk, p_ro, p_rd,
-                                              _ptr(work), _ptr(wcount), st), "enslam_decoder_bwd")
+        L.check(lib.enslam_decoder_bwd_partials(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
+                                                _ptr(d_raw), _ptr(d_scale), _ptr(act), ctx.act_light, _ptr(dgw), gg, gpk, gpart, p_ro, p_rd,
+                                                _ptr(work), _ptr(wcount), st), "enslam_decoder_bwd")
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
@@ -911,6 +917,7 @@ class _RenderFn(torch.autograd.Function):
         views_by_kind = {}
         npk = len(kinds_p)
         kind_arr, pk_arr, structs = (ctypes.c_int32 * max(npk, 1))(), (ctypes.c_void_p * max(npk, 1))(), (L.MlpParams * max(npk, 1))()
+        part_arr = (ctypes.c_void_p * max(npk, 1))()
         if kinds_p:
             all_sizes = [int(torch.Size(sh).numel()) for k in kinds_p for sh in shapes_by_kind[k]]
             pflat = torch.empty(sum(all_sizes), dtype=torch.float32, device=dev)
@@ -919,18 +926,13 @@ class _RenderFn(torch.autograd.Function):
                 views = [next(it).view(sh) for sh in shapes_by_kind[k]]
                 views_by_kind[k] = views
                 kind_arr[j], pk_arr[j] = k, g_packed[k]
+                part_arr[j] = gpart[k]
                 structs[j] = _fill_params_struct(k, views)
-        if persistent:
-            L.check(lib.enslam_step_finish_rays_prev(nc, srcs, dsts, vs, need_ptrs, prev_ptrs, npk, kind_arr, pk_arr, structs,
-                                                     L.STAGE[plan.stage], N if ray_pending else 0, S, _ptr(ro), _ptr(rd), _ptr(z),
-                                                     ctypes.byref(sc), _ptr(dgw), p_ro, p_rd, _ptr(work), _ptr(wcount), st),
-                    "enslam_step_finish_rays_prev")
-        elif ray_pending:
-            L.check(lib.enslam_step_finish_rays(nc, srcs, dsts, vs, need_ptrs, npk, kind_arr, pk_arr, structs, L.STAGE[plan.stage],
-                                                N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc), _ptr(dgw), p_ro, p_rd,
-                                                _ptr(work), _ptr(wcount), st), "enslam_step_finish_rays")
-        elif nc or npk:
-            L.check(lib.enslam_step_finish(nc, srcs, dsts, vs, need_ptrs, npk, kind_arr, pk_arr, structs, st), "enslam_step_finish")
+        if nc or npk or ray_pending:
+            L.check(lib.enslam_step_finish_partials(nc, srcs, dsts, vs, need_ptrs, prev_ptrs, npk, kind_arr, pk_arr, part_arr, structs,
+                                                    L.STAGE[plan.stage], N if ray_pending else 0, S, _ptr(ro), _ptr(rd), _ptr(z),
+                                                    ctypes.byref(sc), _ptr(dgw) if ray_pending else None, p_ro, p_rd, _ptr(work),
+                                                    _ptr(wcount), st), "enslam_step_finish")
         for k in plan.kinds:
             out += views_by_kind.get(k, [None] * plan.n_params[k])
         return tuple(out)       # (the saved buffers go with the graph; kept so that retain_graph backwards work)
@@ -941,6 +943,9 @@ class _RenderFn(torch.autograd.Function):
 ACT_WORKSPACE_LIMIT_BYTES = 8 << 30
 
 INLINE_RAY_GRAD = {'1': True, '0': False}.get(os.environ.get('ENSLAM_INLINE_RAY_GRAD', ''), None)     # None: decided per call
+# weight gradients as per-workgroup partial images summed by the finish launch instead of float atomics at the backward's tail:
+# backward 138 -> 132 us, finish launch 22 -> 28 us (17.6 MB more to read), step unchanged -- off by default (round 3)
+USE_DW_PARTIALS = os.environ.get('ENSLAM_DW_PARTIALS', '0') == '1'
 USE_WORK_LIST = os.environ.get('ENSLAM_WORK_LIST', '1') == '1'     # backward walks only the tiles with non-zero d_raw
 
 

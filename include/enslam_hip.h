@@ -224,6 +224,17 @@ int enslam_step_finish_rays_prev(int32_t n_conv, const float *const *src, float 
                                  const double *z_vals, const enslam_scene *scene, float *dgrid_ws, float *g_rays_o,
                                  float *g_rays_d, const int32_t *work_list, const int32_t *work_count, void *stream);
 
+/* The general finish launch: enslam_step_finish_rays_prev (prev NULL: no persistent destinations; dgrid_ws NULL or
+ * n_rays == 0: no ray-gradient role) which, for every decoder i with grad_partials[i] != NULL, forms the gradient as the SUM
+ * of the per-workgroup partial images enslam_decoder_bwd_partials left there instead of reading packed_grads[i]. */
+int enslam_step_finish_partials(int32_t n_conv, const float *const *src, float *const *dst, const int64_t *n_voxels,
+                                const uint8_t *const *need, uint8_t *const *prev, int32_t n_dec, const int32_t *kinds,
+                                const float *const *packed_grads, const float *const *grad_partials,
+                                const enslam_mlp_params *grads, int32_t stage, int32_t n_rays, int32_t n_samples,
+                                const float *rays_o, const float *rays_d, const double *z_vals, const enslam_scene *scene,
+                                float *dgrid_ws, float *g_rays_o, float *g_rays_d, const int32_t *work_list,
+                                const int32_t *work_count, void *stream);
+
 /* Sample distances along rays (mark_scene / mark_flags non-NULL: also does enslam_mark_blocks' work for stage mark_stage
  * on the samples it has just placed -- one launch less per render call).
  *   Replaces Renderer.render_batch_ray lines 83-171
@@ -328,6 +339,21 @@ int enslam_decoder_bwd_scaled(int32_t stage, int32_t n_rays, int32_t n_samples, 
                               const double *d_raw_scale, const float *act_ws, int32_t act_light, float *dgrid_ws,
                               const enslam_grid *grad_grids, float *const *grad_packed, float *g_rays_o,
                               float *g_rays_d, const int32_t *work_list, const int32_t *work_count, void *stream);
+/* enslam_decoder_bwd_scaled whose decoder-parameter gradients leave the kernel as per-workgroup PARTIAL IMAGES instead of
+ * float atomics into grad_packed: grad_partial[k] (float32 [enslam_bwd_partial_floats(k)], need not be cleared; NULL: atomics as
+ * before) receives a 16-float header (word 0, int32: number of rows) and one row of enslam_packed_grad_floats(k) floats per
+ * workgroup of decoder k's role; enslam_step_finish_partials sums the rows while it unpacks.  grad_packed[k] must still be
+ * given (it selects which decoders get parameter gradients) but is not written for those decoders.  All workgroups of the
+ * persistent backward finish within microseconds of each other; their 17.6 MB of atomics onto the same 53 k addresses ran at
+ * the chip-wide float-atomic rate (10-13 us at the tail of a 137 us kernel).  Replaces nothing in the reference (autograd
+ * sums the weight gradients inside its mm kernels). */
+size_t enslam_bwd_partial_floats(int kind);
+int enslam_decoder_bwd_partials(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                                const double *z_vals, const enslam_scene *scene, const float *d_raw,
+                                const double *d_raw_scale, const float *act_ws, int32_t act_light, float *dgrid_ws,
+                                const enslam_grid *grad_grids, float *const *grad_packed, float *const *grad_partial,
+                                float *g_rays_o, float *g_rays_d, const int32_t *work_list, const int32_t *work_count,
+                                void *stream);
 /* Work list (optional everywhere, NULL/NULL = every tile): the 16-sample tiles (ray * n_samples/16 + tile) whose d_raw is
  * not all zero -- behind a converged surface the transmittance underflows to 0 and the far tiles of most rays carry no
  * gradient.  The kernel that produces d_raw appends them ray by ray (work_list int32 [n_rays * n_samples/16], work_count
