@@ -36,7 +36,14 @@ def _ptr(t):
 # in the graph's private memory pool and only hold data once that graph has been replayed; every replay rewrites them
 # with the values its inputs had at the START of the replay.  They are therefore tagged with the capture they were made
 # in and are invisible to everything outside that capture (an eager render after replays re-packs from the live tensors).
-_capture = {'epoch': 0, 'active': 0, 'raw_writes': None, 'init_zero': None}
+_capture = {'epoch': 0, 'active': 0, 'raw_writes': None, 'init_zero': None, 'persist': None}
+
+# Persistent dense gradients of captured steps (see _RenderFn.backward): data_ptr of the gradient buffer -> the uint8 flags of
+# the 64-voxel blocks that hold non-zeros (`prev` of enslam_step_finish_rays_prev).  The finish launch of the next replay
+# rewrites exactly the blocks flagged here or touched by its own rays, so EVERY other writer of such a buffer has to add the
+# blocks it fills to these flags: parallel.allreduce_gradients (the sums of the other ranks' blocks) does through
+# note_foreign_blocks().  Entries live as long as the GraphedStep that captured them (graph.GraphedStep.__del__).
+_persist_prev = {}
 
 
 def _capturing():
@@ -58,15 +65,24 @@ def begin_capture():
     _capture['active'] = _capture['epoch']
     _capture['raw_writes'] = []
     _capture['init_zero'] = []
+    _capture['persist'] = {}          # id(grid) -> (gradient data_ptr, prev flags) of this capture
 
 
-def end_capture():
-    """-> the tensors that kernels of the captured step write behind torch's back (note_raw_write)."""
+def end_capture(ok=True):
+    """-> the tensors that kernels of the captured step write behind torch's back (note_raw_write).  ok=False: the capture
+    raised -- its storages belong to a pool that is being torn down, nothing is touched (and nothing here may hide the
+    original exception)."""
     log, _capture['raw_writes'] = _capture['raw_writes'] or [], None
     _capture['active'] = 0
     # persistent gradient tensors of the captured step and their block flags (see _RenderFn.backward): the protocol starts
     # from all-zero memory; filled here, eagerly, once -- a fill inside the capture would run at every replay
     init, _capture['init_zero'] = _capture['init_zero'] or [], None
+    if not ok:
+        for ptr, _pv in (_capture['persist'] or {}).values():
+            _persist_prev.pop(ptr, None)
+        _capture['persist'] = None
+        end_capture.persist_keys = []
+        return []
     for storage in init:
         torch.empty(0, dtype=torch.uint8, device=storage.device).set_(storage).zero_()
     seen, out = set(), []
@@ -74,7 +90,26 @@ def end_capture():
         if id(t) not in seen:
             seen.add(id(t))
             out.append(t)
+    persist, _capture['persist'] = _capture['persist'] or {}, None
+    end_capture.persist_keys = [ptr for ptr, _pv in persist.values()]      # (read by graph.GraphedStep)
     return out
+
+
+def forget_persistent(keys):
+    """The graph that owned these persistent gradient buffers is gone (graph.GraphedStep.__del__)."""
+    for k in keys:
+        _persist_prev.pop(k, None)
+
+
+def note_foreign_blocks(grad, flags):
+    """`grad` (a dense feature-grid gradient) has just been written in the 64-voxel blocks flagged in `flags` (uint8, one per
+    block) by something other than the render backward -- the unpack of a gradient all-reduce.  If it is the persistent
+    gradient buffer of a captured step, those blocks join the flags of the blocks its next replay must rewrite."""
+    pv = _persist_prev.get(grad.data_ptr())
+    if pv is not None and pv.numel() == flags.numel():
+        torch.maximum(pv, flags.reshape(pv.shape).to(pv.dtype), out=pv)
+        return True
+    return False
 
 
 def note_raw_write(tensors):
@@ -758,6 +793,7 @@ class _RenderFn(torch.autograd.Function):
                     "enslam_composite_fwd")
             ctx.sv = (SV, raw_v, z_v)
         ctx.plan, ctx.S, ctx.dims, ctx.act_light, ctx.accum = plan, S, dims, act_light, accum
+        ctx.cap_arena = cap
         ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act, flags)
         ctx.rgb = rgb if plan.loss is not None else None
         ctx.d_raw_unit = d_raw_unit if plan.loss is not None else None
@@ -897,6 +933,12 @@ class _RenderFn(torch.autograd.Function):
         # ~85 % of the tensor no ray came near.  The buffers start zeroed by end_capture(); only their STORAGES are kept
         # there (a second reference to the tensor itself would make AccumulateGrad clone the 16 MB instead of adopting it).
         persistent = _capturing() and _capture['init_zero'] is not None and nc > 0
+        # A second backward into the same grid inside one captured step (AccumulateGrad adds its gradient into the first
+        # one's persistent buffer) must not be persistent itself: it returns a fresh, fully written gradient, and the blocks
+        # it touched join the first buffer's flags (a captured elementwise max below), so the next replay clears them there.
+        again = [ctx.grid_ids[i] for i, _k in conv if persistent and ctx.grid_ids[i] in _capture['persist']]
+        if again:
+            persistent = False
         prev_ptrs = (ctypes.c_void_p * max(nc, 1))() if persistent else None
         prev_keep = []
         for j, (i, k) in enumerate(conv):
@@ -909,6 +951,8 @@ class _RenderFn(torch.autograd.Function):
                 prev_keep.append(pv)
                 plan.state.flags[ctx.grid_ids[i]] = pv      # the launch moves the flags there (last_block_flags)
                 _capture['init_zero'] += [g.untyped_storage(), pv.untyped_storage()]
+                _capture['persist'][ctx.grid_ids[i]] = (g.data_ptr(), pv)
+                _persist_prev[g.data_ptr()] = pv
         for k in plan.kinds:
             out.append(grid_out.get(k))
         pm = iter(ctx.param_meta)
@@ -933,6 +977,12 @@ class _RenderFn(torch.autograd.Function):
                                                     L.STAGE[plan.stage], N if ray_pending else 0, S, _ptr(ro), _ptr(rd), _ptr(z),
                                                     ctypes.byref(sc), _ptr(dgw) if ray_pending else None, p_ro, p_rd, _ptr(work),
                                                     _ptr(wcount), st), "enslam_step_finish")
+        for i, k in conv:
+            if ctx.grid_ids[i] in again:                    # (captured: runs at every replay, after the finish launch)
+                pv_first = _capture['persist'][ctx.grid_ids[i]][1]
+                torch.maximum(pv_first, flags[i], out=pv_first)
+                if ctx.cap_arena:
+                    flags[i].zero_()                        # no fill node re-zeroes a captured step's arena
         for k in plan.kinds:
             out += views_by_kind.get(k, [None] * plan.n_params[k])
         return tuple(out)       # (the saved buffers go with the graph; kept so that retain_graph backwards work)

@@ -30,13 +30,23 @@ class GraphedStep:
         from . import functional as EF
         self.graph = torch.cuda.CUDAGraph()
         EF.begin_capture()
+        ok = False
         try:
             with torch.cuda.graph(self.graph):
                 self.out = step_fn()
+            ok = True
         finally:
             # tensors the captured kernels overwrite behind torch's back (FusedAdam, MaskedGridOptimizer): the Python
             # calls that announce those writes only ran now, so every replay announces them again
-            self.raw_writes = EF.end_capture()
+            self.raw_writes = EF.end_capture(ok)
+            self._persist_keys = list(getattr(EF.end_capture, 'persist_keys', []))
+
+    def __del__(self):
+        try:
+            from . import functional as EF
+            EF.forget_persistent(getattr(self, '_persist_keys', []))
+        except Exception:
+            pass
 
     def replay(self):
         self.graph.replay()

@@ -197,6 +197,15 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags, prepared=None):
     run(lib.enslam_bucket_pack, "enslam_bucket_pack")
     dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     run(lib.enslam_bucket_unpack, "enslam_bucket_unpack")
+    # The unpack has just written the UNION's blocks of every grid gradient.  Where that gradient is the persistent buffer of
+    # a captured step (functional._persist_prev), the finish launch of the next replay only rewrites the blocks it knows of
+    # -- this rank's, now and one replay earlier -- so the other ranks' blocks are added to its flags here; without this their
+    # sums stay in the buffer and are sent (and grow) again every step.
+    if grid_items:
+        from .functional import note_foreign_blocks
+        for (g, _V, layout, f), seg in zip(grid_items, allf.split([it[3].numel() for it in grid_items])):
+            if layout == 0:
+                note_foreign_blocks(g, seg)
     return bucket.numel() * 4
 
 

@@ -151,12 +151,18 @@ class Renderer(object):
             z = rays_o.new_zeros((0,))
             return z.double(), z.double(), rays_o.new_zeros((0, 3))
         if N > self.HIERARCHICAL_MAX_RAYS:
-            if gt_depth is not None:
-                raise NotImplementedError("hierarchical sampling of more than 32768 depth-guided rays in one call: the sampler's "
-                                          "batch maxima (Renderer.py:110,145) span the call; split the batch in the caller")
-            outs = [self._render_hierarchical(c, decoders, rays_d[i:i + self.HIERARCHICAL_MAX_RAYS],
-                                              rays_o[i:i + self.HIERARCHICAL_MAX_RAYS], device, stage, None)
-                    for i in range(0, N, self.HIERARCHICAL_MAX_RAYS)]
+            # chunked internally; the sampler's batch maxima (Renderer.py:110,145) span the whole call, so they are taken here
+            # once and handed to every chunk (render_img / render_img_rescale pass up to ray_batch_size = 100000 rays)
+            prev = self.depth_max_override
+            if gt_depth is not None and prev is None:
+                self.depth_max_override = EF.batch_depth_max(gt_depth.reshape(-1))
+            try:
+                outs = [self._render_hierarchical(c, decoders, rays_d[i:i + self.HIERARCHICAL_MAX_RAYS],
+                                                  rays_o[i:i + self.HIERARCHICAL_MAX_RAYS], device, stage,
+                                                  None if gt_depth is None else gt_depth.reshape(-1)[i:i + self.HIERARCHICAL_MAX_RAYS])
+                        for i in range(0, N, self.HIERARCHICAL_MAX_RAYS)]
+            finally:
+                self.depth_max_override = prev
             return tuple(torch.cat(t, 0) for t in zip(*outs))
         dev = rays_o.device
         n_surf = self.N_surface if gt_depth is not None else 0

@@ -147,7 +147,8 @@ class SLAM:
             masks = {k: frustum_mask(cur_c2w, gt_depth, tuple(self.shared_c[k].shape[2:]), self.bound, self.cam) for k in MAP_KEYS}
         ba = bool(m.get('BA', False)) and len(self.keyframe_dict) > 4 and idx > 0      # Mapper.py:700: BA once 4 keyframes exist
         cfg = dict(self.cfg)
-        cfg['mapping'] = dict(m, BA=ba)
+        # the first frame is mapped with lr_first_factor (Mapper.py:794-796: lr_factor = lr_first_factor with iters_first)
+        cfg['mapping'] = dict(m, BA=ba, lr_factor=m.get('lr_first_factor', m['lr_factor']) if idx == 0 else m['lr_factor'])
         it = MapperIteration(cfg, self.renderer, self.shared_c, self.shared_decoders, frames, self.cam, masks=masks, keys=MAP_KEYS,
                              static_shapes=self.static_shapes)
         loss = None

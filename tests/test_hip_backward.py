@@ -203,3 +203,30 @@ def test_large_batch_forward_kernel_feeds_the_same_backward():
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'WORST' in r.stdout
+
+
+def test_weight_gradients_as_partial_images_match_the_atomic_path():
+    """enslam_decoder_bwd_partials + enslam_step_finish_partials (per-workgroup partial images summed by the finish launch)
+    against the default float-atomic accumulation, every decoder parameter of the colour stage."""
+    import evennicer_slam_amd as E
+    import evennicer_slam_amd.functional as EF
+    from tests.hip_util import DEV, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    out = {}
+    for mode in (False, True):
+        old = EF.USE_DW_PARTIALS
+        EF.USE_DW_PARTIALS = mode
+        try:
+            for p in model.parameters():
+                p.grad = None
+            g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+            d, v, c = renderer.render_batch_ray(g, model, rays['rays_d'], rays['rays_o'], DEV, 'color', gt_depth=rays['gt_depth'])
+            E.losses.rgbd_loss(d, c, rays['gt_depth'], rays['gt_color'], 0.2).backward()
+            torch.cuda.synchronize()
+            out[mode] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            EF.USE_DW_PARTIALS = old
+    assert out[False].keys() == out[True].keys() and len(out[True]) >= 69
+    for n, a in out[False].items():
+        b = out[True][n]
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), n

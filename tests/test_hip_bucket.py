@@ -206,3 +206,77 @@ def test_two_rank_sharded_step_with_local_union_flags_matches_unsharded():
             assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-30)
     for a, b in zip(outs[0]['grads'], outs[1]['grads']):
         assert np.array_equal(a, b)                         # replicas hold identical sums
+
+
+def _replay_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import evennicer_slam_amd as E
+        from evennicer_slam_amd import parallel as PAR
+        from evennicer_slam_amd.graph import GraphedStep
+        from tests.hip_util import DEV, tiny_on_gpu
+        s, bound, model, grids, rays, renderer = tiny_on_gpu()
+        g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+        ro, rd, gd, gc = [rays[k].clone() for k in ('rays_o', 'rays_d', 'gt_depth', 'gt_color')]
+        base = [t.clone() for t in (ro, rd, gd, gc)]
+        leaves = [g[k] for k in ('grid_middle', 'grid_fine', 'grid_color')] + list(model.color_decoder.parameters())
+        sr = PAR.ShardedRenderer(renderer)
+
+        def local_step():
+            for t in leaves:
+                t.grad = None
+            (depth, var, color), sl = sr.render_batch_ray(g, model, rd, ro, DEV, 'color', gt_depth=gd)
+            loss = E.losses.rgbd_loss(depth, color, gd[sl], gc[sl], 0.2)
+            loss.backward()
+            return loss
+
+        gs = GraphedStep(local_step)
+        out = []
+        for it in range(4):                     # a different half of the rays per replay: the touched blocks move
+            for t, b in zip((ro, rd, gd, gc), base):
+                t.copy_(torch.roll(b, 16 * it, 0) if it < 3 else b)
+            gs.replay()
+            PAR.allreduce_gradients(leaves, block_flags=renderer.state.last_block_flags())
+            torch.cuda.synchronize()
+            out.append([t.grad.cpu().numpy().copy() for t in leaves])
+        q.put({'rank': rank, 'grads': out})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_graph_replay_with_allreduce_keeps_foreign_blocks_clean():
+    """under hipGraph replay the dense grid gradients are persistent buffers of which the finish launch
+    rewrites only the blocks this rank touched now or one replay earlier; the all-reduce's unpack writes the union over ranks
+    into the same buffers.  Four replays with changing rays + allreduce_gradients after each must equal the unsharded eager
+    gradients of the same rays (stale sums of the other rank's blocks would be sent again and grow)."""
+    import torch.multiprocessing as mp
+    import evennicer_slam_amd as E
+    from tests.hip_util import DEV, tiny_on_gpu
+    world, port = 2, 39500 + (os.getpid() % 2000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replay_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=900) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    base = [rays[k] for k in ('rays_o', 'rays_d', 'gt_depth', 'gt_color')]
+    for it in range(4):
+        ro, rd, gd, gc = [torch.roll(b, 16 * it, 0) if it < 3 else b for b in base]
+        g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+        leaves = [g[k] for k in ('grid_middle', 'grid_fine', 'grid_color')] + list(model.color_decoder.parameters())
+        for t in model.color_decoder.parameters():
+            t.grad = None
+        depth, var, color = renderer.render_batch_ray(g, model, rd, ro, DEV, 'color', gt_depth=gd)
+        E.losses.rgbd_loss(depth, color, gd, gc, 0.2).backward()
+        want = [t.grad.cpu().numpy() for t in leaves]
+        for o in outs:
+            for a, b in zip(o['grads'][it], want):
+                assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30), (it, o['rank'])
+                assert np.array_equal(a == 0, b == 0) or np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30)

@@ -238,3 +238,38 @@ def test_fused_rgbd_loss_matches_torch(room0):
         assert abs(l1.item() - l2.item()) < 1e-6 * abs(l2.item())
         for a, b in zip(g1, g2):
             assert torch.allclose(a, b.to(a.dtype), rtol=1e-6, atol=1e-7)
+
+
+def test_two_backwards_into_one_grid_inside_a_captured_step():
+    """AccumulateGrad adds a second backward's gradient into the first one's persistent buffer; the blocks only
+    the second call touched must be cleared by the next replay as well."""
+    import evennicer_slam_amd as E
+    from evennicer_slam_amd.graph import GraphedStep
+    from tests.hip_util import DEV, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+    ro, rd, gd, gc = [rays[k].clone() for k in ('rays_o', 'rays_d', 'gt_depth', 'gt_color')]
+    base = [t.clone() for t in (ro, rd, gd, gc)]
+    leaves = [g[k] for k in ('grid_middle', 'grid_fine', 'grid_color')]
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        for sl in (slice(0, 32), slice(32, 64)):
+            d, v, c = renderer.render_batch_ray(g, model, rd[sl], ro[sl], DEV, 'color', gt_depth=gd[sl])
+            E.losses.rgbd_loss(d, c, gd[sl], gc[sl], 0.2).backward()
+
+    gs = GraphedStep(step)
+    for it in range(4):
+        for t, b in zip((ro, rd, gd, gc), base):
+            t.copy_(torch.roll(b, 16 * it, 0) if it < 3 else b)
+        gs.replay()
+        torch.cuda.synchronize()
+        got = [t.grad.clone() for t in leaves]
+        g2 = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+        for sl in (slice(0, 32), slice(32, 64)):
+            d, v, c = renderer.render_batch_ray(g2, model, rd[sl], ro[sl], DEV, 'color', gt_depth=gd[sl])
+            E.losses.rgbd_loss(d, c, gd[sl], gc[sl], 0.2).backward()
+        for a, k in zip(got, ('grid_middle', 'grid_fine', 'grid_color')):
+            b = g2[k].grad
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (it, k)

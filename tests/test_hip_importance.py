@@ -84,3 +84,16 @@ def test_second_pass_distances_and_no_grad_call():
         d, u, c = renderer.render_batch_ray(grids, model, rays['rays_d'], rays['rays_o'], DEV, 'color', gt_depth=rays['gt_depth'])
     assert not d.requires_grad
     assert rel_err(d.cpu().numpy(), g['color_depth']) < 1e-4
+
+
+def test_hierarchical_render_is_chunked_with_the_whole_call_depth_maxima():
+    """a depth-guided hierarchical call above the 64-sample ray limit is chunked internally; the sampler's
+    batch maxima span the whole call, so every chunk gets them and the result equals the unchunked call."""
+    s, bound, model, grids, rays, renderer = _setup()
+    with torch.no_grad():
+        want = renderer.render_batch_ray(grids, model, rays['rays_d'], rays['rays_o'], DEV, 'color', gt_depth=rays['gt_depth'])
+        renderer.HIERARCHICAL_MAX_RAYS = 24                     # 64 rays -> chunks of 24, 24, 16
+        got = renderer.render_batch_ray(grids, model, rays['rays_d'], rays['rays_o'], DEV, 'color', gt_depth=rays['gt_depth'])
+    assert renderer.depth_max_override is None
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a, b)

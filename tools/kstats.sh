@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: tools/kstats.sh <tag> <python args...>   -> prints top kernels by total time (run on the GPU box)
-tag=$1; shift
+tag=${1:?tag}; shift
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -o k -- python3 "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
 python3 - <<PY

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_lds_$1; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O="$R/gpurun_out/pmc_lds_${1:?tag}"; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 if [ -n "$2" ]; then export ENSLAM_LIB=$R/$2 ENSLAM_LIB_ALLOW_MISSING=1; fi
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O -o p -- python3 $R/bench.py --steps 10 --warmup 3 --eager --no-secondary --no-cpu-baseline --no-kernel-events > $O.log 2>&1

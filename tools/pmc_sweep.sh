@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/pmc_sweep.sh <tag> [lib]  -- a wider SQ counter sweep (several --pmc passes) of the bench step's kernels
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_sw_$1; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O="$R/gpurun_out/pmc_sw_${1:?tag}"; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 if [ -n "$2" ]; then export ENSLAM_LIB=$R/$2 ENSLAM_LIB_ALLOW_MISSING=1; fi
 i=0

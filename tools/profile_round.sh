@@ -5,7 +5,7 @@
 # config-4 measurement launches the same kernels on office0 / 5000 rays and would mix into the per-kernel means;
 # --no-kernel-events: the event passes include launches that walk every tile).
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O="$R/gpurun_out/prof_round"; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--no-secondary --no-cpu-baseline --no-kernel-events"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/graph -o g -- python3 $R/bench.py --steps 100 --warmup 10 $ARGS > $O/graph.log 2>&1
