@@ -14,12 +14,18 @@ One "step" = Renderer.render_batch_ray (sampling, gather, decoders, compositing)
   --config 5            BASELINE configs[4] shapes: RPG recording4 (206 MB of grids, RPG camera), synthetic images,
                         1000 rays per GPU (the real sequence and the callers' pipeline are not in the image)
 
-  N > 1: launched by torch.distributed.run, one rank per GPU.  Leaf gradients are summed with one bucketed RCCL
-  all-reduce (touched 64-voxel blocks only).  The default run (config 2) also measures config 4 on the same ranks
+  N > 1: one rank per GPU under torch.distributed.run.  Started WITHOUT it (`python bench.py --gpus N`, no WORLD_SIZE in the
+  environment) the script starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself as a child process
+  -- before this process has touched the GPU -- and exits with the child's code; rank 0 of the child prints the JSON line.
+  Leaf gradients are summed with one bucketed RCCL all-reduce (touched 64-voxel blocks only).  The default run (config 2) also measures config 4 on the same ranks
   and reports it inside the SAME JSON line under "also" (disable with --no-secondary), so that a 1/2/4/8-GPU sweep
   records both the weak (room0) and the strong (office0, 5000 rays) curve.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the `roofline` and `cpu_baseline` objects).
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the `roofline` and `cpu_baseline` objects).  At N = 1 the default
+run adds, under "also": config 4 on this GPU, config 3 (the tracker's camera iteration with the event term: path only, path +
+U-Net, one hipGraph per iteration), the 200-ray tracker iteration, and the headline step on a map with real surfaces (an
+analytic room fitted by the path's own mapper) next to the random-init scene; `api_rays_per_s` is the Python-driven step through
+the reference API only (render_batch_ray + torch loss + backward), no graph capture and no fused-loss entry point.
 """
 import argparse
 import gc as _gcmod
@@ -104,6 +110,45 @@ def make_rays(sc, n_rays, seed):
     return ro.float().contiguous(), rd.float().contiguous(), gd.float().contiguous(), gc.float().contiguous()
 
 
+def fit_map(renderer, grids, model, sc, dev, iters=400, rays=1000, seed=7):
+    """Second scene variant of the bench: fit the map to the analytic room the images now show, through the path itself
+    (random pixels -> render_batch_ray_rgbd_loss -> backward -> Adam on the grids and the decoders, colour stage), so that the
+    timed step afterwards runs on a map with real surfaces (occupancy rising at gt_depth) instead of random-init occupancy.
+    Returns the mean |depth - gt_depth| of a fixed ray batch before and after."""
+    from evennicer_slam_amd.common import get_samples
+    cam = sc['cam']
+    dimg, cimg, c2w = sc['depth_img'].to(dev), sc['color_img'].to(dev), sc['c2w'].to(dev)
+    gen_state = torch.cuda.get_rng_state(dev)
+    torch.manual_seed(seed)
+
+    def draw(n):
+        ro, rd, gd, gc = get_samples(0, cam['H'], 0, cam['W'], n, cam['H'], cam['W'], cam['fx'], cam['fy'], cam['cx'], cam['cy'],
+                                     c2w, dimg, cimg, dev)
+        return ro.float(), rd.float(), gd.float(), gc.float()
+
+    ev = draw(rays)
+
+    def depth_l1():
+        with torch.no_grad():
+            d, _u, _c = renderer.render_batch_ray(grids, model, ev[1], ev[0], dev, 'color', gt_depth=ev[2])
+            return float((d - ev[2].double()).abs().mean())
+
+    before = depth_l1()
+    gl = [grids[k] for k in ('grid_middle', 'grid_fine', 'grid_color')]
+    opt = torch.optim.Adam([{'params': gl, 'lr': 0.02}, {'params': [q for q in model.parameters() if q.requires_grad], 'lr': 2e-3}])
+    for _ in range(iters):
+        ro, rd, gd, gc = draw(rays)
+        opt.zero_grad(set_to_none=True)
+        loss, _d, _v, _c = renderer.render_batch_ray_rgbd_loss(grids, model, rd, ro, dev, 'color', gd, gc, 0.2)
+        loss.backward()
+        opt.step()
+    after = depth_l1()
+    for t in gl + list(model.parameters()):
+        t.grad = None
+    torch.cuda.set_rng_state(gen_state, dev)
+    return {"iters": iters, "depth_l1_before_m": before, "depth_l1_after_m": after}
+
+
 def mapper_loss(depth, color, gt_depth, gt_color, stage, w_color=0.2):
     """Mapper.py:553-562: L1 depth over pixels with valid depth (+ w_color * L1 colour in the colour stage).
     Written with a multiplicative mask instead of boolean indexing: same sum, no device->host sync."""
@@ -134,16 +179,19 @@ def cpu_baseline(sc, rays, stage, budget_s=20.0):
         mapper_loss(d, c, gd, gc, stage).backward()
 
     # The op mix is many small tensors: more threads is not faster (128 threads ran 2.6x SLOWER than one on the
-    # 64-core EPYC of the GPU box), so a few thread counts are timed and the best is the baseline.
+    # 64-core EPYC of the GPU box), so 1 thread, 8, 32 and ALL PHYSICAL CORES are timed; `value` is the
+    # best of them, `cores` the physical core count of the host, `threads_best` the thread count `value` was measured at.
     n = ro.shape[0]
     all_threads = torch.get_num_threads()
+    phys, model_name = physical_cores()
     results = {}
     try:
-        for nt in sorted({1, 8, 32, all_threads}):
-            if nt > all_threads:
+        for nt in sorted({1, 8, 32, phys}):
+            if nt > max(all_threads, phys):
                 continue
             torch.set_num_threads(nt)
-            step()                                          # warm-up at this thread count
+            step()                                          # two warm-ups at this thread count
+            step()
             times = []
             t_budget = time.perf_counter()
             while len(times) < 5 and (len(times) < 2 or time.perf_counter() - t_budget < budget_s / 4):
@@ -155,17 +203,39 @@ def cpu_baseline(sc, rays, stage, budget_s=20.0):
         torch.set_num_threads(all_threads)
     best = min(results, key=lambda k: results[k][0])
     med, iters = results[best]
-    model_name = ""
+    others = ", ".join(f"{k} thr {n / v[0]:.0f}" for k, v in sorted(results.items()))
+    return {"value": n / med, "unit": "rays/s", "cores": phys, "threads_best": best, "kind": "port", "cpu": model_name,
+            "value_1_thread": n / results[1][0] if 1 in results else None,
+            "value_all_cores": n / results[phys][0] if phys in results else None,
+            "sample": f"{n} rays x 48 samples, stage {stage}, fwd+loss+bwd, torch CPU oracle; median of {iters} iterations after "
+                      f"2 warm-ups per thread count (rays/s: {others}); value = the best thread count"}
+
+
+def physical_cores():
+    """(physical core count, CPU model name) of this host from /proc/cpuinfo (fallback: os.cpu_count())."""
+    model_name, cores = "", set()
     try:
+        phys_id = core_id = None
         with open("/proc/cpuinfo") as f:
-            model_name = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+            for ln in f:
+                if ln.startswith("model name") and not model_name:
+                    model_name = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    phys_id = ln.split(":", 1)[1].strip()
+                elif ln.startswith("core id"):
+                    core_id = ln.split(":", 1)[1].strip()
+                elif not ln.strip():
+                    if phys_id is not None and core_id is not None:
+                        cores.add((phys_id, core_id))
+                    phys_id = core_id = None
     except OSError:
         pass
-    others = ", ".join(f"{k} thr {n / v[0]:.0f}" for k, v in sorted(results.items()))
-    return {"value": n / med, "unit": "rays/s", "cores": best, "kind": "port", "cpu": model_name,
-            "value_1_thread": n / results[1][0] if 1 in results else None,
-            "sample": f"{n} rays x 48 samples, stage {stage}, fwd+loss+bwd, torch CPU oracle; median of {iters} iterations after "
-                      f"1 warm-up at the best of the thread counts tried (rays/s: {others})"}
+    n = len(cores) if cores else (os.cpu_count() or 1)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))           # a container's CPU share
+    except (AttributeError, OSError):
+        pass
+    return max(n, 1), model_name
 
 
 class Env:
@@ -178,10 +248,7 @@ class Env:
         self.rank = int(os.environ.get('RANK', '0'))
         local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         if args.gpus > 1 and self.world == 1 and os.environ.get('ENSLAM_BENCH_FORCE_COMM') != '1':
-            raise SystemExit(
-                f"bench.py --gpus {args.gpus} must run under torch.distributed.run, one rank per GPU:\n"
-                f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
-                f"--master-port 29500 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
+            raise SystemExit(f"bench.py --gpus {args.gpus}: WORLD_SIZE is 1 (main() starts the ranks itself when it is unset)")
         if self.world != args.gpus and self.world > 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
         if not torch.cuda.is_available():
@@ -232,7 +299,25 @@ class Env:
             self.dist.destroy_process_group()
 
 
-def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, want_cpu_baseline):
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process (one rank per GPU, RCCL)
+    and hand back its exit code.  The child inherits stdout / stderr, so rank 0's JSON line appears as this command's own.
+    Never a re-exec: this process has not initialised the GPU and simply waits."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                    # a free rendezvous port on the loopback interface
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, want_cpu_baseline, variant=None):
     """Measure one configuration.  scaling 'weak': `rays` per rank (batch = world x rays); 'strong': `rays` per
     iteration, split over the ranks in contiguous blocks (parallel.shard_range)."""
     import evennicer_slam_amd as E
@@ -242,6 +327,13 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
     stage = args.stage
 
     sc = build_scene_cpu(scene, seed=0)                            # identical replicas on every rank
+    if variant == 'surfaces':                                      # analytic room instead of the random depth / colour images
+        from evennicer_slam_amd.synthetic import BoxRoom
+        room = BoxRoom.for_bound(sc['bound'], margin=0.7, seed=0)
+        c4 = torch.eye(4, dtype=torch.float64)
+        c4[:3] = sc['c2w'].double()
+        col, dep = room.render(c4, sc['cam'])
+        sc['color_img'], sc['depth_img'] = col.float(), dep
     if scaling == 'weak':                                          # rank r's block has its own seed; batch = all blocks
         blocks = [make_rays(sc, rays, seed=1000 + r) for r in range(world)]
         batch = [torch.cat([b[i] for b in blocks]) for i in range(4)]
@@ -264,6 +356,9 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
     for k in kinds:
         leaves += list(getattr(model, E._lib.MLP_NAMES[k]).parameters())
 
+    fit = None
+    if variant == 'surfaces':
+        fit = fit_map(renderer, grids, model, sc, dev, iters=int(os.environ.get('ENSLAM_BENCH_FIT_ITERS', '400')))
     comm_on, force_comm = env.comm_on, env.force_comm
     # Ray sharding hands every rank the WHOLE batch (parallel.ShardedRenderer): each rank holds all ranks' rays, so the
     # batch maxima of gt_depth and the union of the touched 64-voxel blocks are computed locally -- one marking launch
@@ -365,6 +460,27 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
                 step()
             torch.cuda.synchronize()
 
+    # What an UNCHANGED caller gets: the reference API only (render_batch_ray -> the caller's torch loss -> loss.backward()),
+    # Python-driven, no graph capture, no fused-loss entry point (Mapper.py:548-575 around this Renderer).
+    api = None
+    if world == 1 and stage != 'coarse' and not args.no_api:
+        def api_step():
+            EF.clear_caches()
+            for t in leaves:
+                t.grad = None
+            ro.grad = None
+            rd.grad = None
+            depth, var, color = renderer.render_batch_ray(grids, model, rd, ro, dev, stage, gt_depth=gd)
+            loss = mapper_loss(depth, color, gd, gc, stage)
+            loss.backward()
+            return loss
+        for _ in range(5):
+            api_step()
+        n_api = min(steps, 100)
+        api_el, _l = env.timed(api_step, n_api)
+        del _l
+        api = (n_local * n_api / api_el, api_el / n_api * 1e3)
+
     mode = 'eager'
     gstep = None
     phases = None
@@ -461,6 +577,11 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
                                                                   else "fused into the compositing launches (render_batch_ray_rgbd_loss)"),
         "eager_rays_per_s": total_rays * eager_steps / eager_elapsed,
     }
+    if api is not None:
+        out["api_rays_per_s"], out["api_ms_per_step"] = api
+        out["api_step"] = "render_batch_ray + torch L1 losses + loss.backward(), Python-driven (no hipGraph, no fused-loss entry)"
+    if fit is not None:
+        out["fit"] = fit
     if comm_on:
         out["comm"] = dict(comm_ms, bucket_bytes=int(comm['bytes']), mode=mode,
                            flags="marked locally from the whole batch" if whole_batch else "MAX all-reduce of per-rank flags")
@@ -473,7 +594,7 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes + WRITE_SIZE); they are NOT measured in this run
         traffic, tsrc = None, None
-        for tname in ("r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and scene == 'room0' and n_local == 1000 and stage == 'color':
                 traffic = json.load(open(tpath)).get("decoder_bwd_split_kernel", {}).get("bytes_per_launch")
@@ -510,6 +631,159 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
     return out
 
 
+def _timed_plain(fn, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(n):
+        out = None
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, out
+
+
+def run_config3(dev, steps=20):
+    """BASELINE config 3: the tracker's camera iteration with the event term on room0 at Replica resolution --
+    200-pixel RGB-D batch + render_img_rescale (0.15 x 680 x 1200 = 18 360 rays x 48, gradients to the pose; src/Tracker.py:150)
+    -> PyTorch-ROCm UNet_2heads(6,2,2) (seeded random weights: the checkpoint is not in the image) -> blurred-L2 event loss
+    (kernel 9, balancer 0.025; Tracker.py:206-232) -> backward to the 7 pose numbers -> Adam.  Path alone and path + U-Net are
+    timed separately, Python-driven with the reference's .item() syncs, and as one hipGraph per iteration."""
+    import evennicer_slam_amd as E
+    import evennicer_slam_amd.functional as EF
+    from evennicer_slam_amd.mapper import FusedAdam
+    sc = build_scene_cpu('room0', 0)
+    model = sc['model'].to(dev)
+    attach_bounds(model, sc['bound'])
+    for q in model.parameters():
+        q.requires_grad_(False)
+    grids = {k: v.to(dev) for k, v in sc['grids'].items()}
+    renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **CAM))
+    H, W = CAM['H'], CAM['W']
+    g = torch.Generator().manual_seed(1)
+    depth_img = (torch.rand(H, W, generator=g) * 3.0 + 0.5).to(dev)
+    color_img = torch.rand(H, W, 3, generator=g).to(dev)
+    pre_color = torch.rand(H, W, 3, generator=g).to(dev)
+    gt_event = torch.randint(0, 4, (H, W, 2), generator=g).float().to(dev)
+    gt_mask = (gt_event.sum(-1) > 2).long()
+    cfg = dict(sc['cfg'])
+    cfg['tracking'] = {'device': str(dev), 'w_color_loss': 0.5, 'ignore_edge_W': 100, 'ignore_edge_H': 100, 'handle_dynamic': True,
+                       'use_color_in_tracking': True}
+    cfg['event'] = {'activate_events': True, 'blur': True, 'kernel_sizes': [9], 'kernel_weights': [1], 'unblurred_weight': 0,
+                    'balancer': 0.025}
+    torch.manual_seed(0)
+    net = E.event.UNet_2heads(6, 2, 2)
+    for q in net.parameters():
+        q.requires_grad_(False)
+    net = net.to(dev).eval()
+    slam = types.SimpleNamespace(nice=True, bound=sc['bound'], renderer=renderer, event_net=net, low_gpu_mem=False, **CAM)
+    trk = E.tracker.TrackerIteration(cfg, None, slam)
+    trk.c, trk.decoders = grids, model
+    ct = torch.tensor([1.0, 0.0, 0.0, 0.0, 3.0, 1.0, 0.0], device=dev, requires_grad=True)
+    opt = FusedAdam([ct], lr=1e-3)
+    SF = 0.15
+    rays = int(H * SF) * int(W * SF)
+
+    def full():
+        return trk.optimize_cam_in_batch(ct, None, color_img, depth_img, gt_event, gt_mask, 200, opt, 0, 0, pre_color, rgbd=True,
+                                         event=True, scale_factor=SF)
+
+    def path_only():
+        opt.zero_grad()
+        col = trk._render_rescaled(ct, depth_img, SF)
+        col.sum().backward()
+        opt.step()
+
+    def unet_only():
+        x = torch.rand(1, 6, int(H * SF), int(W * SF), device=dev, requires_grad=True)
+        e, m = net(x)
+        (e.sum() + m.sum()).backward()
+
+    for f in (full, path_only, unet_only):
+        for _ in range(3):
+            f()
+    losses = [float(x) for x in full()[:2]]
+    t_full, _o = _timed_plain(full, steps)
+    t_path, _o = _timed_plain(path_only, steps)
+    t_unet, _o = _timed_plain(unet_only, steps)
+    del _o
+    out = {"workload": f"Replica room0, tracker camera iteration with the event term: 200-ray RGB-D batch + {rays}-ray x 48 "
+                       f"render_img_rescale (scale 0.15) with gradient to the pose + UNet_2heads(6,2,2) fp32 (random weights) + "
+                       f"blurred-L2 event loss + Adam",
+           "rays": rays, "path_ms": t_path * 1e3, "path_rays_per_s": rays / t_path, "unet_ms": t_unet * 1e3,
+           "path_plus_unet_ms": t_full * 1e3, "loss_rgbd": losses[0], "loss_event": losses[1]}
+    try:
+        _gcmod.collect()
+        git = E.tracker.GraphedCameraIteration(trk, ct, opt, color_img, depth_img, gt_event, gt_mask, pre_color, batch_size=200,
+                                               rgbd=True, event=True, scale_factor=SF)
+        for _ in range(3):
+            git.step()
+        tg, _o = _timed_plain(git.step, steps * 2)
+        del _o
+        out["graphed_ms"] = tg * 1e3
+        del git
+    except Exception as exc:            # the capture is an optimisation of the caller's loop, not the measurement
+        out["graphed_ms"] = None
+        out["graphed_error"] = f"{type(exc).__name__}: {exc}"
+    del trk, net, grids, model, renderer
+    EF.clear_caches()
+    _gcmod.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_tracker_iter(dev, n_rays=200, steps=200):
+    """The tracker's RGB-D camera iteration (Tracker.py:141-197 + the optimiser step) on room0, colour stage, map and decoders
+    fixed: camera tensor -> pose -> n_rays random pixels -> render -> uncertainty-weighted loss -> backward to the 7 pose
+    numbers -> Adam; one hipGraph per iteration (the small-batch floor)."""
+    import evennicer_slam_amd as E
+    import evennicer_slam_amd.functional as EF
+    from evennicer_slam_amd.graph import GraphedStep
+    from evennicer_slam_amd.mapper import FusedAdam
+    sc = build_scene_cpu('room0', 0)
+    model = sc['model'].to(dev)
+    attach_bounds(model, sc['bound'])
+    for q in model.parameters():
+        q.requires_grad_(False)
+    grids = {k: v.to(dev) for k, v in sc['grids'].items()}
+    renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **CAM))
+    H, W, fx, fy, cx, cy = (CAM[k] for k in ('H', 'W', 'fx', 'fy', 'cx', 'cy'))
+    g = torch.Generator().manual_seed(1)
+    depth_img = (torch.rand(H, W, generator=g) * 3.0 + 0.5).to(dev)
+    color_img = torch.rand(H, W, 3, generator=g).to(dev)
+    ct = torch.tensor([1.0, 0.0, 0.0, 0.0, 3.0, 1.0, 0.0], device=dev, requires_grad=True)
+    opt = FusedAdam([ct], lr=1e-3)
+    edge, one = 100, {}
+
+    def it():
+        opt.zero_grad()
+        ro, rd, gd, gc = E.tracker.get_samples_from_camera_tensor(edge, H - edge, edge, W - edge, n_rays, H, W, fx, fy, cx, cy, ct,
+                                                                  depth_img, color_img, dev)
+        depth, unc, color = renderer.render_batch_ray(grids, model, rd, ro, dev, 'color', gt_depth=gd)
+        loss = E.losses.tracker_loss(depth, unc, color, gd, gc, 0.5)
+        if 'one' not in one:
+            one['one'] = torch.ones_like(loss)
+        loss.backward(gradient=one['one'])
+        opt.step()
+        return loss
+
+    for _ in range(5):
+        it()
+    te, last = _timed_plain(it, 30)
+    del last
+    opt.zero_grad()
+    _gcmod.collect()
+    gs = GraphedStep(it)
+    tg, loss = _timed_plain(gs.replay, steps)
+    out = {"workload": f"Replica room0, tracker RGB-D camera iteration, {n_rays} rays x 48, colour stage, fixed map, gradient to the "
+                       f"pose + Adam", "rays": n_rays, "graphed_us": tg * 1e6, "eager_us": te * 1e6, "rays_per_s": n_rays / tg,
+           "loss": float(loss.item())}
+    del gs, grids, model, renderer
+    EF.clear_caches()
+    _gcmod.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -523,11 +797,15 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='default run: skip the extra config-4 measurement reported under "also"')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--no-api', action='store_true', help='skip the reference-API-only (Python-driven) timing `api_rays_per_s`')
+    ap.add_argument('--variant', default=None, choices=('surfaces',), help='primary workload on a map fitted to an analytic room')
     ap.add_argument('--torch-loss', action='store_true', help='compute the mapper loss with torch ops instead of the fused HIP loss')
     ap.add_argument('--separate-loss', action='store_true', help='render_batch_ray, then losses.rgbd_loss as its own launches')
     ap.add_argument('--eager', action='store_true', help='time the plain Python-driven step instead of hipGraph replays')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and os.environ.get('ENSLAM_BENCH_FORCE_COMM') != '1':
+        sys.exit(spawn_ranks(args.gpus))        # (nothing in this process has touched the GPU yet)
     env = Env(args)
     spec = dict(CONFIGS[args.config])
     customised = args.rays is not None or args.scene is not None or args.scaling is not None
@@ -536,7 +814,7 @@ def main():
     scaling = args.scaling or spec['scaling']
     primary = run_workload(env, args, scene, rays, scaling, args.steps, args.warmup,
                            want_events=not args.no_kernel_events,
-                           want_cpu_baseline=env.rank == 0 and env.world == 1 and not args.no_cpu_baseline)
+                           want_cpu_baseline=env.rank == 0 and env.world == 1 and not args.no_cpu_baseline, variant=args.variant)
     primary["config"]["baseline_config"] = spec['name'] if not customised else "custom"
     if args.config == 2 and not customised and not args.no_secondary and args.stage == 'color':
         s4 = CONFIGS[4]
@@ -545,6 +823,27 @@ def main():
         keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "mode", "loss", "comm", "eager_rays_per_s")
         primary["also"] = {"config4": dict({k: sec[k] for k in keep if k in sec}, workload=sec["config"]["workload"],
                                            rays_per_gpu=sec["config"]["rays_per_gpu"])}
+        if env.world == 1:
+            # further single-GPU measurements of the default run (each guarded: a failure is reported, never fatal)
+            def guarded(name, fn):
+                try:
+                    primary["also"][name] = fn()
+                except Exception as exc:
+                    primary["also"][name] = {"error": f"{type(exc).__name__}: {exc}"}
+
+            def surfaces():
+                r = run_workload(env, args, scene, rays, scaling, max(50, args.steps // 2), max(5, args.warmup // 2),
+                                 want_events=not args.no_kernel_events, want_cpu_baseline=False, variant='surfaces')
+                o = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "mode", "loss", "fit", "api_rays_per_s") if k in r}
+                rf = r.get("roofline") or {}
+                o.update({k: rf.get(k) for k in ("active_tile_fraction", "avg_launch_us", "frac", "frac_executed", "step_frac")})
+                o["workload"] = ("config 2 on a map with surfaces: room0 grids and decoders fitted (through this path) to an analytic "
+                                 "room (box room + one box, smooth view-consistent colours) seen from the bench camera")
+                return o
+
+            guarded("config2_surfaces", surfaces)
+            guarded("config3", lambda: run_config3(env.dev, steps=max(10, min(30, args.steps // 10))))
+            guarded("tracker_iter_200", lambda: run_tracker_iter(env.dev, 200, steps=max(50, args.steps)))
     if env.rank == 0:
         print(json.dumps(primary), flush=True)
     env.close()
