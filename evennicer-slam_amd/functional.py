@@ -21,12 +21,26 @@ def _require_hip(t, what):
                             f"fallback")
 
 
+def _f32c(t):
+    """detached contiguous float32 form of t (no copies, no dispatcher calls beyond detach() when it already is one)."""
+    t = t.detach()
+    if t.dtype is not torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def _stream():
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    """Device address of t as a plain int (None -> NULL): ctypes converts both for c_void_p parameters, and an int costs a
+    quarter of a c_void_p object (a colour-stage step passes ~180 addresses)."""
+    return t.data_ptr() if t is not None else None
+
+
+def _ptrv(t):
+    return t.data_ptr() if t is not None else 0
 
 
 # ------------------------------------------------------------------------------------------------
@@ -51,7 +65,10 @@ def _capturing():
 
 
 def _cap_tag():
-    """0 outside a capture, else the id of the capture being recorded."""
+    """0 outside a capture, else the id of the capture being recorded.  (graph.GraphedStep announces its capture through
+    begin_capture(): without one no stream query is made -- six of them cost 25 us of a Python-driven step.)"""
+    if not _capture['active']:
+        return 0
     return _capture['active'] if _capturing() else 0
 
 
@@ -116,16 +133,27 @@ def note_raw_write(tensors):
     """A library kernel is about to overwrite these tensors in place (mapper.FusedAdam, MaskedGridOptimizer): bump their
     version counters so the caches keyed on `_version` miss, and -- under capture -- remember them so that every replay
     of the graph bumps them again (the Python call itself only runs at capture time)."""
-    for t in tensors:
-        torch._C._increment_version(t)
+    torch._C._increment_version(list(tensors))      # (a LIST: handed a tensor, the call iterates over its rows -- 25 us each)
     if _capture['raw_writes'] is not None and _capturing():
         _capture['raw_writes'].extend(tensors)
 
 
+_bound6_cache = {}
+
+
 def bound6(bound):
-    """[3,2] tensor -> (c_double*6) x_lo,x_hi,y_lo,y_hi,z_lo,z_hi."""
+    """[3,2] tensor -> (c_double*6) x_lo,x_hi,y_lo,y_hi,z_lo,z_hi.  Cached per (tensor identity, version): a scene's bound is
+    set once (EvenNICER_SLAM.load_bound) and read by every render call."""
+    key = id(bound)
+    hit = _bound6_cache.get(key)
+    if hit is not None and hit[0]() is bound and hit[1] == bound._version:
+        return hit[2]
     b = bound.detach().to('cpu', torch.float64).reshape(-1).tolist()
-    return (ctypes.c_double * 6)(*b)
+    out = (ctypes.c_double * 6)(*b)
+    if len(_bound6_cache) > 64:
+        _bound6_cache.clear()
+    _bound6_cache[key] = (weakref.ref(bound), bound._version, out)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -155,21 +183,52 @@ def decoder_params(dec, kind):
     return ps
 
 
+_flat_offsets = {}
+
+
+def _flat_params_struct(kind, like, base):
+    """enslam_mlp_params of tensors laid out back to back (float32) from address `base` in decoder_params() order with the
+    sizes of `like` -> (struct, address behind the last one).  The byte offsets are cached per (kind, sizes)."""
+    key = (kind, tuple(t.numel() for t in like))
+    offs = _flat_offsets.get(key)
+    if offs is None:
+        o, offs = 0, []
+        for n in key[1]:
+            offs.append(o)
+            o += 4 * n
+        offs.append(o)
+        _flat_offsets[key] = offs = tuple(offs)
+    s = L.MlpParams()
+    it = iter(offs)
+    for i in range(5):
+        s.W[i] = base + next(it)
+        s.b[i] = base + next(it)
+    if kind != L.MLP_COARSE:
+        for i in range(5):
+            s.Wc[i] = base + next(it)
+            s.bc[i] = base + next(it)
+    s.Wo = base + next(it)
+    s.bo = base + next(it)
+    if kind != L.MLP_COARSE:
+        s.B = base + next(it)
+    return s, base + offs[-1]
+
+
 def _fill_params_struct(kind, tensors):
     """enslam_mlp_params from tensors in decoder_params() order (entries may be None)."""
     s = L.MlpParams()
     it = iter(tensors)
     for i in range(5):
-        s.W[i] = _ptr(next(it)).value
-        s.b[i] = _ptr(next(it)).value
+        s.W[i] = _ptrv(next(it))
+        s.b[i] = _ptrv(next(it))
     if kind != L.MLP_COARSE:
         for i in range(5):
-            s.Wc[i] = _ptr(next(it)).value
-            s.bc[i] = _ptr(next(it)).value
-    s.Wo = _ptr(next(it)).value
-    s.bo = _ptr(next(it)).value
+            s.Wc[i] = _ptrv(next(it))
+            s.bc[i] = _ptrv(next(it))
+    s.Wo = _ptrv(next(it))
+    s.bo = _ptrv(next(it))
     if kind != L.MLP_COARSE:
-        s.B = _ptr(next(it)).value
+        s.B = _ptrv(next(it))
     return s
 
 
@@ -200,6 +259,19 @@ def _check_params(kind, ps):
         _require_hip(t, "decoder parameters")
 
 
+_ELEM_SIZE = {torch.uint8: 1, torch.int32: 4, torch.float32: 4, torch.float64: 8, torch.int64: 8}
+_size_memo = {}
+
+
+def _lib_size(name, *args):
+    """Memoised size queries of the library (enslam_packed_floats & co.: pure functions of small integers)."""
+    key = (name,) + args
+    v = _size_memo.get(key)
+    if v is None:
+        v = _size_memo[key] = int(getattr(L.lib(), name)(*args))
+    return v
+
+
 class _ZeroArena:
     """One zero-filled allocation per render call, handed out in aligned typed slices (block flags, validity
     bitmaps, packed-decoder buffers): one fill node in the step's graph instead of one per consumer."""
@@ -223,7 +295,7 @@ class _ZeroArena:
     def take(self, n, dtype):
         if self.buf is None:
             self._alloc()
-        nb = n * torch.empty((), dtype=dtype).element_size()
+        nb = n * _ELEM_SIZE[dtype]
         off = (self.off + 15) & ~15
         if off + nb > self.buf.numel():
             return torch.zeros(n, dtype=dtype, device=self.buf.device)
@@ -243,7 +315,7 @@ class _PackCache:
         return key == self.key and self.packed is not None and _tag_visible(self.tag)
 
     def get(self, kind, ps):
-        key = tuple((id(p), p.data_ptr(), p._version) for p in ps)
+        key = _params_key(self, ps)
         if not self.fresh(key):
             _check_params(kind, ps)
             n = L.lib().enslam_packed_floats(kind)
@@ -258,6 +330,22 @@ class _PackCache:
 _pack_caches = weakref.WeakKeyDictionary()      # decoder module -> _PackCache
 
 
+def _params_key(cache, ps):
+    """Cache key of a decoder's parameter list: (id, data_ptr, _version) per tensor -- 69 x 3 attribute reads per colour-stage
+    call when built naively.  While the list holds the SAME tensor objects as the previous call (the normal case: a module's
+    parameters) only the version counters and the storage addresses are re-read, and the address part of the previous key is
+    reused when none moved (an optimiser step changes versions, never storage)."""
+    prev = getattr(cache, 'ps_seen', None)
+    if prev is not None and len(prev) == len(ps) and all(a is b for a, b in zip(prev, ps)):
+        ptrs = tuple(p.data_ptr() for p in ps)
+        if ptrs == cache.ptrs_seen:
+            return (cache.ids_seen, ptrs, tuple(p._version for p in ps))
+    cache.ps_seen = list(ps)
+    cache.ids_seen = tuple(id(p) for p in ps)
+    cache.ptrs_seen = tuple(p.data_ptr() for p in ps)
+    return (cache.ids_seen, cache.ptrs_seen, tuple(p._version for p in ps))
+
+
 def packed_decoders(items, arena=None, defer=False):
     """Packed forms of several decoders [(module, kind, params)]; stale ones are rebuilt with ONE zero-fill and ONE
     launch (up to three decoders per launch).  defer=True (at most three stale decoders): nothing is launched, the
@@ -269,7 +357,7 @@ def packed_decoders(items, arena=None, defer=False):
         cache = _pack_caches.get(dec)
         if cache is None:
             cache = _pack_caches[dec] = _PackCache()
-        key = tuple((id(p), p.data_ptr(), p._version) for p in ps)
+        key = _params_key(cache, ps)
         if cache.fresh(key):
             out.append(cache.packed)
         else:
@@ -285,14 +373,14 @@ def packed_decoders(items, arena=None, defer=False):
 
     if stale:
         lib = L.lib()
-        sizes = [lib.enslam_packed_floats(items[i][1]) for i, _, _ in stale]
+        sizes = [_lib_size('enslam_packed_floats', items[i][1]) for i, _, _ in stale]
         flat = (arena.take(sum(sizes), torch.float32) if arena is not None else
                 torch.zeros(sum(sizes), dtype=torch.float32, device=items[stale[0][0]][2][0].device))
         pieces = flat.split(sizes)
         for j, (i, cache, key) in enumerate(stale):
             # an optimiser step changes versions, not storage: the shape checks and the pointer struct of unchanged
             # storages are reused (they are half of the host cost of a re-pack)
-            where = tuple(k[:2] for k in key)
+            where = key[:2]
             if where != getattr(cache, 'where', None):
                 _check_params(items[i][1], items[i][2])
                 cache.where, cache.struct = where, _fill_params_struct(items[i][1], items[i][2])
@@ -477,9 +565,9 @@ def refresh_in_place(c, decoders, stage='color'):
         if cache is None or cache.packed is None or cache.tag != 0:
             continue
         ps = decoder_params(dec, k)
-        key = tuple((id(p), p.data_ptr(), p._version) for p in ps)
+        key = _params_key(cache, ps)
         if key != cache.key:
-            where = tuple(q[:2] for q in key)
+            where = key[:2]
             if where != getattr(cache, 'where', None) or getattr(cache, 'struct', None) is None:
                 _check_params(k, ps)
                 cache.where, cache.struct = where, _fill_params_struct(k, ps)
@@ -618,7 +706,7 @@ class _Accumulators:
             D, H, W = dims[k]
             sizes.append(D * H * W * 32 if (self.need_grid[k] and k not in plan.vm) else 0)
         for k in plan.kinds:
-            sizes.append(lib.enslam_packed_grad_floats(k) if self.need_par[k] else 0)
+            sizes.append(_lib_size('enslam_packed_grad_floats', k) if self.need_par[k] else 0)
         sizes.append(6 * N if self.need_rays else 0)
         offs = [0]
         for n in sizes:
@@ -665,9 +753,8 @@ class _RenderFn(torch.autograd.Function):
         dev = rays_o.device
         S = plan.n_lin + (plan.n_surf if gt_depth is not None else 0)
         st = _stream()
-        ro = rays_o.detach().contiguous().float()
-        rd = rays_d.detach().contiguous().float()
-        gd = gt_depth.detach().contiguous().float().reshape(-1) if gt_depth is not None else None
+        ro, rd = _f32c(rays_o), _f32c(rays_d)
+        gd = _f32c(gt_depth).reshape(-1) if gt_depth is not None else None
         SV = None                                   # real samples per ray when the last tile is padded
         if plan.z_given is not None:
             z = plan.z_given.detach().to(torch.float64).contiguous()
@@ -694,7 +781,7 @@ class _RenderFn(torch.autograd.Function):
         # in the flat buffer the prepare launch clears.  Everywhere else: one zero-filled arena per call.
         cap = bool(_capturing() and _capture['init_zero'] is not None and plan.loss is not None and plan.z_given is None
                    and any(ctx.needs_input_grad[5:5 + nk]))
-        arena = _ZeroArena(dev, 2 * sum(nblk) + 4 * sum(lib.enslam_packed_floats(k) for k in plan.kinds) + 256 + 32, persistent=cap)
+        arena = _ZeroArena(dev, 2 * sum(nblk) + 4 * sum(_lib_size('enslam_packed_floats', k) for k in plan.kinds) + 256 + 32, persistent=cap)
         flags = [None] * nk
         grids_vm, packed = {k: vmg[k].vm for k in vmg}, {}
         state = plan.state
@@ -759,7 +846,7 @@ class _RenderFn(torch.autograd.Function):
         # no decoder parameter wants a gradient (tracker; mapper stages with fixed decoders): the light workspace
         act_light = int(not any(ctx.needs_input_grad[5 + nk:]))
         if any(ctx.needs_input_grad):
-            n_act = lib.enslam_activation_floats(L.STAGE[plan.stage], N, S, act_light)
+            n_act = _lib_size('enslam_activation_floats', L.STAGE[plan.stage], N, S, act_light)
             if 0 < n_act * 4 <= ACT_WORKSPACE_LIMIT_BYTES and max(d[0] * d[1] * d[2] for d in dims.values()) < (1 << 29):
                 act = torch.empty(n_act, dtype=torch.float32, device=dev)
         loss = None
@@ -802,7 +889,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.work_filled = plan.loss is not None and work is not None and d_raw_unit is not None      # (by the forward)
         ctx.grid_shapes = [tuple(g.shape) for g in grids]
         ctx.grid_ids = [id(g) for g in grids]
-        ctx.param_meta = [(tuple(t.shape)) for t in tensors[nk:]]
+        ctx.param_like = tensors[nk:]
         if loss is not None:
             ctx.mark_non_differentiable(depth, var, rgb)
             return loss[0], depth, var, rgb
@@ -827,7 +914,12 @@ class _RenderFn(torch.autograd.Function):
         def prep(g, dtype, shape):
             if g is None:
                 return None
-            return g.detach().to(dtype).expand(shape).contiguous()
+            g = g.detach()
+            if g.dtype is not dtype:
+                g = g.to(dtype)
+            if tuple(g.shape) != shape:
+                g = g.expand(shape)
+            return g if g.is_contiguous() else g.contiguous()
 
         gD, gV, gC = prep(g_depth, torch.float64, (N,)), prep(g_var, torch.float64, (N,)), prep(g_rgb, torch.float32, (N, 3))
         gL = prep(g_loss, torch.float64, (1,))
@@ -863,10 +955,10 @@ class _RenderFn(torch.autograd.Function):
                 g_packed[k] = zbase + 4 * offs[nk + i]
                 gpk[k] = g_packed[k]
                 if USE_DW_PARTIALS:
-                    part_keep[k] = torch.empty(lib.enslam_bwd_partial_floats(k), dtype=torch.float32, device=dev)
+                    part_keep[k] = torch.empty(_lib_size('enslam_bwd_partial_floats', k), dtype=torch.float32, device=dev)
                     gpart[k] = part_keep[k].data_ptr()
         g_ro = g_rd = None
-        p_ro = p_rd = ctypes.c_void_p(0)
+        p_ro = p_rd = None
         if need_rays:
             r0 = offs[2 * nk] - n_grid
             g_ro = zbuf[r0:r0 + 3 * N].view(N, 3)
@@ -907,7 +999,7 @@ class _RenderFn(torch.autograd.Function):
         inline_rays = (not finish_needed) if INLINE_RAY_GRAD is None else INLINE_RAY_GRAD
         dgw = None
         if act is not None and need_rays and not inline_rays:
-            dgw = torch.empty(lib.enslam_grid_handoff_floats(L.STAGE[plan.stage], N, S), dtype=torch.float32, device=dev)
+            dgw = torch.empty(_lib_size('enslam_grid_handoff_floats', L.STAGE[plan.stage], N, S), dtype=torch.float32, device=dev)
         ev = plan.state.profile.get('decoder_bwd')
         if ev is not None:                      # bench.py: HIP events around the dominant kernel, on this stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -955,23 +1047,33 @@ class _RenderFn(torch.autograd.Function):
                 _persist_prev[g.data_ptr()] = pv
         for k in plan.kinds:
             out.append(grid_out.get(k))
-        pm = iter(ctx.param_meta)
-        shapes_by_kind = {k: [next(pm) for _ in range(plan.n_params[k])] for k in plan.kinds}
         kinds_p = [k for k in plan.kinds if need_par[k]]
         views_by_kind = {}
         npk = len(kinds_p)
         kind_arr, pk_arr, structs = (ctypes.c_int32 * max(npk, 1))(), (ctypes.c_void_p * max(npk, 1))(), (L.MlpParams * max(npk, 1))()
         part_arr = (ctypes.c_void_p * max(npk, 1))()
         if kinds_p:
-            all_sizes = [int(torch.Size(sh).numel()) for k in kinds_p for sh in shapes_by_kind[k]]
-            pflat = torch.empty(sum(all_sizes), dtype=torch.float32, device=dev)
-            it = iter(pflat.split(all_sizes))
+            # the gradients of all decoder parameters are views of ONE fresh flat buffer, shaped like the parameters by one
+            # C++ call (69 x split + view in Python cost 0.19 ms per step); the pointer structs come from the flat base and
+            # the parameters' (fixed) sizes
+            like, po = [], nk
+            like_by_kind = {}
+            for k in plan.kinds:
+                if need_par[k]:
+                    like_by_kind[k] = ctx.param_like[po - nk:po - nk + plan.n_params[k]]
+                    like += like_by_kind[k]
+                po += plan.n_params[k]
+            total = sum(t.numel() for t in like)
+            pflat = torch.empty(total, dtype=torch.float32, device=dev)
+            views = torch._C._nn.unflatten_dense_tensors(pflat, like)
+            base, vo = pflat.data_ptr(), 0
             for j, k in enumerate(kinds_p):
-                views = [next(it).view(sh) for sh in shapes_by_kind[k]]
-                views_by_kind[k] = views
+                n = plan.n_params[k]
+                views_by_kind[k] = list(views[vo:vo + n])
+                vo += n
                 kind_arr[j], pk_arr[j] = k, g_packed[k]
                 part_arr[j] = gpart[k]
-                structs[j] = _fill_params_struct(k, views)
+                structs[j], base = _flat_params_struct(k, like_by_kind[k], base)
         if nc or npk or ray_pending:
             L.check(lib.enslam_step_finish_partials(nc, srcs, dsts, vs, need_ptrs, prev_ptrs, npk, kind_arr, pk_arr, part_arr, structs,
                                                     L.STAGE[plan.stage], N if ray_pending else 0, S, _ptr(ro), _ptr(rd), _ptr(z),
@@ -1004,7 +1106,18 @@ def last_active_tile_fraction():
     return _latest_state[0].last_active_tile_fraction()
 
 
+# torch.autograd.Function.apply first scans every argument for functorch wrappers (30-35 us for the ~80 arguments of a
+# colour-stage call); no transform is ever active on this path, so the C-level apply is bound directly.  Falls back to the
+# public entry when the private attribute is missing or a functorch transform IS active.
+try:
+    _render_apply = torch._C._FunctionBase.__dict__['apply'].__get__(None, _RenderFn)
+except Exception:           # pragma: no cover
+    _render_apply = None
+
+
 def render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params_flat):
+    if _render_apply is not None and not torch._C._are_functorch_transforms_active():
+        return _render_apply(plan, rays_o, rays_d, gt_depth, t_rand, *grids, *params_flat)
     return _RenderFn.apply(plan, rays_o, rays_d, gt_depth, t_rand, *grids, *params_flat)
 
 

@@ -50,6 +50,6 @@ class GraphedStep:
 
     def replay(self):
         self.graph.replay()
-        for t in self.raw_writes:
-            torch._C._increment_version(t)
+        if self.raw_writes:
+            torch._C._increment_version(self.raw_writes)        # one call for the list (a bare tensor would be iterated row by row)
         return self.out

@@ -14,11 +14,11 @@ ro.requires_grad_(True); rd.requires_grad_(True)
 renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **bench.CAM))
 leaves = [grids[k] for k in ('grid_middle','grid_fine','grid_color')] + [p for n in ('middle_decoder','fine_decoder','color_decoder') for p in getattr(model, n).parameters()]
 def step():
-    EF.clear_caches()
+    torch._C._increment_version(leaves)
     for t in leaves: t.grad = None
     ro.grad = None; rd.grad = None
     d, v, c = renderer.render_batch_ray(grids, model, rd, ro, dev, 'color', gt_depth=gd)
-    E.losses.rgbd_loss(d, c, gd, gc, 0.2).backward()
+    (bench.mapper_loss(d, c, gd, gc, 'color') if os.environ.get('TORCH_LOSS', '1') == '1' else E.losses.rgbd_loss(d, c, gd, gc, 0.2)).backward()
 for _ in range(20): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -27,7 +27,9 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"host-only per step {1e3*(t1-t0)/200:.3f} ms ; with final sync {1e3*(t2-t0)/200:.3f} ms")
+torch.autograd.set_multithreading_enabled(False)      # the engine then calls the Python backward on this thread: cProfile sees it
 pr = cProfile.Profile(); pr.enable()
 for _ in range(200): step()
 pr.disable(); torch.cuda.synchronize()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(28); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(40); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(30); print(s.getvalue()[:7000])
