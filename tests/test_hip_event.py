@@ -200,3 +200,58 @@ def test_static_shape_and_graphed_iteration_match_fixture(monkeypatch):
 def E_tracker():
     import evennicer_slam_amd as E
     return E.tracker
+
+
+def test_render_img_rescale_full_size_matches_reference():
+    """BASELINE config 3's cost centre at FULL size: Renderer.render_img_rescale on room0, 102 x 180 = 18 360 rays x 48,
+    scale 0.15, against the reference's own render_img_rescale (tests/golden/room0_rescale_18360.npz): colour / depth /
+    uncertainty images to 1e-4 relative, the gradient of a seeded functional of colour and depth with respect to c2w to 1e-3,
+    and the tracker's fused pose -> ray formulation (TrackerIteration._render_rescaled) against the same colour image."""
+    import types
+    import bench
+    import evennicer_slam_amd as E
+    from tests.util import load, rel_err, within_rel
+    DEV = 'cuda:0'
+    g = load('room0_rescale_18360')
+    sc = bench.build_scene_cpu('room0', seed=0)
+    assert np.allclose([float(sc['grids'][k].double().sum()) for k in sc['grids']], g['grid_checksum'], rtol=0, atol=1e-9)
+    assert abs(float(sc['depth_img'].double().sum()) - float(g['depth_img_checksum'])) < 1e-6
+    model = sc['model'].cuda()
+    bench.attach_bounds(model, sc['bound'])
+    for q in model.parameters():
+        q.requires_grad_(False)
+    grids = {k: v.cuda() for k, v in sc['grids'].items()}
+    renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **bench.CAM))
+    depth_img = sc['depth_img'].cuda()
+    c2w = torch.from_numpy(g['c2w']).cuda().requires_grad_(True)
+    sf = float(g['scale_factor'])
+    depth, unc, color = renderer.render_img_rescale(grids, model, c2w, DEV, 'color', gt_depth=depth_img, scale_factor=sf)
+    assert tuple(color.shape) == (102, 180, 3) and depth.dtype == torch.float64
+    # floor: entries below 10 % of the image's largest magnitude are compared against that 10 % (the colour of random-init
+    # decoders is a signed float32 sum over 48 samples that cancels to near zero in places: its absolute rounding error is
+    # ~5e-6 of the largest value on either implementation)
+    for name, got in (('color', color), ('depth', depth), ('uncertainty', unc)):
+        # (uncertainty = second moment about the rendered depth: not part of north_star's 1e-4 bar, amplifies the float32
+        # rounding of the resized depth image; 3e-4 above a 1 % floor)
+        ok, worst = within_rel(got.detach().cpu().numpy(), g[name], rel=3e-4 if name == 'uncertainty' else 1e-4,
+                               floor={'color': 0.1, 'depth': 1e-3}.get(name, 1e-2))
+        assert ok, (name, worst)
+    loss = (color * torch.from_numpy(g['w_color']).cuda()).sum().double() + (depth * torch.from_numpy(g['w_depth']).cuda()).sum()
+    assert abs(float(loss) - float(g['loss'])) < 1e-4 * max(abs(float(g['loss'])), 1.0)
+    loss.backward()
+    assert rel_err(c2w.grad.cpu().numpy(), g['g_c2w']) < 1e-3
+    # the tracker's formulation: camera tensor (quaternion + translation) -> rays in one fused launch
+    cfg = dict(sc['cfg'])
+    cfg['tracking'] = {'device': DEV, 'w_color_loss': 0.5, 'ignore_edge_W': 100, 'ignore_edge_H': 100, 'handle_dynamic': True,
+                       'use_color_in_tracking': True}
+    cfg['event'] = {'activate_events': False, 'blur': False, 'kernel_sizes': [9], 'kernel_weights': [1], 'unblurred_weight': 0,
+                    'balancer': 0.025}
+    slam = types.SimpleNamespace(nice=True, bound=sc['bound'], renderer=renderer, event_net=None, low_gpu_mem=False, **bench.CAM)
+    trk = E.tracker.TrackerIteration(cfg, None, slam)
+    trk.c, trk.decoders = grids, model
+    ct = E.common.get_tensor_from_camera(torch.from_numpy(g['c2w'])).to(DEV).float().requires_grad_(True)
+    col2 = trk._render_rescaled(ct, depth_img, sf)
+    ok, worst = within_rel(col2.detach().cpu().numpy(), g['color'], rel=1e-4, floor=0.1)
+    assert ok, worst
+    (col2 * torch.from_numpy(g['w_color']).cuda()).sum().backward()
+    assert ct.grad is not None and bool(torch.isfinite(ct.grad).all()) and float(ct.grad.abs().max()) > 0

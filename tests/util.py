@@ -34,3 +34,13 @@ def elem_rel_err(a, b, floor):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
+
+
+def within_rel(a, b, rel=1e-4, floor=1e-2):
+    """north_star's output bar as a PURE relative test with an explicit near-zero floor: |a - b| <= rel * max(|b|, floor * max|b|)
+    elementwise -- entries smaller than `floor` of the tensor's largest magnitude are compared against that magnitude (a
+    relative test of a value that is itself rounding noise says nothing)."""
+    import numpy as np
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = np.maximum(np.abs(b), floor * np.abs(b).max())
+    return bool(np.all(np.abs(a - b) <= rel * scale)), float((np.abs(a - b) / scale).max())
