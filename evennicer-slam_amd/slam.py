@@ -9,10 +9,19 @@ the same per-frame schedule runs in one process on one GPU, tracker and mapper a
   every `mapping.every_frame`-th frame: `mapping.iters` joint iterations (`mapper.MapperIteration`: frustum-masked grids,
                   colour decoder, local BA over the window of keyframes -- the reference's `global` selection: random
                   keyframes + the latest one + the current frame, Mapper.py:280-303) and `update_para_from_mapping`
+                  then -- `cfg['coarse']` -- the COARSE mapper's round on the same frame (the reference's third process,
+                  EvenNICER_SLAM.py:303-311: `Mapper(..., coarse_mapper=True)` runs the same schedule with stage `coarse`
+                  only, every voxel of `grid_coarse` optimisable, no depth guidance, no BA; Mapper.py:133-136,326-328,
+                  460-461,550,797-798)
   keyframes       every `mapping.keyframe_every` frames (Mapper.py:687-692)
   end             `Logger.log` checkpoint in the reference's format, ATE through `eval_ate.evaluate_checkpoint`
 
-Not here: the coarse mapper process (scene-extent prediction), mesh extraction, visualiser, wandb."""
+`SLAM.prefit_decoders` stands in for the pretrained ConvONet decoders the reference loads (EvenNICER_SLAM.load_pretrain;
+the checkpoints are not in the image): decoders and grids are fitted jointly to a few ground-truth-posed frames of the
+sequence, the decoders are kept, the grids are re-initialised -- the run itself then optimises grids (and the colour decoder)
+only, as the reference does.
+
+Not here: mesh extraction, visualiser, wandb."""
 import os
 import time
 import types
@@ -105,7 +114,7 @@ class SLAM:
         self.tracker.c = {k: v.detach().clone() for k, v in self.shared_c.items()}
 
     def track(self, idx, gt_color, gt_depth, gt_event, gt_mask, pre_gt_color):
-        t = self.cfg['tracking']
+        t = getattr(self, '_track_cfg', None) or self.cfg['tracking']
         pre = self.estimate_c2w_list[idx - 1].to(self.device)
         if t.get('const_speed_assumption', True) and idx - 2 >= 0:         # Tracker.py:295-301
             pre = pre.float()
@@ -116,16 +125,22 @@ class SLAM:
         camera_tensor = get_tensor_from_camera(est.detach()).to(self.device).requires_grad_(True)
         opt = FusedAdam([camera_tensor], lr=t['lr'])
         use_event = self.event_net is not None and self.cfg['event'].get('activate_events', False)
-        best, best_loss = camera_tensor.detach().clone(), None
+        best, best_loss, first_loss = camera_tensor.detach().clone(), None, None
         for it in range(t['iters']):
             out = self.tracker.optimize_cam_in_batch(camera_tensor, est, gt_color, gt_depth, gt_event, gt_mask, t['pixels'], opt,
                                                      idx, it, pre_gt_color, rgbd=True, event=use_event,
                                                      scale_factor=self.cfg['event'].get('scale_factor', 0.1))
             loss = out[0] + (out[1] if (use_event and out[1] is not None) else 0.0)
+            if it == 0:
+                first_loss = loss
             if best_loss is None or loss < best_loss:                       # Tracker.py:321-330 (candidate with the least loss)
                 best_loss, best = loss, camera_tensor.detach().clone()
         c2w = torch.eye(4, device=self.device)
         c2w[:3] = get_camera_from_tensor(best)
+        if self.verbose:
+            gt = self.gt_c2w_list[idx][:3, 3].to(self.device)
+            print(f'frame {idx}: tracking loss {first_loss} -> {best_loss}; translation error init '
+                  f'{float((est[:3, 3] - gt).norm()):.4f} -> {float((c2w[:3, 3] - gt).norm()):.4f} m', flush=True)
         return c2w
 
     # ---------------------------------------------------------------- mapper side
@@ -155,6 +170,17 @@ class SLAM:
         for j in range(iters):
             loss = it.step(j, iters)
         cams = it.finish()
+        if self.cfg.get('coarse', False):
+            # the coarse mapper's round on this frame (the reference's third process): stage `coarse`, every voxel of grid_coarse,
+            # the same selected frames at their current (fixed) poses
+            cfg_c = dict(self.cfg)
+            cfg_c['mapping'] = dict(cfg['mapping'], BA=False)
+            frames_c = [dict(f, fixed=True) for f in frames]
+            itc = MapperIteration(cfg_c, self.renderer, self.shared_c, self.shared_decoders, frames_c, self.cam, masks=None,
+                                  keys=('grid_coarse',), static_shapes=self.static_shapes)
+            for j in range(iters):
+                self.last_coarse_loss = itc.step(j, iters)
+            itc.finish()
         if ba:                                                               # Mapper.py:644-660: poses back to the lists
             for f, ct in zip(frames, cams):
                 if ct is None:
@@ -168,8 +194,50 @@ class SLAM:
         return cur_c2w, (float(loss.item()) if loss is not None else None)
 
     # ---------------------------------------------------------------- the run
-    def run(self, max_frames=None):
-        m, t = self.cfg['mapping'], self.cfg['tracking']
+    def prefit_decoders(self, indices, iters=300, pixels=None, lr_grid=0.02, lr_dec=2e-3, seed=0):
+        """Stand-in for `load_pretrain` (no checkpoint ships with the image): fit ALL decoders and the grids jointly to the
+        frames `indices` of the dataset at their ground-truth poses (random pixels -> render -> the mapper's loss -> Adam,
+        colour stage, through the HIP path), keep the decoders, re-initialise the grids.  Returns the final loss."""
+        from .common import get_samples
+        from .losses import rgbd_loss
+        dev = self.device
+        pixels = pixels or self.cfg['mapping']['pixels']
+        items = [self.dataset[i] for i in indices]
+        frames = [(it[1].float(), it[2], it[-1][:3].to(dev)) for it in items]
+        grids = {k: v.detach().clone().requires_grad_(True) for k, v in self.shared_c.items()}
+        dec = self.shared_decoders
+        params = [q for q in dec.parameters()]
+        for q in params:
+            q.requires_grad_(True)
+        opt = torch.optim.Adam([{'params': [grids[k] for k in MAP_KEYS], 'lr': lr_grid}, {'params': params, 'lr': lr_dec}])
+        gen = torch.cuda.get_rng_state(dev)
+        torch.manual_seed(seed)
+        n = max(pixels // len(frames), 1)
+        loss = None
+        for _ in range(iters):
+            ro, rd, gd, gc = [], [], [], []
+            for color, depth, c2w in frames:
+                o, d, dep, col = get_samples(0, self.H, 0, self.W, n, self.H, self.W, self.fx, self.fy, self.cx, self.cy, c2w,
+                                             depth, color, dev)
+                ro.append(o.float()); rd.append(d.float()); gd.append(dep.float()); gc.append(col.float())
+            ro, rd, gd, gc = torch.cat(ro), torch.cat(rd), torch.cat(gd), torch.cat(gc)
+            opt.zero_grad(set_to_none=True)
+            depth, _u, color = self.renderer.render_batch_ray(grids, dec, rd, ro, dev, 'color', gt_depth=gd)
+            loss = rgbd_loss(depth, color, gd, gc, self.cfg['mapping']['w_color_loss'])
+            loss.backward()
+            opt.step()
+        for q in params:
+            q.grad = None
+        torch.cuda.set_rng_state(gen, dev)
+        return float(loss.item()) if loss is not None else None
+
+    def run(self, max_frames=None, tracking_iters=None):
+        """tracking_iters overrides cfg['tracking']['iters'] (0: poses stay at their constant-speed initialisation -- the
+        baseline an ATE improvement is measured against)."""
+        m, t = self.cfg['mapping'], dict(self.cfg['tracking'])
+        if tracking_iters is not None:
+            t['iters'] = int(tracking_iters)
+        self._track_cfg = t
         n = self.n_img if max_frames is None else min(max_frames, self.n_img)
         pre_color = None
         for idx in range(n):

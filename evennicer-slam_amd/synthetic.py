@@ -98,3 +98,50 @@ def trajectory(room, n_frames, step=0.02, yaw_deg=0.4):
         tgt = c + ext * np.array([0.20 * math.cos(a) + 0.10, -0.25 + 0.20 * math.sin(a), 0.02 * math.sin(2 * a)])
         poses.append(look_at(eye, tgt).float())
     return poses
+
+
+def demo_config(inp, evf, cam, device='cuda:0', env=None):
+    """Configuration of the run harness for the tiny analytic room of `write_demo_sequence` (the reference's schedule and
+    learning rates, configs/nice_slam.yaml, at a size that runs in seconds; environment-style overrides through `env`).
+    One deliberate difference: lr_first_factor is 1, not 5 -- the decoders here are fitted to a handful of frames
+    (SLAM.prefit_decoders), not ConvONet-pretrained, and a middle-grid learning rate of 0.5 on frame 0 left the map at its
+    initial loss in about half of the runs (measured: tools/run_synthetic_slam.py, LR_FIRST=5)."""
+    env = env or {}
+    stage = {'coarse': dict(decoders_lr=0.0, coarse_lr=0.001, middle_lr=0.0, fine_lr=0.0, color_lr=0.0),
+             'middle': dict(decoders_lr=0.0, coarse_lr=0.0, middle_lr=0.1, fine_lr=0.0, color_lr=0.0),
+             'fine': dict(decoders_lr=0.0, coarse_lr=0.0, middle_lr=0.005, fine_lr=0.005, color_lr=0.0),
+             'color': dict(decoders_lr=0.005, coarse_lr=0.0, middle_lr=0.005, fine_lr=0.005, color_lr=0.005)}
+    return {
+        'dataset': 'replica_event', 'scale': 1, 'occupancy': True, 'coarse': True, 'data': {'dim': 3, 'input_folder': inp, 'event_folder': evf},
+        'rendering': {'lindisp': False, 'perturb': 0.0, 'N_samples': 32, 'N_surface': 16, 'N_importance': 0},
+        'model': {'c_dim': 32, 'coarse_bound_enlarge': 2, 'pos_embedding_method': 'fourier'},
+        'grid_len': {'coarse': 0.8, 'middle': 0.32, 'fine': 0.16, 'color': 0.16, 'bound_divisible': 0.32},
+        'cam': dict(cam, png_depth_scale=6553.5, crop_edge=0),
+        'mapping': {'bound': [[-1.0, 1.1], [-0.9, 0.8], [-0.7, 0.6]], 'w_color_loss': 0.2, 'lr_factor': 1, 'lr_first_factor': float(env.get('LR_FIRST', 1)),
+                    'BA': False, 'BA_cam_lr': 0.001, 'middle_iter_ratio': 0.4, 'fine_iter_ratio': 0.6, 'fix_fine': True,
+                    'fix_color': False, 'pixels': int(env.get('MAP_PIXELS', 600)), 'iters_first': int(env.get('ITERS_FIRST', 400)),
+                    'iters': int(env.get('MAP_ITERS', 30)), 'every_frame': int(env.get('EVERY', 3)), 'keyframe_every': 6,
+                    'mapping_window_size': 5, 'frustum_feature_selection': True, 'stage': stage},
+        'tracking': {'device': device, 'w_color_loss': 0.5, 'ignore_edge_W': 4, 'ignore_edge_H': 4, 'handle_dynamic': True,
+                     'use_color_in_tracking': True, 'lr': float(env.get('TRACK_LR', 0.002)), 'pixels': int(env.get('TRACK_PIXELS', 400)),
+                     'iters': int(env.get('TRACK_ITERS', 20)), 'const_speed_assumption': True, 'gt_camera': False},
+        'event': {'activate_events': False, 'blur': True, 'kernel_sizes': [9], 'kernel_weights': [1], 'unblurred_weight': 0,
+                  'balancer': 0.025, 'scale_factor': 0.5},
+    }
+
+
+def write_demo_sequence(root, n, cam, step=0.012, yaw_deg=0.5):
+    """n frames of a BoxRoom inside the demo bound along `trajectory`, written in the Replica_event layout (all-zero events).
+    Returns ((input_folder, event_folder), poses)."""
+    from . import datasets as D
+    from .scene import scene_bound
+    bound = scene_bound([[-1.0, 1.1], [-0.9, 0.8], [-0.7, 0.6]], 1.0, 0.32)
+    room = BoxRoom.for_bound(bound, margin=0.12, seed=1)
+    poses = trajectory(room, n, step=step, yaw_deg=yaw_deg)
+    frames, events = [], []
+    for i, c2w in enumerate(poses):
+        col, dep = room.render(c2w.double(), cam)
+        frames.append((col.numpy(), dep.numpy()))
+        if i > 0:
+            events.append(np.zeros((cam['H'], cam['W'], 2), dtype=np.uint8))
+    return D.write_replica_event_sequence(root, frames, [p.numpy() for p in poses], 6553.5, events), poses

@@ -50,8 +50,10 @@ def test_replica_event_reader_roundtrip(tmp_path):
     assert tuple(d2.shape) == (20, 28) and tuple(e2.shape) == (20, 28, 2)
     assert np.allclose(d2.numpy(), 2.0 * frames[1][1][2:-2, 2:-2], atol=2.0 / 6553.5)
     assert np.allclose(p2[:3, 3].numpy(), 2.0 * poses[1][:3, 3], atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        D.get_dataset(dict(cfg, cam=dict(cfg['cam'], distortion=[0.1, 0, 0, 0])), types.SimpleNamespace(), 1, device='cpu')
+    # a lens model on a Replica-layout sequence: the colour image is undistorted, the depth is not (datasets.py:84-88)
+    ds3 = D.get_dataset(dict(cfg, cam=dict(cfg['cam'], crop_edge=0, distortion=[0.1, 0, 0, 0])), types.SimpleNamespace(), 1, device='cpu')
+    _, c3, d3, _e, _m, _p = ds3[1]
+    assert torch.equal(d3, ds[1][2]) and not torch.equal(c3, ds[1][1])
 
 
 def test_frustum_mask_selects_what_the_camera_sees():
@@ -117,3 +119,78 @@ def test_checkpoint_format_and_ate_against_the_reference_tool(tmp_path):
     theirs = ref.evaluate_ate(first, second, "")
     for k, v in theirs.items():
         assert abs(mine[k] - v) <= 1e-9 * max(1.0, abs(v)), k
+
+
+def _smooth_image(u, v):
+    """A smooth analytic grey image as a function of (undistorted) pixel coordinates."""
+    return 127.5 + 60.0 * np.sin(0.05 * u + 0.3) * np.cos(0.04 * v - 0.2) + 40.0 * np.sin(0.021 * (u + v))
+
+
+def test_undistort_round_trip_and_identity():
+    """`undistort` = cv2.undistort(img, K, dist) restated (cv2 is not in the image): zero coefficients are the identity, and an
+    image DISTORTED analytically with OpenCV's lens model (rational radial + tangential, the RPG configuration's coefficients
+    times 5 to make the effect large) comes back as the undistorted original up to bilinear interpolation error."""
+    H, W = 130, 173
+    K = (98.36, 98.34, 86.25, 64.75)                                   # configs/rpg/rpg.yaml:62-68 at half resolution
+    dist = np.array([-0.08409333, 0.05335822, -0.00065521, -0.0001679, 0, 0, 0, 0]) * 5
+    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    ideal = _smooth_image(u, v)
+    assert np.array_equal(D.undistort(ideal.astype(np.uint8), K, np.zeros(8)), ideal.astype(np.uint8))
+    # what the lens shows at distorted pixel (u', v'): the scene ray (x, y) with distort(x, y) = ((u'-cx)/fx, (v'-cy)/fy);
+    # invert the model by fixed-point iteration (the way cv2.undistortPoints does)
+    xd, yd = (u - K[2]) / K[0], (v - K[3]) / K[1]
+    x, y = xd.copy(), yd.copy()
+    for _ in range(600):
+        fx_, fy_ = D.distort_points(x, y, dist)
+        x, y = x - (fx_ - xd), y - (fy_ - yd)
+    fx_, fy_ = D.distort_points(x, y, dist)
+    assert np.abs(fx_ - xd).max() < 1e-9 and np.abs(fy_ - yd).max() < 1e-9
+    lens = _smooth_image(K[0] * x + K[2], K[1] * y + K[3])              # float image as the distorting lens records it
+    back = D.undistort(lens, K, dist)
+    # compare where the source position of the pixel lies inside the recorded image (elsewhere: zero border)
+    sx, sy = D.distort_points((u - K[2]) / K[0], (v - K[3]) / K[1], dist)
+    mx, my = K[0] * sx + K[2], K[1] * sy + K[3]
+    inside = (mx >= 1) & (mx <= W - 2) & (my >= 1) & (my <= H - 2)
+    assert inside.mean() > 0.8
+    assert np.abs(back - ideal)[inside].max() < 0.25                    # grey levels of 255: bilinear error of a smooth image
+    moved = np.hypot(mx - u, my - v)
+    assert moved.max() > 3.0                                            # the lens model really moved pixels (by > 3 px at the rim)
+    out8 = D.undistort(np.clip(np.rint(lens), 0, 255).astype(np.uint8), K, dist)
+    assert out8.dtype == np.uint8 and np.abs(out8.astype(np.float64) - ideal)[inside].max() <= 1.5
+
+
+def test_rpg_event_reader_roundtrip(tmp_path):
+    """RPG_event (src/utils/datasets.py:242-319; BASELINE config 5's format): grey frames replicated to 3 channels, 16-bit depth
+    / png_depth_scale, event pngs (+, -, 0) handed out as (-, +), mask, pose flip; with cam.distortion colour and events are
+    undistorted and the depth is not."""
+    rng = np.random.default_rng(3)
+    n, H, W = 4, 26, 34
+    frames = [((rng.random((H, W)) * 255).astype(np.uint8), (rng.random((H, W)) * 3).astype(np.float32)) for _ in range(n)]
+    poses = []
+    for i in range(n):
+        p = np.eye(4)
+        p[:3, 3] = [0.1 * i, 0.02 * i, -0.05 * i]
+        poses.append(p)
+    events = [rng.integers(0, 3, (H, W, 2)).astype(np.uint8) for _ in range(n - 1)]
+    inp, evf = D.write_rpg_event_sequence(str(tmp_path), frames, poses, 1000.0, events)
+    cam = dict(H=H, W=W, fx=19.6, fy=19.6, cx=16.5, cy=12.5, png_depth_scale=1000.0, crop_edge=0)
+    cfg = {'dataset': 'rpg_event', 'cam': cam, 'data': {'input_folder': inp, 'event_folder': evf}}
+    ds = D.get_dataset(cfg, types.SimpleNamespace(input_folder=None, event_folder=None), 1, device='cpu')
+    assert len(ds) == n
+    idx, color, depth, event, mask, pose = ds[2]
+    assert color.dtype == torch.float64 and tuple(color.shape) == (H, W, 3)
+    assert np.array_equal(np.rint(color.numpy() * 255).astype(np.uint8), np.repeat(frames[2][0][:, :, None], 3, 2))
+    assert float((depth - torch.from_numpy(frames[2][1])).abs().max()) <= 0.5 / 1000.0 + 1e-6
+    assert np.array_equal(event.numpy(), events[1]) and event.dtype == torch.uint8      # (-, +)
+    assert np.array_equal(mask.numpy(), (events[1] != 0).any(-1).astype(np.int64))
+    assert np.allclose(pose.numpy(), poses[2], atol=1e-6)
+    assert int(ds[0][3].abs().max()) == 0
+    cfg_d = dict(cfg, cam=dict(cam, distortion=[-0.4, 0.25, -0.003, -0.001, 0, 0, 0, 0]))
+    dsd = D.get_dataset(cfg_d, types.SimpleNamespace(input_folder=None, event_folder=None), 1, device='cpu')
+    _, cd, dd, ed, md, _pd = dsd[2]
+    assert torch.equal(dd, depth)                                       # the depth is never undistorted
+    assert not torch.equal(cd, color) and not torch.equal(ed, event)
+    K = (cam['fx'], cam['fy'], cam['cx'], cam['cy'])
+    want = D.undistort(np.repeat(frames[2][0][:, :, None], 3, 2), K, np.array(cfg_d['cam']['distortion']))
+    assert np.array_equal(np.rint(cd.numpy() * 255).astype(np.uint8), want)
+    assert 'rpg' in D.dataset_dict and issubclass(D.RPG_event, D.RPG)
