@@ -30,7 +30,7 @@ class _OracleRenderer:
         return d[:-1], v[:-1], c_[:-1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_rays=64):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -41,8 +41,8 @@ def _worker(rank, world, port, q):
         params, grids, bound, s = tiny_scene()
         params = {k: v.requires_grad_(True) for k, v in params.items()}
         grids = {k: v.requires_grad_(True) for k, v in grids.items()}
-        ro, rd = torch.from_numpy(s['rays_o']), torch.from_numpy(s['rays_d'])
-        gd, gc = torch.from_numpy(s['gt_depth']), torch.from_numpy(s['gt_color'])
+        ro, rd = torch.from_numpy(s['rays_o'])[:n_rays], torch.from_numpy(s['rays_d'])[:n_rays]
+        gd, gc = torch.from_numpy(s['gt_depth'])[:n_rays], torch.from_numpy(s['gt_color'])[:n_rays]
         sr = ShardedRenderer(_OracleRenderer(params, bound))
         (depth, var, color), sl = sr.render_batch_ray(grids, None, rd, ro, 'cpu', 'color', gt_depth=gd)
         R.mapper_loss(depth, color, gd[sl], gc[sl], 'color').backward()
@@ -206,3 +206,40 @@ def test_two_rank_row_sharded_image_render_matches_unsharded():
     assert np.abs(outs[0]['own'] + outs[1]['own'] - want).max() <= 1e-5 * np.abs(want).max()
     assert np.array_equal(outs[0]['color'], outs[1]['color'])                   # replicas see the identical image
     assert np.abs(outs[0]['own'] - want).max() > 1e-3 * np.abs(want).max()      # each rank really holds only a part
+
+
+@pytest.mark.parametrize("world,n_rays", [(3, 61), (4, 62)])
+def test_sharded_step_with_ray_counts_not_divisible_by_the_world_size(world, n_rays):
+    """world sizes 3 and 4, ray counts the world size does not divide (blocks of 21/20/20 and 16/16/15/15
+    rays): the shards tile the batch, sample exactly like the whole batch (batch-global depth maxima) and the one bucketed
+    all-reduce leaves every rank with the unsharded gradients."""
+    from oracle import render_oracle as R
+    from evennicer_slam_amd.parallel import shard_range
+    port = 33500 + (os.getpid() % 2000) + world
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_rays)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=600) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    params, grids, bound, s = tiny_scene()
+    params = {k: v.requires_grad_(True) for k, v in params.items()}
+    grids = {k: v.requires_grad_(True) for k, v in grids.items()}
+    ro, rd = torch.from_numpy(s['rays_o'])[:n_rays], torch.from_numpy(s['rays_d'])[:n_rays]
+    gd, gc = torch.from_numpy(s['gt_depth'])[:n_rays], torch.from_numpy(s['gt_color'])[:n_rays]
+    depth, var, color = R.render_batch_ray(params, grids, rd, ro, 'color', bound, gt_depth=gd)
+    R.mapper_loss(depth, color, gd, gc, 'color').backward()
+    assert [o['slice'] for o in outs] == [shard_range(n_rays, r, world) for r in range(world)]
+    sizes = [b - a for a, b in (o['slice'] for o in outs)]
+    assert sum(sizes) == n_rays and max(sizes) - min(sizes) == 1
+    # (torch's CPU matmul blocks 21- and 61-row batches differently: equal to float32 rounding, not bit for bit)
+    assert np.allclose(np.concatenate([o['depth'] for o in outs]), depth.detach().numpy(), rtol=1e-5, atol=1e-7)
+    for o in outs:
+        ref = grids['grid_fine'].grad.numpy()
+        assert np.abs(o['g_fine'] - ref).max() <= 1e-5 * np.abs(ref).max()
+        ref = params['color_decoder.pts_linears.0.weight'].grad.numpy()
+        assert np.abs(o['g_w'] - ref).max() <= 1e-5 * np.abs(ref).max()
+        assert np.array_equal(o['g_fine'], outs[0]['g_fine'])          # replicas hold identical sums
