@@ -54,6 +54,7 @@ SCENES = {      # mapping.bound of the reference configs (configs/Replica/room0.
 }
 CAM = dict(H=680, W=1200, fx=600.0, fy=600.0, cx=599.5, cy=339.5)       # configs/Replica/replica.yaml:37-43
 CAM_RPG = dict(H=260, W=346, fx=196.71854278974607, fy=196.68898128242577, cx=172.5, cy=129.5)     # configs/rpg/rpg.yaml:62-68
+BUCKET_BLOCK = int(os.environ.get('ENSLAM_BUCKET_BLOCK', '16'))      # voxels per block of the gradient bucket (N > 1)
 GRID_LEN = {'coarse': 2, 'middle': 0.32, 'fine': 0.16, 'color': 0.16, 'bound_divisible': 0.32}
 
 # measurement configurations of BASELINE.json / SURVEY.md 8(d): scene, rays, how the rays relate to the GPU count
@@ -379,7 +380,8 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
         if whole_batch:
             torch.amax(gd_all, dim=0, keepdim=True, out=dmax_static[0:1])
             torch.mul(dmax_static[0:1], 1.2, out=dmax_static[1:2])
-            prep['flags'] = PAR.batch_block_flags(renderer, grids, model, ro_all, rd_all, gd_all, stage, out=prep['flags'])
+            prep['flags'] = PAR.batch_block_flags(renderer, grids, model, ro_all, rd_all, gd_all, stage, out=prep['flags'],
+                                                  block_voxels=BUCKET_BLOCK)
             prep['prepared'] = PAR.PreparedFlags([prep['flags'][id(t)] for t in leaves if t.dim() == 5])
         elif dmax_static is not None:       # batch-global sampler maxima over all shards (tiny MAX all-reduce)
             PAR.global_depth_max(gd, force=force_comm, out=dmax_static)
@@ -585,7 +587,8 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
         out["fit"] = fit
     if comm_on:
         out["comm"] = dict(comm_ms, bucket_bytes=int(comm['bytes']), mode=mode,
-                           flags="marked locally from the whole batch" if whole_batch else "MAX all-reduce of per-rank flags")
+                           flags="marked locally from the whole batch" if whole_batch else "MAX all-reduce of per-rank flags",
+                           bucket_block_voxels=BUCKET_BLOCK if whole_batch else 64)
     if events:
         dur = np.array([a.elapsed_time(b) for a, b in events]) * 1e-3          # seconds
         avg = float(dur.mean())

@@ -69,6 +69,12 @@ _SIGS = {
                                           c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64), c_int64, c_void_p, c_void_p]),
     "enslam_bucket_unpack": (ctypes.c_int, [c_int32, POINTER(c_void_p), c_int32, POINTER(c_int64), POINTER(c_int32), c_void_p,
                                             c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64), c_int64, c_void_p, c_void_p]),
+    "enslam_mark_blocks_g": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
+                                            POINTER(c_void_p), c_int32, c_void_p]),
+    "enslam_bucket_pack_g": (ctypes.c_int, [c_int32, POINTER(c_void_p), c_int32, POINTER(c_int64), POINTER(c_int32), c_void_p,
+                                            c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64), c_int64, c_void_p, c_int32, c_void_p]),
+    "enslam_bucket_unpack_g": (ctypes.c_int, [c_int32, POINTER(c_void_p), c_int32, POINTER(c_int64), POINTER(c_int32), c_void_p,
+                                              c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64), c_int64, c_void_p, c_int32, c_void_p]),
     "enslam_step_prepare": (ctypes.c_int, [c_int32, POINTER(c_int32), POINTER(MlpParams), POINTER(c_void_p),
                                            c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),
                                            POINTER(c_void_p), c_int32, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),

@@ -486,8 +486,11 @@ int enslam_adam_tensors(int32_t n, float* const* param, const float* const* grad
 
 static int bucket_job(int32_t n_grids, float* const* grid_grad, int32_t channels, const int64_t* n_voxels,
                       const int32_t* layout, const uint8_t* flags, const int32_t* pos, int32_t n_small,
-                      float* const* small, const int64_t* small_numel, int64_t small_base, float* bucket, BucketJob& job) {
+                      float* const* small, const int64_t* small_numel, int64_t small_base, float* bucket, BucketJob& job,
+                      int block_voxels = 64) {
     if (n_grids < 0 || n_grids > 4 || n_small < 0 || n_small > ENS_ADAM_MAX_TENSORS) return ENSLAM_EUNSUPPORTED;
+    if (block_voxels != 64 && block_voxels != 32 && block_voxels != 16 && block_voxels != 8) return ENSLAM_EINVAL;
+    job.bs = block_voxels;
     if (!bucket || channels < 1 || small_base < 0) return ENSLAM_EINVAL;
     if (n_grids > 0 && (!grid_grad || !n_voxels || !layout || !flags || !pos)) return ENSLAM_EINVAL;
     if (n_small > 0 && (!small || !small_numel)) return ENSLAM_EINVAL;
@@ -498,7 +501,7 @@ static int bucket_job(int32_t n_grids, float* const* grid_grad, int32_t channels
         if (!grid_grad[g] || n_voxels[g] < 0 || (layout[g] != 0 && layout[g] != 1)) return ENSLAM_EINVAL;
         job.grid[g] = grid_grad[g]; job.V[g] = n_voxels[g]; job.layout[g] = layout[g];
         job.blk_begin[g] = (int)blocks;
-        blocks += (n_voxels[g] + 63) / 64;
+        blocks += (n_voxels[g] + block_voxels - 1) / block_voxels;
         if (blocks > 0x3fffffff) return ENSLAM_EUNSUPPORTED;
     }
     for (int g = n_grids; g <= 4; ++g) job.blk_begin[g] = (int)blocks;
@@ -537,11 +540,37 @@ int enslam_bucket_unpack(int32_t n_grids, float* const* grid_grad, int32_t chann
 
 int enslam_mark_blocks(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                        const double* z_vals, const enslam_scene* scene, uint8_t* const* flags, void* stream) {
+    return enslam_mark_blocks_g(stage, n_rays, n_samples, rays_o, rays_d, z_vals, scene, flags, 64, stream);
+}
+int enslam_mark_blocks_g(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                         const double* z_vals, const enslam_scene* scene, uint8_t* const* flags, int32_t block_voxels,
+                         void* stream) {
     if (n_rays < 0 || n_samples < 1 || stage < 0 || stage > 3) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     DevScene d;
     if (!to_dev_scene(scene, d) || !rays_o || !rays_d || !z_vals || !flags) return ENSLAM_EINVAL;
-    return ens_launch_mark_blocks(stage, n_rays, n_samples, rays_o, rays_d, z_vals, d, flags, (hipStream_t)stream);
+    const int rc = ens_launch_mark_blocks(stage, n_rays, n_samples, rays_o, rays_d, z_vals, d, flags, (hipStream_t)stream, block_voxels);
+    return rc == 0 ? ENSLAM_OK : (rc == -1 ? ENSLAM_EINVAL : ENSLAM_ELAUNCH);
+}
+int enslam_bucket_pack_g(int32_t n_grids, const float* const* grid_grad, int32_t channels, const int64_t* n_voxels,
+                         const int32_t* layout, const uint8_t* flags, const int32_t* pos, int32_t n_small,
+                         const float* const* small, const int64_t* small_numel, int64_t small_base, float* bucket,
+                         int32_t block_voxels, void* stream) {
+    BucketJob job;
+    const int rc = bucket_job(n_grids, const_cast<float* const*>(grid_grad), channels, n_voxels, layout, flags, pos, n_small,
+                              const_cast<float* const*>(small), small_numel, small_base, bucket, job, block_voxels);
+    if (rc != ENSLAM_OK) return rc;
+    return ens_launch_bucket(job, false, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+int enslam_bucket_unpack_g(int32_t n_grids, float* const* grid_grad, int32_t channels, const int64_t* n_voxels,
+                           const int32_t* layout, const uint8_t* flags, const int32_t* pos, int32_t n_small,
+                           float* const* small, const int64_t* small_numel, int64_t small_base, const float* bucket,
+                           int32_t block_voxels, void* stream) {
+    BucketJob job;
+    const int rc = bucket_job(n_grids, grid_grad, channels, n_voxels, layout, flags, pos, n_small, small, small_numel,
+                              small_base, const_cast<float*>(bucket), job, block_voxels);
+    if (rc != ENSLAM_OK) return rc;
+    return ens_launch_bucket(job, true, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
 
 int enslam_grid_to_voxel_major(const float* src, float* dst, int64_t n_voxels, void* stream) {

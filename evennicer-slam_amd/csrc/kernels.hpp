@@ -73,6 +73,7 @@ struct BucketJob {
     int layout[4];
     int blk_begin[5];            // block range of each grid inside flags / pos (ceil(V / 64) blocks per grid)
     int n_grids, C;
+    int bs;                      // voxels per block (64, 32, 16 or 8): granularity of flags / pos / bucket slots
     const uint8_t* flags;        // [blk_begin[n_grids]] union over ranks of the touched blocks
     const int* pos;              // inclusive prefix sum of flags: a flagged block b owns bucket slot pos[b] - 1 (C * 64 floats)
     float* small[ENS_ADAM_MAX_TENSORS];
@@ -113,7 +114,7 @@ int ens_launch_adam(const AdamJob& job, hipStream_t st);
 int ens_launch_adam_tensors(const AdamTensorsJob& job, hipStream_t st);
 int ens_launch_zero_blocks(const ConvJob& job, float* flat, int64_t n_flat, hipStream_t st);
 int ens_launch_mark_blocks(int stage, int n_rays, int S, const float* ro, const float* rd, const double* z,
-                           const DevScene& sc, uint8_t* const* flags, hipStream_t st);
+                           const DevScene& sc, uint8_t* const* flags, hipStream_t st, int block_voxels = 64);
 struct MarkArgs {                // optional block marking inside the sampler (mark_blocks_kernel's work, one launch less)
     DevScene sc;                 // bounds and grid dims (data pointers unused)
     int kmask;                   // grids to mark (bit k)

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void adam_tensors_kernel(AdamTensorsJob job) {
 __global__ __launch_bounds__(256) void mark_blocks_kernel(int64_t n_samples_total, int S, const float* __restrict__ ro,
                                                           const float* __restrict__ rd, const double* __restrict__ z,
                                                           DevScene sc, int kmask, uint8_t* f0, uint8_t* f1, uint8_t* f2,
-                                                          uint8_t* f3) {
+                                                          uint8_t* f3, int shift) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_samples_total) return;
     const int64_t ray = i / S;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void mark_blocks_kernel(int64_t n_samples_tota
         for (int c = 0; c < 8; ++c) {
             int64_t idx; float w;
             corner(v, sc.grid[k], c, idx, w);
-            fl[k][idx >> 6] = 1;
+            fl[k][idx >> shift] = 1;
         }
     }
 }
@@ -755,25 +755,26 @@ template <bool UNPACK>
 __global__ __launch_bounds__(256) void bucket_kernel(BucketJob job) {
     const int nb = job.blk_begin[job.n_grids];
     const int b = (int)blockIdx.x;
+    const int BS = job.bs;                                   // voxels per block: 64 (the renderer's flags) or 32 / 16 / 8
     if (b < nb) {
         if (!job.flags[b]) return;
         int g = 0;
 #pragma unroll
         for (int k = 1; k < 4; ++k) if (k < job.n_grids && b >= job.blk_begin[k]) g = k;
         const int C = job.C;
-        const int64_t V = job.V[g], v0 = (int64_t)(b - job.blk_begin[g]) * 64;
+        const int64_t V = job.V[g], v0 = (int64_t)(b - job.blk_begin[g]) * BS;
         float* __restrict__ G = job.grid[g];
-        float* __restrict__ S = job.bucket + (int64_t)(job.pos[b] - 1) * C * 64;
+        float* __restrict__ S = job.bucket + (int64_t)(job.pos[b] - 1) * C * BS;
         if (job.layout[g] == 0) {
-            const int v = threadIdx.x & 63;
+            const int v = threadIdx.x % BS, cstep = 256 / BS;
             const bool in = v0 + v < V;
-            for (int c = threadIdx.x >> 6; c < C; c += 4) {
-                if (UNPACK) { if (in) G[(int64_t)c * V + v0 + v] = S[c * 64 + v]; }
-                else S[c * 64 + v] = in ? G[(int64_t)c * V + v0 + v] : 0.f;
+            for (int c = threadIdx.x / BS; c < C; c += cstep) {
+                if (UNPACK) { if (in) G[(int64_t)c * V + v0 + v] = S[c * BS + v]; }
+                else S[c * BS + v] = in ? G[(int64_t)c * V + v0 + v] : 0.f;
             }
         } else {
-            const int64_t n_in = (V - v0 < 64 ? V - v0 : 64) * C;
-            for (int e = threadIdx.x; e < C * 64; e += 256) {
+            const int64_t n_in = (V - v0 < BS ? V - v0 : BS) * C;
+            for (int e = threadIdx.x; e < C * BS; e += 256) {
                 if (UNPACK) { if (e < n_in) G[v0 * C + e] = S[e]; }
                 else S[e] = e < n_in ? G[v0 * C + e] : 0.f;
             }
@@ -810,12 +811,14 @@ int ens_launch_adam_tensors(const AdamTensorsJob& job, hipStream_t st) {
 }
 
 int ens_launch_mark_blocks(int stage, int n_rays, int S, const float* ro, const float* rd, const double* z,
-                           const DevScene& sc, uint8_t* const* flags, hipStream_t st) {
+                           const DevScene& sc, uint8_t* const* flags, hipStream_t st, int block_voxels) {
+    int shift = 6;
+    switch (block_voxels) { case 64: shift = 6; break; case 32: shift = 5; break; case 16: shift = 4; break; case 8: shift = 3; break; default: return -1; }
     const int64_t n = (int64_t)n_rays * S;
     if (n <= 0) return 0;
     const int kmask = stage == 0 ? 1 : (stage == 1 ? 2 : (stage == 2 ? 6 : 14));
     mark_blocks_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, S, ro, rd, z, sc, kmask, flags[0], flags[1],
-                                                                               flags[2], flags[3]);
+                                                                               flags[2], flags[3], shift);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -136,6 +136,7 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags, prepared=None):
     dev = (tensors[0].grad_vm if isinstance(tensors[0], VoxelMajorGrid) else tensors[0]).device
     grid_items, small = [], []              # (gradient, V, layout, flags) / dense gradients
     C = None
+    bs = None                               # voxels per flagged block (set by the first grid's flags)
     for t in tensors:
         if isinstance(t, VoxelMajorGrid):
             g, V, c, layout = t.grad_vm, t.grad_vm.shape[0], t.grad_vm.shape[1], 1
@@ -153,16 +154,20 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags, prepared=None):
             continue
         C = c
         f = block_flags.get(id(t)) if block_flags else None
-        nblk = (V + 63) // 64
-        if f is None or f.numel() != nblk:
+        # flags come at 64 voxels per block (the renderer's own) or finer (batch_block_flags(..., block_voxels=16)); every grid
+        # of one bucket must use the same granularity
+        fbs = next((b for b in (64, 32, 16, 8) if f is not None and f.numel() == (V + b - 1) // b), None)
+        if fbs is None or (bs is not None and fbs != bs):
+            fbs = bs or 64
             g2 = g.reshape(c, V) if layout == 0 else g
-            nfull = V // 64
+            nfull = V // fbs
             if layout == 0:
-                f = (g2[:, :nfull * 64].reshape(c, nfull, 64) != 0).any(dim=2).any(dim=0).to(torch.uint8)
+                f = (g2[:, :nfull * fbs].reshape(c, nfull, fbs) != 0).any(dim=2).any(dim=0).to(torch.uint8)
             else:
-                f = (g2[:nfull * 64].reshape(nfull, 64 * c) != 0).any(dim=1).to(torch.uint8)
-            if nblk > nfull:                # the partial last block always travels
+                f = (g2[:nfull * fbs].reshape(nfull, fbs * c) != 0).any(dim=1).to(torch.uint8)
+            if (V + fbs - 1) // fbs > nfull:                # the partial last block always travels
                 f = torch.cat([f, f.new_ones(1)])
+        bs = fbs
         grid_items.append((g, V, layout, f.reshape(-1)))
     for g in small:
         if g.dtype != torch.float32:
@@ -175,7 +180,8 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags, prepared=None):
         dist.all_reduce(allf, op=dist.ReduceOp.MAX, group=group)          # union of the touched blocks
         pos = torch.cumsum(allf, 0, dtype=torch.int32)
         n_slots = int(pos[-1].item())                                     # the one host read: the bucket size
-    slot = (C or 0) * 64
+    bs = bs or 64
+    slot = (C or 0) * bs
     n_small = sum(g.numel() for g in small)
     bucket = torch.empty(n_slots * slot + n_small, dtype=torch.float32, device=dev)
     ng = len(grid_items)
@@ -190,13 +196,13 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags, prepared=None):
             sp = (ctypes.c_void_p * max(len(part), 1))(*[g.data_ptr() for g in part])
             sn = (ctypes.c_int64 * max(len(part), 1))(*[g.numel() for g in part])
             L.check(fn(ng if first else 0, gp, C or 1, nv, lay, _ptr(allf), _ptr(pos), len(part), sp, sn, base, _ptr(bucket),
-                       _stream()), name)
+                       bs, _stream()), name)
             base += sum(g.numel() for g in part)
             first = False
 
-    run(lib.enslam_bucket_pack, "enslam_bucket_pack")
+    run(lib.enslam_bucket_pack_g, "enslam_bucket_pack")
     dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
-    run(lib.enslam_bucket_unpack, "enslam_bucket_unpack")
+    run(lib.enslam_bucket_unpack_g, "enslam_bucket_unpack")
     # The unpack has just written the UNION's blocks of every grid gradient.  Where that gradient is the persistent buffer of
     # a captured step (functional._persist_prev), the finish launch of the next replay only rewrites the blocks it knows of
     # -- this rank's, now and one replay earlier -- so the other ranks' blocks are added to its flags here; without this their
@@ -205,6 +211,10 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags, prepared=None):
         from .functional import note_foreign_blocks
         for (g, _V, layout, f), seg in zip(grid_items, allf.split([it[3].numel() for it in grid_items])):
             if layout == 0:
+                if bs != 64:                # the finish launch keeps its flags per 64 voxels: any finer block set -> its 64-block
+                    k = 64 // bs
+                    pad = (-seg.numel()) % k
+                    seg = (torch.cat([seg, seg.new_zeros(pad)]) if pad else seg).view(-1, k).amax(dim=1)
                 note_foreign_blocks(g, seg)
     return bucket.numel() * 4
 
@@ -236,10 +246,11 @@ class PreparedFlags:
         return int(self.count[0])
 
 
-def batch_block_flags(renderer, c, decoders, rays_o, rays_d, gt_depth, stage, out=None):
+def batch_block_flags(renderer, c, decoders, rays_o, rays_d, gt_depth, stage, out=None, block_voxels=64):
     """{id(grid tensor): uint8 flags} of the 64-voxel blocks the samples of a ray batch touch in the dense grids of
     `stage` -- the sampler's block marking on its own (one launch), for batches that are not rendered here: the other
-    ranks' blocks of a sharded batch.  The batch maxima of gt_depth are taken over the rays given, i.e. pass the whole
+    ranks' blocks of a sharded batch.  block_voxels 32 / 16 / 8: flags per that many voxels (a second launch marks them from
+    the sampled distances): the bucket of a step then carries 3.35 MB (16) instead of 6.52 MB (64) at room0 / 1000 rays.  The batch maxima of gt_depth are taken over the rays given, i.e. pass the whole
     batch.  Deterministic sampling only (perturb == 0).  out: flags dict of an earlier call to refill."""
     import ctypes
     from . import _lib as L
@@ -254,8 +265,9 @@ def batch_block_flags(renderer, c, decoders, rays_o, rays_d, gt_depth, stage, ou
     t_lin, t_surf = renderer._t_vals(dev, n_lin, renderer.N_surface)
     kinds = [k for k in EF.stage_kinds(stage) if not isinstance(c[L.GRID_NAMES[k]], EF.VoxelMajorGrid)]
     grids = {k: c[L.GRID_NAMES[k]] for k in kinds}
+    bv = int(block_voxels)
     if out is None:
-        out = {id(g): torch.empty((g.shape[2] * g.shape[3] * g.shape[4] + 63) // 64, dtype=torch.uint8, device=dev)
+        out = {id(g): torch.empty((g.shape[2] * g.shape[3] * g.shape[4] + bv - 1) // bv, dtype=torch.uint8, device=dev)
                for g in grids.values()}
     msc = L.Scene()
     msc.bound, msc.coarse_bound = EF.bound6(renderer.bound), EF.bound6(renderer._coarse_bound(decoders))
@@ -269,9 +281,13 @@ def batch_block_flags(renderer, c, decoders, rays_o, rays_d, gt_depth, stage, ou
     gd = gt_depth.detach().contiguous().float().reshape(-1) if guided else None
     z = torch.empty((N, n_lin + n_surf), dtype=torch.float64, device=dev)
     scratch = torch.empty(2, dtype=torch.float32, device=dev)
+    fine = bv != 64
     L.check(lib.enslam_sample_rays(N, n_lin, n_surf, EF._ptr(ro), EF._ptr(rd), EF._ptr(gd), msc.bound, EF._ptr(t_lin),
                                    EF._ptr(t_surf), int(bool(renderer.lindisp)), None, EF._ptr(scratch), 0, EF._ptr(z), L.STAGE[stage],
-                                   ctypes.byref(msc), fptr, EF._stream()), "enslam_sample_rays")
+                                   None if fine else ctypes.byref(msc), None if fine else fptr, EF._stream()), "enslam_sample_rays")
+    if fine:
+        L.check(lib.enslam_mark_blocks_g(L.STAGE[stage], N, n_lin + n_surf, EF._ptr(ro), EF._ptr(rd), EF._ptr(z), ctypes.byref(msc),
+                                         fptr, bv, EF._stream()), "enslam_mark_blocks_g")
     return out
 
 

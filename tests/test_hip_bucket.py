@@ -146,7 +146,7 @@ def test_two_rank_allreduce_of_hip_gradients():
         assert o['nbytes'] == 4 * (32 * 64 * (3 + 2) + 10)
 
 
-def _shard_worker(rank, world, port, q):
+def _shard_worker(rank, world, port, q, block_voxels=64):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
@@ -161,13 +161,17 @@ def _shard_worker(rank, world, port, q):
         ro, rd, gd, gc = rays['rays_o'], rays['rays_d'], rays['gt_depth'], rays['gt_color']
         leaves = [g[k] for k in ('grid_middle', 'grid_fine', 'grid_color')] + list(model.color_decoder.parameters())
         # every rank holds the whole batch: union of the touched blocks and the bucket layout before the local step
-        flags = PAR.batch_block_flags(renderer, g, model, ro, rd, gd, 'color')
+        flags = PAR.batch_block_flags(renderer, g, model, ro, rd, gd, 'color', block_voxels=block_voxels)
         prepared = PAR.PreparedFlags([flags[id(t)] for t in leaves if t.dim() == 5])
         sr = PAR.ShardedRenderer(renderer)
         (depth, var, color), sl = sr.render_batch_ray(g, model, rd, ro, DEV, 'color', gt_depth=gd)
         E.losses.rgbd_loss(depth, color, gd[sl], gc[sl], 0.2).backward()
         own_flags = E.functional.last_block_flags()
-        covered = all(bool((flags[id(t)] >= own_flags[id(t)]).all()) for t in leaves if t.dim() == 5)
+        def coarsen(f):                     # flags per block_voxels voxels -> per 64 voxels (the renderer's own granularity)
+            k = 64 // block_voxels
+            pad = (-f.numel()) % k
+            return (torch.cat([f, f.new_zeros(pad)]) if pad else f).view(-1, k).amax(dim=1)
+        covered = all(bool((coarsen(flags[id(t)]) >= own_flags[id(t)]).all()) for t in leaves if t.dim() == 5)
         nbytes = PAR.allreduce_gradients(leaves, block_flags=flags, prepared=prepared)
         torch.cuda.synchronize()
         q.put({'rank': rank, 'nbytes': nbytes, 'covered': covered, 'slice': (sl.start, sl.stop),
@@ -176,17 +180,18 @@ def _shard_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_sharded_step_with_local_union_flags_matches_unsharded():
+@pytest.mark.parametrize("block_voxels", [64, 16])
+def test_two_rank_sharded_step_with_local_union_flags_matches_unsharded(block_voxels):
     """Ray-sharded step on HIP tensors, 2 ranks: the union of touched blocks marked locally over the whole batch
-    (batch_block_flags), bucket layout prepared before the step (PreparedFlags), ONE collective -- the summed gradients
-    equal the unsharded step's."""
+    (batch_block_flags, at 64 or 16 voxels per block), bucket layout prepared before the step (PreparedFlags), ONE
+    collective -- the summed gradients equal the unsharded step's."""
     import torch.multiprocessing as mp
     import evennicer_slam_amd as E
     from tests.hip_util import DEV, tiny_on_gpu
     world, port = 2, 37500 + (os.getpid() % 2000)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port + block_voxels, q, block_voxels)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=600) for _ in range(world)], key=lambda o: o['rank'])
