@@ -100,6 +100,10 @@ _SIGS = {
     "enslam_sample_rays": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                           POINTER(c_double), c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                           c_int32, c_void_p, c_int32, POINTER(Scene), POINTER(c_void_p), c_void_p]),
+    "enslam_sample_rays_g": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                            POINTER(c_double), c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                            c_int32, c_void_p, c_int32, POINTER(Scene), POINTER(c_void_p), c_int32, POINTER(c_void_p),
+                                            c_void_p]),
     "enslam_render_fwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "enslam_activation_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),

@@ -586,7 +586,17 @@ int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const floa
                        const float* gt_depth, const double* bound_host, const float* t_lin, const double* t_surf,
                        int32_t lindisp, const float* t_rand, float* scratch, int32_t depth_max_given, double* z_vals,
                        int32_t mark_stage, const enslam_scene* mark_scene, uint8_t* const* mark_flags, void* stream) {
+    return enslam_sample_rays_g(n_rays, n_lin, n_surf, rays_o, rays_d, gt_depth, bound_host, t_lin, t_surf, lindisp, t_rand, scratch,
+                                depth_max_given, z_vals, mark_stage, mark_scene, mark_flags, 64, nullptr, stream);
+}
+int enslam_sample_rays_g(int32_t n_rays, int32_t n_lin, int32_t n_surf, const float* rays_o, const float* rays_d,
+                         const float* gt_depth, const double* bound_host, const float* t_lin, const double* t_surf,
+                         int32_t lindisp, const float* t_rand, float* scratch, int32_t depth_max_given, double* z_vals,
+                         int32_t mark_stage, const enslam_scene* mark_scene, uint8_t* const* mark_flags,
+                         int32_t mark_block_voxels, uint8_t* const* mark_flags64, void* stream) {
     if (n_rays < 0 || n_lin < 1 || n_surf < 0) return ENSLAM_EINVAL;
+    int shift = 6;
+    switch (mark_block_voxels) { case 64: shift = 6; break; case 32: shift = 5; break; case 16: shift = 4; break; case 8: shift = 3; break; default: return ENSLAM_EINVAL; }
     if (n_rays == 0) return ENSLAM_OK;
     if (!rays_o || !rays_d || !bound_host || !t_lin || !z_vals) return ENSLAM_EINVAL;
     if (gt_depth != nullptr && (scratch == nullptr || (n_surf > 0 && t_surf == nullptr))) return ENSLAM_EINVAL;
@@ -595,7 +605,8 @@ int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const floa
     if (marking) {
         if (mark_stage < 0 || mark_stage > 3 || !to_dev_scene(mark_scene, mk.sc)) return ENSLAM_EINVAL;
         mk.kmask = mark_stage == 0 ? 1 : (mark_stage == 1 ? 2 : (mark_stage == 2 ? 6 : 14));
-        for (int k = 0; k < 4; ++k) mk.flags[k] = mark_flags[k];
+        for (int k = 0; k < 4; ++k) { mk.flags[k] = mark_flags[k]; mk.flags64[k] = (mark_flags64 != nullptr && shift < 6) ? mark_flags64[k] : nullptr; }
+        mk.shift = shift;
     }
     return ens_launch_sample(n_rays, n_lin, n_surf, rays_o, rays_d, gt_depth, bound_host, t_lin, t_surf, lindisp,
                              t_rand, scratch, depth_max_given, z_vals, marking ? &mk : nullptr, (hipStream_t)stream);

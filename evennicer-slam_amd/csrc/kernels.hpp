@@ -119,6 +119,8 @@ struct MarkArgs {                // optional block marking inside the sampler (m
     DevScene sc;                 // bounds and grid dims (data pointers unused)
     int kmask;                   // grids to mark (bit k)
     uint8_t* flags[4];
+    int shift;                   // log2(voxels per flag): 6 (the renderer's own 64-voxel blocks) .. 3
+    uint8_t* flags64[4];         // optional (shift < 6): the same marks at 64 voxels per flag as well
 };
 int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
                       const double* bound, const float* t_lin, const double* t_surf, int lindisp,

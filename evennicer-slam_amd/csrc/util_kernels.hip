@@ -142,8 +142,14 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
                     const int y = min(iy + (c & 1), g.H - 1), zc = min(iz + (c >> 1), g.D - 1);
                     const int64_t idx = ((int64_t)zc * g.H + y) * g.W + ix;
                     uint8_t* f = mk.flags[k];
-                    f[idx >> 6] = 1;
-                    if (((idx + dx) >> 6) != (idx >> 6)) f[(idx + dx) >> 6] = 1;
+                    const int sh = mk.shift;
+                    f[idx >> sh] = 1;
+                    if (((idx + dx) >> sh) != (idx >> sh)) f[(idx + dx) >> sh] = 1;
+                    if (mk.flags64[k] != nullptr) {              // (finer flags for the gradient bucket: the 64-voxel form too)
+                        uint8_t* f6 = mk.flags64[k];
+                        f6[idx >> 6] = 1;
+                        if (((idx + dx) >> 6) != (idx >> 6)) f6[(idx + dx) >> 6] = 1;
+                    }
                 }
             }
         }
@@ -829,7 +835,7 @@ int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const 
     if (n_lin + n_surf > MAX_S || n_lin < 1) return -1;
     const int dmax_inline = (gd != nullptr && !dmax_given && n_rays <= 4096) ? 1 : 0;
     MarkArgs mk;
-    if (mark != nullptr) mk = *mark; else { mk.kmask = 0; for (int k = 0; k < 4; ++k) mk.flags[k] = nullptr; }
+    if (mark != nullptr) mk = *mark; else { mk.kmask = 0; mk.shift = 6; for (int k = 0; k < 4; ++k) { mk.flags[k] = nullptr; mk.flags64[k] = nullptr; } }
     if (gd != nullptr && !dmax_given && !dmax_inline) depth_max_kernel<<<1, 1024, 0, st>>>(n_rays, gd, scratch);
     sample_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(n_rays, n_lin, gd ? n_surf : 0, ro, rd, gd, b[0], b[1],
                                                                  b[2], b[3], b[4], b[5], t_lin, t_surf, lindisp,

@@ -209,14 +209,33 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags, prepared=None):
     # sums stay in the buffer and are sent (and grow) again every step.
     if grid_items:
         from .functional import note_foreign_blocks
-        for (g, _V, layout, f), seg in zip(grid_items, allf.split([it[3].numel() for it in grid_items])):
+        for gi, ((g, _V, layout, f), seg) in enumerate(zip(grid_items, allf.split([it[3].numel() for it in grid_items]))):
             if layout == 0:
                 if bs != 64:                # the finish launch keeps its flags per 64 voxels: any finer block set -> its 64-block
-                    k = 64 // bs
-                    pad = (-seg.numel()) % k
-                    seg = (torch.cat([seg, seg.new_zeros(pad)]) if pad else seg).view(-1, k).amax(dim=1)
+                    pre_c = getattr(prepared, 'coarse', None) if (prepared is not None and allf is prepared.allf) else None
+                    seg = pre_c[gi] if pre_c is not None else _coarsen(seg, 64 // bs)
                 note_foreign_blocks(g, seg)
     return bucket.numel() * 4
+
+
+def _coarsen(f, k):
+    """uint8 flags per b voxels -> per k*b voxels (any fine block set -> its coarse block)."""
+    pad = (-f.numel()) % k
+    return (torch.cat([f, f.new_zeros(pad)]) if pad else f).view(-1, k).amax(dim=1)
+
+
+_PINNED = {'buf': None, 'next': 0}
+
+
+def _pinned_slot():
+    """One int32 of page-locked host memory from a small ring allocated once: a fresh `torch.empty(..., pin_memory=True)` per
+    step goes through hipHostMalloc / hipHostFree, which wait for the device -- the host then cannot run ahead of the GPU
+    and a 0.5 ms step became 1.5 ms (1-rank RCCL rehearsal, round 3)."""
+    if _PINNED['buf'] is None:
+        _PINNED['buf'] = torch.empty(64, dtype=torch.int32, pin_memory=True)
+    i = _PINNED['next']
+    _PINNED['next'] = (i + 1) % 64
+    return _PINNED['buf'][i:i + 1]
 
 
 class PreparedFlags:
@@ -227,13 +246,19 @@ class PreparedFlags:
     collective nor a host wait (the read finished while the step was running).
 
     flag_list: the uint8 flag tensors of the grids, in the order the grids appear in the tensors later handed to
-    allreduce_gradients (the same objects as in its block_flags dict)."""
+    allreduce_gradients (the same objects as in its block_flags dict).  coarse: their 64-voxel forms when the flags are finer
+    (batch_block_flags leaves them under the keys ('c64', id(grid)); derived here when absent)."""
 
-    def __init__(self, flag_list):
+    def __init__(self, flag_list, block_voxels=64, coarse=None):
         self.ids = [(f.data_ptr(), f.numel()) for f in flag_list]
         self.allf = torch.cat([f.reshape(-1) for f in flag_list]) if len(flag_list) > 1 else flag_list[0].reshape(-1).clone()
+        # flags finer than the finish launch's 64 voxels per block: their 64-voxel form (what allreduce_gradients reports to the
+        # persistent gradient buffers of a captured step) is made here, before the local step, not behind the collective
+        self.coarse = None
+        if block_voxels != 64:
+            self.coarse = list(coarse) if coarse is not None else [_coarsen(f.reshape(-1), 64 // block_voxels) for f in flag_list]
         self.pos = torch.cumsum(self.allf, 0, dtype=torch.int32)
-        self.count = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self.count = _pinned_slot()
         self.count.copy_(self.pos[-1:], non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
@@ -266,28 +291,44 @@ def batch_block_flags(renderer, c, decoders, rays_o, rays_d, gt_depth, stage, ou
     kinds = [k for k in EF.stage_kinds(stage) if not isinstance(c[L.GRID_NAMES[k]], EF.VoxelMajorGrid)]
     grids = {k: c[L.GRID_NAMES[k]] for k in kinds}
     bv = int(block_voxels)
-    if out is None:
-        out = {id(g): torch.empty((g.shape[2] * g.shape[3] * g.shape[4] + bv - 1) // bv, dtype=torch.uint8, device=dev)
-               for g in grids.values()}
+    if out is None:                 # every flag array of the call (fine and, when finer than 64, the 64-voxel form) in ONE buffer:
+        sizes, keys = [], []        # one clearing launch per call instead of one per array
+        for g in grids.values():
+            V = g.shape[2] * g.shape[3] * g.shape[4]
+            sizes.append((V + bv - 1) // bv)
+            keys.append(id(g))
+            if bv != 64:
+                sizes.append((V + 63) // 64)
+                keys.append(('c64', id(g)))
+        flat = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+        out = dict(zip(keys, flat.split(sizes)))
+        out['_flat'] = flat
+    if '_flat' in out:
+        out['_flat'].zero_()
+    else:
+        for k_, f_ in out.items():
+            f_.zero_()
     msc = L.Scene()
     msc.bound, msc.coarse_bound = EF.bound6(renderer.bound), EF.bound6(renderer._coarse_bound(decoders))
     fptr = (ctypes.c_void_p * 4)()
     for k, g in grids.items():
-        f = out[id(g)]
-        f.zero_()
         msc.grids[k].D, msc.grids[k].H, msc.grids[k].W = (int(x) for x in g.shape[2:])
-        fptr[k] = f.data_ptr()
+        fptr[k] = out[id(g)].data_ptr()
     ro, rd = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
     gd = gt_depth.detach().contiguous().float().reshape(-1) if guided else None
     z = torch.empty((N, n_lin + n_surf), dtype=torch.float64, device=dev)
     scratch = torch.empty(2, dtype=torch.float32, device=dev)
-    fine = bv != 64
-    L.check(lib.enslam_sample_rays(N, n_lin, n_surf, EF._ptr(ro), EF._ptr(rd), EF._ptr(gd), msc.bound, EF._ptr(t_lin),
-                                   EF._ptr(t_surf), int(bool(renderer.lindisp)), None, EF._ptr(scratch), 0, EF._ptr(z), L.STAGE[stage],
-                                   None if fine else ctypes.byref(msc), None if fine else fptr, EF._stream()), "enslam_sample_rays")
-    if fine:
-        L.check(lib.enslam_mark_blocks_g(L.STAGE[stage], N, n_lin + n_surf, EF._ptr(ro), EF._ptr(rd), EF._ptr(z), ctypes.byref(msc),
-                                         fptr, bv, EF._stream()), "enslam_mark_blocks_g")
+    fptr64 = None
+    if bv != 64:                    # the 64-voxel form of the same marks (what the finish launch keeps), from the same launch
+        fptr64 = (ctypes.c_void_p * 4)()
+        for k, g in grids.items():
+            key = ('c64', id(g))
+            if key not in out:
+                out[key] = torch.zeros((g.shape[2] * g.shape[3] * g.shape[4] + 63) // 64, dtype=torch.uint8, device=dev)
+            fptr64[k] = out[key].data_ptr()
+    L.check(lib.enslam_sample_rays_g(N, n_lin, n_surf, EF._ptr(ro), EF._ptr(rd), EF._ptr(gd), msc.bound, EF._ptr(t_lin),
+                                     EF._ptr(t_surf), int(bool(renderer.lindisp)), None, EF._ptr(scratch), 0, EF._ptr(z), L.STAGE[stage],
+                                     ctypes.byref(msc), fptr, bv, fptr64, EF._stream()), "enslam_sample_rays")
     return out
 
 

@@ -269,6 +269,14 @@ int enslam_sample_rays(int32_t n_rays, int32_t n_lin, int32_t n_surf, const floa
                        const float *gt_depth, const double *bound_host, const float *t_lin, const double *t_surf,
                        int32_t lindisp, const float *t_rand, float *scratch, int32_t depth_max_given, double *z_vals,
                        int32_t mark_stage, const enslam_scene *mark_scene, uint8_t *const *mark_flags, void *stream);
+/* enslam_sample_rays whose block marking works at mark_block_voxels in {64, 32, 16, 8} voxels per flag (mark_flags sized
+ * accordingly) and, for the finer ones, optionally leaves the 64-voxel form in mark_flags64 as well (NULL: not wanted): the flags
+ * of a ray-sharded step's gradient bucket (enslam_bucket_pack_g) and what the finish launch keeps, from ONE launch. */
+int enslam_sample_rays_g(int32_t n_rays, int32_t n_lin, int32_t n_surf, const float *rays_o, const float *rays_d,
+                         const float *gt_depth, const double *bound, const float *t_lin, const double *t_surf,
+                         int32_t lindisp, const float *t_rand, float *scratch, int32_t depth_max_given, double *z_vals,
+                         int32_t mark_stage, const enslam_scene *mark_scene, uint8_t *const *mark_flags,
+                         int32_t mark_block_voxels, uint8_t *const *mark_flags64, void *stream);
 
 /* Forward of Renderer.render_batch_ray lines 173-181 + eval_points (Renderer.py:24-62) +
  * NICE.forward (decoder.py:312-342) + raw2outputs_nerf_color (common.py:256-297, occupancy):

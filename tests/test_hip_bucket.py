@@ -162,7 +162,7 @@ def _shard_worker(rank, world, port, q, block_voxels=64):
         leaves = [g[k] for k in ('grid_middle', 'grid_fine', 'grid_color')] + list(model.color_decoder.parameters())
         # every rank holds the whole batch: union of the touched blocks and the bucket layout before the local step
         flags = PAR.batch_block_flags(renderer, g, model, ro, rd, gd, 'color', block_voxels=block_voxels)
-        prepared = PAR.PreparedFlags([flags[id(t)] for t in leaves if t.dim() == 5])
+        prepared = PAR.PreparedFlags([flags[id(t)] for t in leaves if t.dim() == 5], block_voxels=block_voxels)
         sr = PAR.ShardedRenderer(renderer)
         (depth, var, color), sl = sr.render_batch_ray(g, model, rd, ro, DEV, 'color', gt_depth=gd)
         E.losses.rgbd_loss(depth, color, gd[sl], gc[sl], 0.2).backward()
