@@ -450,8 +450,8 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
         burst(n_ev)
         events = renderer.state.profile.pop('decoder_bwd', None)
         active = renderer.state.last_active_tile_fraction()
-        if EF.USE_WORK_LIST and stage != 'coarse':
-            EF.USE_WORK_LIST = False
+        if renderer.state.use_work_list and stage != 'coarse':
+            renderer.state.use_work_list = False
             try:
                 for _ in range(3):
                     step()
@@ -459,7 +459,7 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
                 burst(n_ev)
                 events_dense = renderer.state.profile.pop('decoder_bwd', None)
             finally:
-                EF.USE_WORK_LIST = True
+                renderer.state.use_work_list = True
             for _ in range(3):
                 step()
             torch.cuda.synchronize()

@@ -77,7 +77,12 @@ def _tag_visible(tag):
 
 
 def begin_capture():
-    """Called by graph.GraphedStep right before it starts recording: new capture id, fresh log of raw writes."""
+    """Called by graph.GraphedStep right before it starts recording: new capture id, fresh log of raw writes.
+    One capture at a time per process: the bookkeeping is process-wide (hipGraph capture itself is per stream, but the caches
+    tagged here are shared), so a second capture started before the first has ended is refused instead of mixing their logs."""
+    if _capture['active']:
+        raise L.EnslamError("a hipGraph capture of this library is already being recorded in this process (captures do not nest "
+                            "and cannot run on two threads at once)")
     _capture['epoch'] += 1
     _capture['active'] = _capture['epoch']
     _capture['raw_writes'] = []
@@ -598,18 +603,25 @@ def stage_kinds(stage):
 # ------------------------------------------------------------------------------------------------
 # the differentiable render call
 # ------------------------------------------------------------------------------------------------
+USE_WORK_LIST = os.environ.get('ENSLAM_WORK_LIST', '1') == '1'     # process-wide default of RenderState.use_work_list
+
+
 class RenderState:
     """What a render call leaves behind for its caller, per Renderer (two renderers -- a tracker's and a mapper's in one
     process, possibly on different streams -- do not see each other's):
       flags    {id(grid tensor): uint8 flags} of the 64-voxel blocks the latest call touched (parallel.allreduce_gradients
                sends only those); under hipGraph replay the buffers are rewritten in place by every replay
       work     (counter tensor, number of tiles) of the latest call's backward work list
-      profile  {'decoder_bwd': [(event, event), ...]} when a caller (bench.py) asks for per-kernel timing"""
+      profile  {'decoder_bwd': [(event, event), ...]} when a caller (bench.py) asks for per-kernel timing
+      use_work_list  whether this renderer's backwards walk the work list of active tiles (default) or every tile"""
 
     def __init__(self):
         self.flags = {}
         self.work = (None, 0)
         self.profile = {}
+        # the backward walks only the 16-sample tiles whose d_raw is not all zero (per renderer; ENSLAM_WORK_LIST=0 sets the
+        # process-wide default to every tile -- a diagnostic: the results are the same)
+        self.use_work_list = USE_WORK_LIST
 
     def last_block_flags(self):
         return dict(self.flags)
@@ -853,7 +865,7 @@ class _RenderFn(torch.autograd.Function):
         # work list of the backward (tiles with non-zero d_raw): filled by whichever kernel produces d_raw; the counter
         # comes zeroed out of this call's arena
         work = wcount = None
-        if act is not None and USE_WORK_LIST and any(ctx.needs_input_grad) and SV is None:
+        if act is not None and state.use_work_list and any(ctx.needs_input_grad) and SV is None:
             work = torch.empty(N * (S // 16), dtype=torch.int32, device=dev)
             wcount = accum.counter() if accum is not None else arena.take(1, torch.int32)    # (cleared by the prepare launch)
         if plan.loss is None:
@@ -1098,7 +1110,6 @@ INLINE_RAY_GRAD = {'1': True, '0': False}.get(os.environ.get('ENSLAM_INLINE_RAY_
 # weight gradients as per-workgroup partial images summed by the finish launch instead of float atomics at the backward's tail:
 # backward 138 -> 132 us, finish launch 22 -> 28 us (17.6 MB more to read), step unchanged -- off by default (round 3)
 USE_DW_PARTIALS = os.environ.get('ENSLAM_DW_PARTIALS', '0') == '1'
-USE_WORK_LIST = os.environ.get('ENSLAM_WORK_LIST', '1') == '1'     # backward walks only the tiles with non-zero d_raw
 
 
 def last_active_tile_fraction():

@@ -142,8 +142,8 @@ def test_bench_step_against_reference(scene, work_list):
     leaves = list(cg.values()) + [ro, rd] + list(model.parameters())
     out = {}
     one = {}
-    prev = EF.USE_WORK_LIST
-    EF.USE_WORK_LIST = work_list
+    prev = renderer.state.use_work_list
+    renderer.state.use_work_list = work_list
     try:
         def step():
             EF.clear_caches()
@@ -168,7 +168,7 @@ def test_bench_step_against_reference(scene, work_list):
         _check_outputs(g, depth, var, color, loss.item())
         _check_grads(g, model, cg, ro, rd)
     finally:
-        EF.USE_WORK_LIST = prev
+        renderer.state.use_work_list = prev
         del gs
         gc.collect()
 

@@ -24,7 +24,7 @@ def run(tag):
     torch.cuda.synchronize()
     ev = renderer.state.profile.pop('decoder_bwd')
     t = np.array([a.elapsed_time(b) for a, b in ev][5:]) * 1e3
-    print(f"work list {'on' if EF.USE_WORK_LIST else 'off'}; {tag}: decoder backward {t.mean():.1f} us (min {t.min():.1f}), loss {loss.item():.1f}, "
+    print(f"work list {'on' if renderer.state.use_work_list else 'off'}; {tag}: decoder backward {t.mean():.1f} us (min {t.min():.1f}), loss {loss.item():.1f}, "
           f"|grad fine| {float(grids['grid_fine'].grad.abs().sum()):.6e}")
 run("bench scene (every tile carries gradient)")
 with torch.no_grad():

@@ -7,7 +7,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}; O="$R/gpurun_out/prof_round"; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-secondary --no-cpu-baseline --no-kernel-events"
+ARGS="--no-secondary --no-cpu-baseline --no-kernel-events --no-api"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/graph -o g -- python3 $R/bench.py --steps 100 --warmup 10 $ARGS > $O/graph.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/eager -o e -- python3 $R/bench.py --steps 50 --warmup 10 --eager $ARGS > $O/eager.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
