@@ -344,6 +344,20 @@ ENS_DEV void ens_sincosf(float x, float& s, float& c) {
 }
 // sin alone: the same reduction and the same two polynomials, but only the one the quadrant selects is evaluated
 // (coefficients chosen by n & 1) -- bit-identical to the s of ens_sincosf.
+#ifdef ENS_HW_SINCOS
+// A/B aid (round 3): the hardware's v_sin_f32 / v_cos_f32 (argument in revolutions) behind a Cody-Waite reduction by 2*pi
+// (6.28125 has 8 significant bits: k * 6.28125 is exact for |k| < 2^16).  7 vector instructions instead of ~20, but 3.9e-7 / 3.5e-7
+// maximum absolute error for |x| <= 4000 against 9e-8 of the polynomial form (build/exp/vsin_test.hip, measured on gfx950).
+ENS_DEV float ens_red_rev(float x) {
+    const float k = rintf(x * 0.15915494309189535f);
+    float r = fmaf(-k, 6.28125f, x);
+    r = fmaf(-k, 1.9350051879882812e-3f, r);
+    r = fmaf(-k, 3.0199159819567529e-7f, r);
+    return r * 0.15915494309189535f;
+}
+ENS_DEV float ens_sinf(float x) { return __builtin_amdgcn_sinf(ens_red_rev(x)); }
+ENS_DEV float ens_cosf(float x) { return __builtin_amdgcn_cosf(ens_red_rev(x)); }
+#else
 ENS_DEV float ens_sinf(float x) {
     int n;
     const float r = ens_reduce_pio2(x, n);
@@ -369,6 +383,7 @@ ENS_DEV float ens_cosf(float x) {
     const float v = fmaf(t, odd ? r : z, odd ? r : fmaf(-0.5f, z, 1.f));
     return ((n + 1) & 2) ? -v : v;
 }
+#endif
 
 // wave-wide helpers (64 lanes)
 ENS_DEV float wave_sum(float v) {
