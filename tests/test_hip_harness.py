@@ -126,3 +126,47 @@ def test_tracking_converges_on_a_view_consistent_sequence(tmp_path):
     assert ate['const_speed_init'] > 0.05                       # without camera iterations the estimate falls behind by > 5 cm
     assert ate['tracked'] < 0.25 * ate['const_speed_init'], ate
     assert ate['tracked'] < 0.025, ate
+
+
+def test_harness_on_an_rpg_event_layout_sequence(tmp_path):
+    """BASELINE config 5's data format through the harness: a grey-scale RPG_event-layout sequence (png frames, 16-bit depth at
+    png_depth_scale 1000, event pngs with channels (+, -, 0), a lens model in cam.distortion) read by datasets.RPG_event -- the
+    colour and event images undistorted, the depth not -- tracked and mapped for a few frames.  The frames are renderings of the
+    analytic room through an ideal pinhole, so with the (weak) lens model removed from them they are only approximately
+    consistent: the assertions are about the pipeline (reader -> tracker -> mapper -> checkpoint), not about accuracy."""
+    from evennicer_slam_amd import datasets as D
+    from evennicer_slam_amd.scene import scene_bound
+    from evennicer_slam_amd.slam import SLAM
+    from evennicer_slam_amd.synthetic import BoxRoom, demo_config, trajectory
+    n = 5
+    cam = dict(H=52, W=70, fx=39.3, fy=39.3, cx=34.5, cy=25.5)            # configs/rpg/rpg.yaml:62-68 at a fifth of the resolution
+    bound = scene_bound([[-1.0, 1.1], [-0.9, 0.8], [-0.7, 0.6]], 1.0, 0.32)
+    room = BoxRoom.for_bound(bound, margin=0.12, seed=1)
+    poses = trajectory(room, n, step=0.012, yaw_deg=0.5)
+    frames, events = [], []
+    rng = np.random.default_rng(0)
+    for i, c2w in enumerate(poses):
+        col, dep = room.render(c2w.double(), cam)
+        grey = np.clip(np.rint(col.mean(-1).numpy() * 255), 0, 255).astype(np.uint8)
+        frames.append((grey, dep.numpy()))
+        if i > 0:
+            events.append(rng.integers(0, 2, (cam['H'], cam['W'], 2)).astype(np.uint8))
+    inp, evf = D.write_rpg_event_sequence(str(tmp_path / 'data'), frames, [p.numpy() for p in poses], 1000.0, events)
+    cfg = demo_config(inp, evf, cam, device=DEV, env={'ITERS_FIRST': 60, 'MAP_ITERS': 10, 'TRACK_ITERS': 5, 'EVERY': 2})
+    cfg['dataset'] = 'rpg_event'
+    cfg['cam'] = dict(cam, png_depth_scale=1000.0, crop_edge=0, distortion=[-0.08409333, 0.05335822, -0.00065521, -0.0001679, 0, 0, 0, 0])
+    ds = D.get_dataset(cfg, types.SimpleNamespace(input_folder=None, event_folder=None), 1, device=DEV)
+    assert isinstance(ds, D.RPG_event) and len(ds) == n
+    idx, color, depth, event, mask, pose = ds[2]
+    assert tuple(color.shape) == (52, 70, 3) and bool((color[..., 0] == color[..., 1]).all())       # grey replicated
+    assert tuple(event.shape) == (52, 70, 2) and tuple(mask.shape) == (52, 70) and depth.dtype == torch.float32
+    assert float((depth.cpu() - torch.from_numpy(frames[2][1])).abs().max()) <= 0.5 / 1000.0 + 1e-6  # the depth is NOT undistorted
+    torch.manual_seed(0)
+    np.random.seed(0)
+    slam = SLAM(cfg, ds, str(tmp_path / 'out'), device=DEV, static_shapes=True)
+    res = slam.run()
+    ckpt = torch.load(res['ckpt'], map_location='cpu', weights_only=False)
+    assert ckpt['idx'] == n - 1 and bool(torch.isfinite(ckpt['estimate_c2w_list']).all())
+    assert torch.equal(ckpt['estimate_c2w_list'][0], ckpt['gt_c2w_list'][0])
+    ate = slam.evaluate(res['ckpt'])
+    assert ate['compared_pose_pairs'] == n and np.isfinite(ate['absolute_translational_error.rmse'])
