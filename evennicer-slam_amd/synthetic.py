@@ -120,11 +120,11 @@ def demo_config(inp, evf, cam, device='cuda:0', env=None):
         'mapping': {'bound': [[-1.0, 1.1], [-0.9, 0.8], [-0.7, 0.6]], 'w_color_loss': 0.2, 'lr_factor': 1, 'lr_first_factor': float(env.get('LR_FIRST', 1)),
                     'BA': False, 'BA_cam_lr': 0.001, 'middle_iter_ratio': 0.4, 'fine_iter_ratio': 0.6, 'fix_fine': True,
                     'fix_color': False, 'pixels': int(env.get('MAP_PIXELS', 600)), 'iters_first': int(env.get('ITERS_FIRST', 400)),
-                    'iters': int(env.get('MAP_ITERS', 30)), 'every_frame': int(env.get('EVERY', 3)), 'keyframe_every': 6,
+                    'iters': int(env.get('MAP_ITERS', 30)), 'every_frame': int(env.get('EVERY', 2)), 'keyframe_every': 6,
                     'mapping_window_size': 5, 'frustum_feature_selection': True, 'stage': stage},
         'tracking': {'device': device, 'w_color_loss': 0.5, 'ignore_edge_W': 4, 'ignore_edge_H': 4, 'handle_dynamic': True,
-                     'use_color_in_tracking': True, 'lr': float(env.get('TRACK_LR', 0.002)), 'pixels': int(env.get('TRACK_PIXELS', 400)),
-                     'iters': int(env.get('TRACK_ITERS', 20)), 'const_speed_assumption': True, 'gt_camera': False},
+                     'use_color_in_tracking': True, 'lr': float(env.get('TRACK_LR', 0.002)), 'pixels': int(env.get('TRACK_PIXELS', 1000)),
+                     'iters': int(env.get('TRACK_ITERS', 40)), 'const_speed_assumption': True, 'gt_camera': False},
         'event': {'activate_events': False, 'blur': True, 'kernel_sizes': [9], 'kernel_weights': [1], 'unblurred_weight': 0,
                   'balancer': 0.025, 'scale_factor': 0.5},
     }

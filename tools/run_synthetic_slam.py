@@ -22,7 +22,7 @@ def run(n=30, verbose=True):
         (inp, evf), poses = write_demo_sequence(os.path.join(tmp, 'data'), n, cam, step=float(os.environ.get('STEP', 0.012)), yaw_deg=float(os.environ.get('YAW', 0.5)))
         cfg = demo_config(inp, evf, cam, device=DEV, env=os.environ)
         ds = D.get_dataset(cfg, types.SimpleNamespace(input_folder=None, event_folder=None), 1, device=DEV)
-        for tag, iters in (('tracked', None), ('const_speed_init', 0)):
+        for tag, iters in ((('tracked', None),) if os.environ.get('SKIP_BASE') == '1' else (('tracked', None), ('const_speed_init', 0))):
             torch.manual_seed(0); np.random.seed(0)
             slam = SLAM(cfg, ds, os.path.join(tmp, 'out_' + tag), device=DEV, static_shapes=True, verbose=os.environ.get('VERBOSE') == '1')
             fit = slam.prefit_decoders(list(range(0, n, max(n // 6, 1))), iters=int(os.environ.get('PREFIT', 400)))
