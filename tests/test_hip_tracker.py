@@ -112,3 +112,86 @@ def test_get_sample_uv_fused_gather_is_bit_exact(cdtype):
     ri, rj, rd, rc = C.select_uv(ii, jj, n, dd, cc, device='cuda:0')
     assert i.dtype == ri.dtype and c.dtype == rc.dtype == cdtype and d.dtype == rd.dtype
     assert torch.equal(i, ri) and torch.equal(j, rj) and torch.equal(d, rd) and torch.equal(c, rc)
+
+
+def test_tracking_loop_twin_against_the_oracle(monkeypatch):
+    """the harness's tracking loop of one frame -- `tracking.iters` camera iterations of
+    `TrackerIteration.optimize_cam_in_batch` (pose -> rays -> HIP render -> uncertainty-weighted loss -> backward -> Adam) with
+    the least-loss candidate kept (slam.SLAM.track, Tracker.py:321-330) -- against an oracle-driven twin on the CPU
+    (oracle/tracker_oracle.camera_iteration + torch.optim.Adam) ON THE SAME PIXEL DRAWS (both sides pop the draws from one
+    pre-generated list: the CPU and HIP generators produce different streams).  Camera tensor after every iteration and the
+    candidate finally kept agree to 1e-4."""
+    import types
+    import evennicer_slam_amd as E
+    from evennicer_slam_amd.mapper import FusedAdam
+    from oracle import tracker_oracle as TO
+    from tests.hip_util import DEV, cfg_like, tiny_on_gpu
+    from tests.util import tiny_scene
+    g = load("tiny_tracker_iter")
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    H, W, fx, fy, cx, cy = [float(x) for x in g['cam']]
+    H, W = int(H), int(W)
+    He, We = int(g['edge'][0]), int(g['edge'][1])
+    w_color, K, n, lr = float(g['w_color_loss']), 6, 48, 2e-3
+    gen = torch.Generator().manual_seed(11)
+    draws = [torch.randint((H - 2 * He) * (W - 2 * We), (n,), generator=gen) for _ in range(K)]
+    ct0 = torch.from_numpy(g['camera_tensor']).float()
+    gd_img, gc_img = torch.from_numpy(g['gt_depth']), torch.from_numpy(g['gt_color'])
+
+    # ---- oracle twin (CPU)
+    params, ogrids, obound, _ = tiny_scene()
+    oct = ct0.clone().requires_grad_(True)
+    oopt = torch.optim.Adam([oct], lr=lr)
+    o_traj, o_losses = [], []
+    for k in range(K):
+        oopt.zero_grad()
+        loss, _d, _v, _c, _inside = TO.camera_iteration(params, ogrids, obound, oct, gd_img, gc_img, (H, W, fx, fy, cx, cy), (He, We), n,
+                                                        w_color, idx=draws[k])
+        o_losses.append(float(loss.item()))
+        o_traj.append(oct.detach().clone())              # the candidate this loss belongs to (the pose BEFORE the step)
+        loss.backward()
+        oopt.step()
+
+    # ---- the harness's loop on the HIP path, fed the same draws
+    for p in model.parameters():
+        p.requires_grad_(False)
+    try:
+        cfg = cfg_like()
+        cfg['tracking'] = {'device': DEV, 'w_color_loss': w_color, 'ignore_edge_W': We, 'ignore_edge_H': He, 'handle_dynamic': False,
+                           'use_color_in_tracking': True, 'lr': lr, 'pixels': n, 'iters': K}
+        cfg['event'] = {'activate_events': False, 'blur': False, 'kernel_sizes': [9], 'kernel_weights': [1], 'unblurred_weight': 0,
+                        'balancer': 0.025}
+        slam = types.SimpleNamespace(nice=True, bound=bound, renderer=renderer, event_net=None, low_gpu_mem=False, H=H, W=W, fx=fx,
+                                     fy=fy, cx=cx, cy=cy)
+        trk = E.tracker.TrackerIteration(cfg, None, slam)
+        trk.c, trk.decoders = grids, model
+        queue = list(draws)
+        real_randint = torch.randint
+
+        def fake_randint(high, size, *a, device=None, **kw):
+            if tuple(size) == (n,) and queue:
+                return queue.pop(0).to(device if device is not None else 'cpu')
+            return real_randint(high, size, *a, device=device, **kw)
+
+        monkeypatch.setattr(torch, 'randint', fake_randint)
+        ct = ct0.clone().to(DEV).requires_grad_(True)
+        opt = FusedAdam([ct], lr=lr)
+        gd_dev, gc_dev = gd_img.to(DEV), gc_img.to(DEV)
+        best, best_loss, h_losses = None, None, []
+        for k in range(K):
+            before = ct.detach().clone()
+            out = trk.optimize_cam_in_batch(ct, None, gc_dev, gd_dev, None, None, n, opt, 1, k, None, rgbd=True, event=False)
+            h_losses.append(out[0])
+            assert float((before.cpu() - o_traj[k]).abs().max()) <= 1e-4, k       # same pose entering iteration k
+            if best_loss is None or out[0] < best_loss:
+                best_loss, best = out[0], before
+        assert not queue                                                        # every draw was consumed by the HIP side
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(True)
+    for a, b in zip(h_losses, o_losses):
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1.0)
+    k_best = int(np.argmin(o_losses))
+    assert float((best.cpu() - o_traj[k_best]).abs().max()) <= 1e-4
+    assert float((ct.detach().cpu() - oct.detach()).abs().max()) <= 1e-4        # after the last Adam step
+    assert float((ct0 - oct.detach()).abs().max()) > 1e-3                       # (the pose really moved)
