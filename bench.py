@@ -318,7 +318,7 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, want_cpu_baseline, variant=None):
+def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, want_cpu_baseline, variant=None, grid_layout=None):
     """Measure one configuration.  scaling 'weak': `rays` per rank (batch = world x rays); 'strong': `rays` per
     iteration, split over the ranks in contiguous blocks (parallel.shard_range)."""
     import evennicer_slam_amd as E
@@ -346,7 +346,13 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
     rays_cpu = [t[lo:hi].contiguous() for t in batch]
     model = sc['model'].to(dev)
     attach_bounds(model, sc['bound'])
-    grids = {k: v.to(dev).requires_grad_(True) for k, v in sc['grids'].items()}
+    # Feature grids: the reference's tensors ([1,32,D,H,W], same values and indexing) in torch's channels_last_3d memory format by
+    # default -- their storage is then the [V][32] layout the gathers read, nothing is converted per step and the gradients come
+    # back in the same format (functional.is_native_grid; the one-line change at grid_init is in INTEGRATION.md).
+    # --grid-layout contiguous: the reference's own strides (what a caller who changes nothing passes; reported under `also`).
+    grid_layout = grid_layout or args.grid_layout
+    mf = torch.channels_last_3d if grid_layout == 'channels_last_3d' else torch.contiguous_format
+    grids = {k: v.to(dev).contiguous(memory_format=mf).requires_grad_(True) for k, v in sc['grids'].items()}
     ro, rd, gd, gc = [t.to(dev) for t in rays_cpu]
     ro.requires_grad_(True)
     rd.requires_grad_(True)
@@ -576,7 +582,7 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{pretty} {scene} full 4-level grid, stage {stage}, {per}, render_batch_ray + mapper loss + "
                                f"backward (grads: grids, all decoder params, rays)",
-                   "rays_per_gpu": n_local, "rays_per_step": total_rays, "samples_per_ray": S,
+                   "rays_per_gpu": n_local, "rays_per_step": total_rays, "samples_per_ray": S, "grid_memory_format": grid_layout,
                    "parallelism": "1 GPU" if world == 1 else f"ray-sharded dp{world}, one bucketed RCCL all-reduce of leaf grads "
                                                             f"(touched 64-voxel blocks only)"},
         "loss": float(loss.item()), "mode": mode, "loss_impl": "torch" if args.torch_loss else ("fused HIP (losses.rgbd_loss)" if args.separate_loss or stage == 'coarse'
@@ -806,6 +812,8 @@ def main():
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-api', action='store_true', help='skip the reference-API-only (Python-driven) timing `api_rays_per_s`')
     ap.add_argument('--variant', default=None, choices=('surfaces',), help='primary workload on a map fitted to an analytic room')
+    ap.add_argument('--grid-layout', default='channels_last_3d', choices=('channels_last_3d', 'contiguous'),
+                    help='memory format of the feature-grid tensors (same shape and values either way)')
     ap.add_argument('--torch-loss', action='store_true', help='compute the mapper loss with torch ops instead of the fused HIP loss')
     ap.add_argument('--separate-loss', action='store_true', help='render_batch_ray, then losses.rgbd_loss as its own launches')
     ap.add_argument('--eager', action='store_true', help='time the plain Python-driven step instead of hipGraph replays')
@@ -848,6 +856,18 @@ def main():
                                  "room (box room + one box, smooth view-consistent colours) seen from the bench camera")
                 return o
 
+            def contiguous_grids():
+                r = run_workload(env, args, scene, rays, scaling, max(50, args.steps // 2), max(5, args.warmup // 2),
+                                 want_events=False, want_cpu_baseline=False, grid_layout='contiguous')
+                o = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "mode", "loss", "api_rays_per_s", "api_ms_per_step",
+                                       "eager_rays_per_s") if k in r}
+                o["workload"] = ("config 2 with the feature grids in the reference's own strides (a caller that changes nothing, not even "
+                                 "the memory format at grid_init): touched blocks converted to [V][32] before the forward and the "
+                                 "gradients transposed back after the backward, every step")
+                return o
+
+            if args.grid_layout != 'contiguous':
+                guarded("config2_contiguous_grids", contiguous_grids)
             guarded("config2_surfaces", surfaces)
             guarded("config3", lambda: run_config3(env.dev, steps=max(10, min(30, args.steps // 10))))
             guarded("tracker_iter_200", lambda: run_tracker_iter(env.dev, 200, steps=max(50, args.steps)))

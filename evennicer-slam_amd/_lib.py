@@ -138,6 +138,17 @@ _SIGS = {
                                                    POINTER(c_void_p), c_int32, POINTER(c_int32), POINTER(c_void_p), POINTER(c_void_p),
                                                    POINTER(MlpParams), c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                                    POINTER(Scene), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "enslam_step_finish_native": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),
+                                                 POINTER(c_void_p), c_int32, POINTER(c_int32), POINTER(c_void_p), POINTER(c_void_p),
+                                                 POINTER(MlpParams), c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                                 POINTER(Scene), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_int64, c_void_p]),
+    "enslam_sample_prepare": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                             POINTER(c_double), c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                             c_int32, c_void_p, c_int32, POINTER(Scene), POINTER(c_void_p), c_int32, POINTER(c_void_p),
+                                             c_int32, POINTER(c_int32), POINTER(MlpParams), POINTER(c_void_p),
+                                             c_int32, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), c_void_p, c_int64,
+                                             c_void_p]),
     "enslam_rgbd_loss_fwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,
                                             c_void_p]),
     "enslam_rgbd_loss_bwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,

@@ -256,7 +256,8 @@ static bool work_list_of(int32_t* tiles, int32_t* count, WorkList& w) {
 static int step_finish_impl(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
                             const uint8_t* const* need, int32_t n_dec, const int32_t* kinds, const float* const* packed_grads,
                             const enslam_mlp_params* grads, const RayGradArgs* rg, void* stream, uint8_t* const* prev = nullptr,
-                            const float* const* partials = nullptr) {
+                            const float* const* partials = nullptr, uint8_t* mv_need = nullptr, uint8_t* mv_prev = nullptr,
+                            int64_t n_move = 0) {
     if (n_dec < 0 || n_dec > 4 || n_conv < 0 || n_conv > 4) return ENSLAM_EINVAL;
     PackJob pj;
     clear_job(pj);
@@ -281,7 +282,8 @@ static int step_finish_impl(int32_t n_conv, const float* const* src, float* cons
             if (!need[i]) return ENSLAM_EINVAL;
         if (!make_conv_job(n_conv, src, dst, n_voxels, need, need ? prev : nullptr, true, cj)) return ENSLAM_EINVAL;
     }
-    return ens_launch_step(pj, true, cj, false, zj, nullptr, 0, rg, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+    if (n_move < 0 || (n_move > 0 && (!mv_need || !mv_prev))) return ENSLAM_EINVAL;
+    return ens_launch_step(pj, true, cj, false, zj, nullptr, 0, rg, (hipStream_t)stream, mv_need, mv_prev, n_move) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
 int enslam_step_finish(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
                        const uint8_t* const* need, int32_t n_dec, const int32_t* kinds, const float* const* packed_grads,
@@ -361,6 +363,36 @@ int enslam_step_finish_partials(int32_t n_conv, const float* const* src, float* 
                            work_list ? &wl : nullptr))
         return ENSLAM_EINVAL;
     return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, &rg, stream, prev, grad_partials);
+}
+
+int enslam_step_finish_native(int32_t n_conv, const float* const* src, float* const* dst, const int64_t* n_voxels,
+                              const uint8_t* const* need, uint8_t* const* prev, int32_t n_dec, const int32_t* kinds,
+                              const float* const* packed_grads, const float* const* grad_partials, const enslam_mlp_params* grads,
+                              int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                              const double* z_vals, const enslam_scene* scene, float* dgrid_ws, float* g_rays_o, float* g_rays_d,
+                              const int32_t* work_list, const int32_t* work_count, uint8_t* move_need, uint8_t* move_prev,
+                              int64_t n_move, void* stream) {
+    if (n_rays < 0 || n_move < 0 || (n_move > 0 && (!move_need || !move_prev))) return ENSLAM_EINVAL;
+    if (prev != nullptr) {
+        if (!need || n_conv < 0 || n_conv > 4) return ENSLAM_EINVAL;
+        for (int i = 0; i < n_conv; ++i)
+            if (!need[i] || !prev[i]) return ENSLAM_EINVAL;
+    }
+    if (n_rays == 0 || stage == ENSLAM_STAGE_COARSE || dgrid_ws == nullptr)
+        return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, nullptr, stream, prev, grad_partials,
+                                move_need, move_prev, n_move);
+    if (!samples_ok(n_samples)) return ENSLAM_EUNSUPPORTED;
+    DevScene d;
+    if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
+    if (!rays_o || !rays_d || !z_vals || !g_rays_o || !g_rays_d) return ENSLAM_EINVAL;
+    RayGradArgs rg;
+    WorkList wl;
+    if (!work_list_of(const_cast<int32_t*>(work_list), const_cast<int32_t*>(work_count), wl)) return ENSLAM_EINVAL;
+    if (!ens_ray_grad_args(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, d, dgrid_ws, g_rays_o, g_rays_d, rg,
+                           work_list ? &wl : nullptr))
+        return ENSLAM_EINVAL;
+    return step_finish_impl(n_conv, src, dst, n_voxels, need, n_dec, kinds, packed_grads, grads, &rg, stream, prev, grad_partials,
+                            move_need, move_prev, n_move);
 }
 
 int enslam_grids_convert(int32_t n, const float* const* src, float* const* dst, const int64_t* n_voxels,
@@ -610,6 +642,52 @@ int enslam_sample_rays_g(int32_t n_rays, int32_t n_lin, int32_t n_surf, const fl
     }
     return ens_launch_sample(n_rays, n_lin, n_surf, rays_o, rays_d, gt_depth, bound_host, t_lin, t_surf, lindisp,
                              t_rand, scratch, depth_max_given, z_vals, marking ? &mk : nullptr, (hipStream_t)stream);
+}
+
+int enslam_sample_prepare(int32_t n_rays, int32_t n_lin, int32_t n_surf, const float* rays_o, const float* rays_d,
+                          const float* gt_depth, const double* bound_host, const float* t_lin, const double* t_surf,
+                          int32_t lindisp, const float* t_rand, float* scratch, int32_t depth_max_given, double* z_vals,
+                          int32_t mark_stage, const enslam_scene* mark_scene, uint8_t* const* mark_flags,
+                          int32_t mark_block_voxels, uint8_t* const* mark_flags64,
+                          int32_t n_dec, const int32_t* kinds, const enslam_mlp_params* params, float* const* packed,
+                          int32_t n_zero, float* const* zero_dst, const int64_t* zero_voxels, const uint8_t* const* zero_need,
+                          float* flat, int64_t n_flat, void* stream) {
+    if (n_rays < 0 || n_lin < 1 || n_surf < 0) return ENSLAM_EINVAL;
+    if (n_dec < 0 || n_dec > 3 || n_zero < 0 || n_zero > 4 || n_flat < 0 || (n_flat > 0 && !flat)) return ENSLAM_EINVAL;
+    int shift = 6;
+    switch (mark_block_voxels) { case 64: shift = 6; break; case 32: shift = 5; break; case 16: shift = 4; break; case 8: shift = 3; break; default: return ENSLAM_EINVAL; }
+    if (n_rays > 0) {
+        if (!rays_o || !rays_d || !bound_host || !t_lin || !z_vals) return ENSLAM_EINVAL;
+        if (gt_depth != nullptr && (scratch == nullptr || (n_surf > 0 && t_surf == nullptr))) return ENSLAM_EINVAL;
+    } else if (!bound_host) {
+        return ENSLAM_EINVAL;
+    }
+    MarkArgs mk;
+    const bool marking = mark_scene != nullptr && mark_flags != nullptr;
+    if (marking) {
+        if (mark_stage < 0 || mark_stage > 3 || !to_dev_scene(mark_scene, mk.sc)) return ENSLAM_EINVAL;
+        mk.kmask = mark_stage == 0 ? 1 : (mark_stage == 1 ? 2 : (mark_stage == 2 ? 6 : 14));
+        for (int k = 0; k < 4; ++k) { mk.flags[k] = mark_flags[k]; mk.flags64[k] = (mark_flags64 != nullptr && shift < 6) ? mark_flags64[k] : nullptr; }
+        mk.shift = shift;
+    }
+    PackJob pj;
+    clear_job(pj);
+    if (n_dec > 0 && (!kinds || !params || !packed)) return ENSLAM_EINVAL;
+    for (int i = 0; i < n_dec; ++i) {
+        if (!packed[i]) return ENSLAM_EINVAL;
+        g_seg_dec = i;
+        pj.packed[i] = packed[i];
+        const bool ok = build_job(kinds[i], params[i], true, pj, true);
+        g_seg_dec = 0;
+        if (!ok) return ENSLAM_EINVAL;
+    }
+    ConvJob zj;
+    empty_conv_job(zj);
+    if (n_zero > 0 && !make_conv_job(n_zero, nullptr, zero_dst, zero_voxels, zero_need, nullptr, false, zj)) return ENSLAM_EINVAL;
+    const int rc = ens_launch_sample_prepare(n_rays, n_lin, n_surf, rays_o, rays_d, gt_depth, bound_host, t_lin, t_surf, lindisp, t_rand,
+                                             scratch, depth_max_given, z_vals, marking ? &mk : nullptr, pj, zj, flat, n_flat,
+                                             (hipStream_t)stream);
+    return rc == 0 ? ENSLAM_OK : (rc == -1 ? ENSLAM_EINVAL : ENSLAM_ELAUNCH);
 }
 
 int enslam_render_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,

@@ -107,7 +107,8 @@ int ens_launch_gather_pixels(int n, const int64_t* idx, int H0, int W0, int ww, 
 int ens_launch_pose_rays(int n, const float* ct, const float* pi, const float* pj, float fx, float fy, float cx, float cy,
                          const float* g_ro, const float* g_rd, float* ro, float* rd, float* g_ct, hipStream_t st);
 int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_vm, const ConvJob& zj, float* flat,
-                    int64_t n_flat, const RayGradArgs* rg, hipStream_t st);
+                    int64_t n_flat, const RayGradArgs* rg, hipStream_t st, uint8_t* mv_need = nullptr, uint8_t* mv_prev = nullptr,
+                    int64_t n_move = 0);
 bool ens_ray_grad_args(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z, const DevScene& sc,
                        float* dgrid_ws, float* g_ro, float* g_rd, RayGradArgs& A, const WorkList* wl = nullptr);
 int ens_launch_adam(const AdamJob& job, hipStream_t st);
@@ -122,6 +123,22 @@ struct MarkArgs {                // optional block marking inside the sampler (m
     int shift;                   // log2(voxels per flag): 6 (the renderer's own 64-voxel blocks) .. 3
     uint8_t* flags64[4];         // optional (shift < 6): the same marks at 64 voxels per flag as well
 };
+struct SampleArgs {              // sample_kernel's scalar arguments (Renderer.py:95-171)
+    int n_rays, n_lin, n_surf, lindisp, dmax_inline;
+    const float* ro;
+    const float* rd;
+    const float* gd;             // gt depth [n_rays] or null
+    double lo[3], hi[3];         // Renderer.bound
+    const float* t_lin;
+    const double* t_surf;
+    const float* t_rand;         // perturbation draws or null
+    const float* dmax;           // {max(gd), fl32(max * 1.2f)} when not reduced inline
+    double* zout;
+};
+int ens_launch_sample_prepare(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
+                              const double* bound, const float* t_lin, const double* t_surf, int lindisp, const float* t_rand,
+                              float* scratch, int dmax_given, double* z, const MarkArgs* mark, const PackJob& pj, const ConvJob& zj,
+                              float* flat, int64_t n_flat, hipStream_t st);
 int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
                       const double* bound, const float* t_lin, const double* t_surf, int lindisp,
                       const float* t_rand, float* scratch, int dmax_given, double* z, const MarkArgs* mark, hipStream_t st);

@@ -32,15 +32,17 @@ __global__ __launch_bounds__(1024) void depth_max_kernel(int n, const float* __r
 //   z_lin   float64: (double)(near * (1.f - t)) + far * (double)t
 //   surface float64: (double)(0.95f*d) * (1 - ts) + (double)(1.05f*d) * ts   | 0.001*(1-ts) + (double)dmax*ts
 constexpr int MAX_S = 64;
-__global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n_surf, const float* __restrict__ ro,
-                                                     const float* __restrict__ rd, const float* __restrict__ gd,
-                                                     double lo0, double hi0, double lo1, double hi1, double lo2,
-                                                     double hi2, const float* __restrict__ t_lin,
-                                                     const double* __restrict__ t_surf, int lindisp,
-                                                     const float* __restrict__ t_rand,
-                                                     const float* __restrict__ dmax, int dmax_inline,
-                                                     double* __restrict__ zout, MarkArgs mk) {
-    const int ray = blockIdx.x, lane = threadIdx.x;
+ENS_DEV void sample_body(const SampleArgs& A, const MarkArgs& mk, const int ray, const int lane) {
+    const int n_rays = A.n_rays, n_lin = A.n_lin, n_surf = A.n_surf, lindisp = A.lindisp, dmax_inline = A.dmax_inline;
+    const float* __restrict__ ro = A.ro;
+    const float* __restrict__ rd = A.rd;
+    const float* __restrict__ gd = A.gd;
+    const float* __restrict__ t_lin = A.t_lin;
+    const double* __restrict__ t_surf = A.t_surf;
+    const float* __restrict__ t_rand = A.t_rand;
+    const float* __restrict__ dmax = A.dmax;
+    double* __restrict__ zout = A.zout;
+    const double lo0 = A.lo[0], hi0 = A.hi[0], lo1 = A.lo[1], hi1 = A.hi[1], lo2 = A.lo[2], hi2 = A.hi[2];
     float dmax0 = 0.f, dmax1 = 0.f;                     // max(gt_depth) over the batch and fl32(max * 1.2f)
     if (gd != nullptr) {
         if (dmax_inline) {                              // small batch: every wave reduces the (L2-resident) depths itself
@@ -53,7 +55,6 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
             dmax0 = dmax[0]; dmax1 = dmax[1];
         }
     }
-    const double lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
     double far_bb = INFINITY;
     {   // the six face distances are ray-uniform: lanes 0..5 divide once each (float64 divisions are the long pole of
         // this kernel), the others pick the results up
@@ -155,6 +156,8 @@ __global__ __launch_bounds__(64) void sample_kernel(int n_rays, int n_lin, int n
         }
     }
 }
+
+__global__ __launch_bounds__(64) void sample_kernel(SampleArgs A, MarkArgs mk) { sample_body(A, mk, (int)blockIdx.x, (int)threadIdx.x); }
 
 // ------------------------------------------------------------------ mapper RGB-D loss (Mapper.py:553-562)
 __global__ __launch_bounds__(1024) void rgbd_loss_fwd_kernel(int n, const double* __restrict__ depth,
@@ -680,7 +683,8 @@ ENS_DEV void unpack_partial_body(const PackJob& job, int seg, int y, int ny) {
 // grid gradients and unpacked decoder gradients.
 __global__ __launch_bounds__(256) void step_kernel(PackJob pj, int unpack, ConvJob cj, int to_vm, ConvJob zj,
                                                    float* __restrict__ flat, int64_t n_flat, int nb_ray, int nb_pack, int nb_conv,
-                                                   int nb_zero, RayGradArgs rg, int pack_ny) {
+                                                   int nb_zero, RayGradArgs rg, int pack_ny, uint8_t* __restrict__ mv_need,
+                                                   uint8_t* __restrict__ mv_prev, int n_move) {
     // Workgroups are dispatched in blockIdx order: the ray-gradient units (latency-bound: float64 geometry, a dependent
     // corner re-gather, a coordinate-gradient reduction; 16 us as a launch of its own) come FIRST so that they run under
     // the bandwidth-bound roles (zero-fill / transposed-back gradients) instead of behind them.
@@ -694,7 +698,31 @@ __global__ __launch_bounds__(256) void step_kernel(PackJob pj, int unpack, ConvJ
         else unpack_partial_body(pj, (b - nb_ray) / pack_ny, (b - nb_ray) % pack_ny, pack_ny);     // partial images to sum
     }
     else if (b < nb_ray + nb_pack + nb_conv) convert_body(cj, to_vm, b - nb_ray - nb_pack);
-    else zero_body(zj, flat, n_flat, b - nb_ray - nb_pack - nb_conv);
+    else if (b < nb_ray + nb_pack + nb_conv + nb_zero) zero_body(zj, flat, n_flat, b - nb_ray - nb_pack - nb_conv);
+    else {
+        // block flags of gradients that live in the kernels' own layout (nothing to transpose back): the flags this step's
+        // sampler marked move to `prev` -- what the next replay's prepare launch clears by and what the gradient bucket reads --
+        // and are cleared for the next replay's sampler (the flag half of convert_body's persistent branch)
+        const int e = (b - nb_ray - nb_pack - nb_conv - nb_zero) * 256 + (int)threadIdx.x;
+        if (e < n_move) {
+            const uint8_t f = mv_need[e];
+            if (mv_prev[e] != f) mv_prev[e] = f;
+            if (f) mv_need[e] = 0;
+        }
+    }
+}
+
+// sampler + prepare roles in one launch (ens_launch_sample_prepare): the rays come FIRST in blockIdx order -- a ray's wave is a
+// dependent chain of float64 divisions and a 21-step shuffle sort (the whole 10 us of the launch), the other roles run under it
+__global__ __launch_bounds__(256) void sample_prepare_kernel(SampleArgs A, MarkArgs mk, PackJob pj, ConvJob zj, float* __restrict__ flat,
+                                                             int64_t n_flat, int nb_samp, int nb_pack) {
+    const int b = blockIdx.x;
+    if (b < nb_samp) {
+        const int ray = b * 4 + (int)(threadIdx.x >> 6);
+        if (ray < A.n_rays) sample_body(A, mk, ray, (int)(threadIdx.x & 63));
+    }
+    else if (b < nb_samp + nb_pack) pack_body(pj, nullptr, 0, (b - nb_samp) >> 2, (b - nb_samp) & 3, 4);
+    else zero_body(zj, flat, n_flat, b - nb_samp - nb_pack);
 }
 
 }  // namespace
@@ -720,7 +748,7 @@ int ens_launch_convert(const ConvJob& job, bool to_vm, hipStream_t st) {
 }
 
 int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_vm, const ConvJob& zj, float* flat,
-                    int64_t n_flat, const RayGradArgs* rg, hipStream_t st) {
+                    int64_t n_flat, const RayGradArgs* rg, hipStream_t st, uint8_t* mv_need, uint8_t* mv_prev, int64_t n_move) {
     bool any_part = false;
     for (int i = 0; i < 4; ++i) any_part = any_part || (unpack && pj.part[i] != nullptr);
     const int pack_ny = any_part ? 64 : 4;
@@ -729,12 +757,15 @@ int ens_launch_step(const PackJob& pj, bool unpack, const ConvJob& cj, bool to_v
     RayGradArgs r;
     if (rg != nullptr) r = *rg; else { r.n_rays = 0; r.ntl = 0; r.n_slots = 0; }
     const int64_t nb_ray = ((int64_t)r.n_rays * r.ntl * r.n_slots + 3) / 4;
-    const int64_t nb = (int64_t)nb_pack + nb_conv + nb_zero + nb_ray;
+    if (n_move < 0 || n_move > 0x7fffff00 || (n_move > 0 && (!mv_need || !mv_prev))) return -1;
+    const int64_t nb_move = (n_move + 255) / 256;
+    const int64_t nb = (int64_t)nb_pack + nb_conv + nb_zero + nb_ray + nb_move;
     if (nb <= 0) return 0;
     if (nb > 0x7fffffff) return -1;
     if (nb_ray > 0x7fffffff) return -1;
     step_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(pj, unpack ? 1 : 0, cj, to_vm ? 1 : 0, zj, flat, flat ? n_flat : 0,
-                                                          (int)nb_ray, nb_pack, nb_conv, (int)nb_zero, r, pack_ny);
+                                                          (int)nb_ray, nb_pack, nb_conv, (int)nb_zero, r, pack_ny, mv_need, mv_prev,
+                                                          (int)n_move);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -828,18 +859,47 @@ int ens_launch_mark_blocks(int stage, int n_rays, int S, const float* ro, const 
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+static bool fill_sample_args(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
+                             const double* b, const float* t_lin, const double* t_surf, int lindisp, const float* t_rand,
+                             float* scratch, int dmax_given, double* z, const MarkArgs* mark, SampleArgs& A, MarkArgs& mk) {
+    if (n_lin + n_surf > MAX_S || n_lin < 1) return false;
+    A.n_rays = n_rays; A.n_lin = n_lin; A.n_surf = gd ? n_surf : 0; A.lindisp = lindisp;
+    A.dmax_inline = (gd != nullptr && !dmax_given && n_rays <= 4096) ? 1 : 0;
+    A.ro = ro; A.rd = rd; A.gd = gd; A.t_lin = t_lin; A.t_surf = t_surf; A.t_rand = t_rand; A.dmax = scratch; A.zout = z;
+    for (int a = 0; a < 3; ++a) { A.lo[a] = b[2 * a]; A.hi[a] = b[2 * a + 1]; }
+    if (mark != nullptr) mk = *mark; else { mk.kmask = 0; mk.shift = 6; for (int k = 0; k < 4; ++k) { mk.flags[k] = nullptr; mk.flags64[k] = nullptr; } }
+    return true;
+}
+
 int ens_launch_sample(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
                       const double* b, const float* t_lin, const double* t_surf, int lindisp, const float* t_rand,
                       float* scratch, int dmax_given, double* z, const MarkArgs* mark, hipStream_t st) {
     if (n_rays <= 0) return 0;
-    if (n_lin + n_surf > MAX_S || n_lin < 1) return -1;
-    const int dmax_inline = (gd != nullptr && !dmax_given && n_rays <= 4096) ? 1 : 0;
+    SampleArgs A;
     MarkArgs mk;
-    if (mark != nullptr) mk = *mark; else { mk.kmask = 0; mk.shift = 6; for (int k = 0; k < 4; ++k) { mk.flags[k] = nullptr; mk.flags64[k] = nullptr; } }
-    if (gd != nullptr && !dmax_given && !dmax_inline) depth_max_kernel<<<1, 1024, 0, st>>>(n_rays, gd, scratch);
-    sample_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(n_rays, n_lin, gd ? n_surf : 0, ro, rd, gd, b[0], b[1],
-                                                                 b[2], b[3], b[4], b[5], t_lin, t_surf, lindisp,
-                                                                 t_rand, scratch, dmax_inline, z, mk);
+    if (!fill_sample_args(n_rays, n_lin, n_surf, ro, rd, gd, b, t_lin, t_surf, lindisp, t_rand, scratch, dmax_given, z, mark, A, mk)) return -1;
+    if (gd != nullptr && !dmax_given && !A.dmax_inline) depth_max_kernel<<<1, 1024, 0, st>>>(n_rays, gd, scratch);
+    sample_kernel<<<dim3(n_rays), dim3(64), 0, st>>>(A, mk);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// The sampler and the forward's prepare launch as ONE launch (grids that arrive in the kernels' own layout need no conversion, so
+// nothing in the prepare roles waits for the sampler's block marks): workgroups [4 rays each | decoder packing | accumulator clearing]
+int ens_launch_sample_prepare(int n_rays, int n_lin, int n_surf, const float* ro, const float* rd, const float* gd,
+                              const double* b, const float* t_lin, const double* t_surf, int lindisp, const float* t_rand,
+                              float* scratch, int dmax_given, double* z, const MarkArgs* mark, const PackJob& pj, const ConvJob& zj,
+                              float* flat, int64_t n_flat, hipStream_t st) {
+    SampleArgs A;
+    MarkArgs mk;
+    if (!fill_sample_args(n_rays, n_lin, n_surf, ro, rd, gd, b, t_lin, t_surf, lindisp, t_rand, scratch, dmax_given, z, mark, A, mk)) return -1;
+    if (n_rays < 0) return -1;
+    const int nb_samp = (n_rays + 3) / 4, nb_pack = pj.n * 4;
+    const int64_t nb_zero = (zj.n > 0 ? zj.block_begin[zj.n] : 0) + (flat != nullptr && n_flat > 0 ? (n_flat + 2047) / 2048 : 0);
+    const int64_t nb = (int64_t)nb_samp + nb_pack + nb_zero;
+    if (nb <= 0) return 0;
+    if (nb > 0x7fffffff) return -1;
+    if (n_rays > 0 && gd != nullptr && !dmax_given && !A.dmax_inline) depth_max_kernel<<<1, 1024, 0, st>>>(n_rays, gd, scratch);
+    sample_prepare_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(A, mk, pj, zj, flat, flat ? n_flat : 0, nb_samp, nb_pack);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -50,7 +50,7 @@ def _ptrv(t):
 # in the graph's private memory pool and only hold data once that graph has been replayed; every replay rewrites them
 # with the values its inputs had at the START of the replay.  They are therefore tagged with the capture they were made
 # in and are invisible to everything outside that capture (an eager render after replays re-packs from the live tensors).
-_capture = {'epoch': 0, 'active': 0, 'raw_writes': None, 'init_zero': None, 'persist': None}
+_capture = {'epoch': 0, 'active': 0, 'raw_writes': None, 'init_zero': None, 'persist': None, 'persist_need': {}}
 
 # Persistent dense gradients of captured steps (see _RenderFn.backward): data_ptr of the gradient buffer -> the uint8 flags of
 # the 64-voxel blocks that hold non-zeros (`prev` of enslam_step_finish_rays_prev).  The finish launch of the next replay
@@ -88,6 +88,7 @@ def begin_capture():
     _capture['raw_writes'] = []
     _capture['init_zero'] = []
     _capture['persist'] = {}          # id(grid) -> (gradient data_ptr, prev flags) of this capture
+    _capture['persist_need'] = {}     # id(grid) -> the flags this step's sampler marks (persistent native gradients)
 
 
 def end_capture(ok=True):
@@ -113,6 +114,7 @@ def end_capture(ok=True):
             seen.add(id(t))
             out.append(t)
     persist, _capture['persist'] = _capture['persist'] or {}, None
+    _capture['persist_need'] = {}
     end_capture.persist_keys = [ptr for ptr, _pv in persist.values()]      # (read by graph.GraphedStep)
     return out
 
@@ -437,6 +439,28 @@ def _check_grid(g):
     _require_hip(g, "feature grids")
 
 
+_CL3D = torch.channels_last_3d
+
+
+def is_native_grid(g):
+    """A feature grid whose storage already is the kernels' own [V][32] layout: a [1,32,D,H,W] tensor in torch's
+    channels_last_3d memory format (`grid.contiguous(memory_format=torch.channels_last_3d)` -- same shape, same values, same
+    indexing as the reference's grids; only the strides differ).  Such a grid is gathered from where it lies, nothing is
+    converted per step, and its gradient comes back in the same memory format without a transposed copy."""
+    return g.dim() == 5 and g.shape[1] == 32 and g.is_contiguous(memory_format=_CL3D) and not g.is_contiguous()
+
+
+def _native_vm(g):
+    """[V,32] view of a native grid's storage."""
+    return g.detach().permute(0, 2, 3, 4, 1).reshape(-1, 32)
+
+
+def _native_grad_view(flat, dims):
+    """[1,32,D,H,W] channels_last_3d tensor over a flat [V*32] gradient buffer."""
+    D, H, W = dims
+    return flat.view(1, D, H, W, 32).permute(0, 4, 1, 2, 3)
+
+
 class _GridCache:
     """Voxel-major copies keyed on tensor IDENTITY + version counter.  (A data_ptr key would go stale when the
     caching allocator hands a freed grid's address to a new tensor, e.g. Tracker.update_para_from_mapping's
@@ -460,6 +484,8 @@ class _GridCache:
 
     def get(self, g):
         _check_grid(g)
+        if is_native_grid(g):
+            return _native_vm(g)
         e = self._lookup(g, False)
         if e is not None:
             return e.vm
@@ -477,6 +503,10 @@ class _GridCache:
         """Voxel-major copies of several grids; all cache misses are converted in ONE launch."""
         out, miss = [], []
         for i, g in enumerate(grids):
+            if is_native_grid(g):
+                _check_grid(g)
+                out.append(_native_vm(g))
+                continue
             e = self._lookup(g, False)
             out.append(e.vm if e is not None else None)
             if e is None:
@@ -704,7 +734,7 @@ class _Accumulators:
     read or transposed back) and one flat buffer of packed-layout decoder gradients and ray gradients.  Laid out in
     the forward, because the launch that prepares the forward's inputs clears them as well."""
 
-    def __init__(self, plan, dims, needs, N, dev, lib):
+    def __init__(self, plan, dims, needs, N, dev, lib, native=(), grid_ids=None):
         nk = len(plan.kinds)
         self.need_rays = bool(needs[1] or needs[2])
         self.need_grid = {k: bool(needs[5 + i]) for i, k in enumerate(plan.kinds)}
@@ -713,13 +743,32 @@ class _Accumulators:
             n = plan.n_params[k]
             self.need_par[k] = any(needs[off:off + n])
             off += n
+        # Gradients of grids that arrive in the kernels' own layout (channels_last_3d tensors, `native`): the buffer the backward
+        # adds into IS the tensor autograd receives.  Eagerly it is a slice of the flat buffer below (fresh and cleared as a whole
+        # per call); under hipGraph capture it is the same memory at every replay and only the blocks the previous replay
+        # touched are cleared (nat_persist: kind -> (gradient buffer [V*32], prev flags); the flags move there in the finish
+        # launch).  A second render of the same grid inside one captured step is not persistent (see _RenderFn.backward).
+        self.native = {k: (k in native and self.need_grid[k]) for k in plan.kinds}
+        self.nat_persist, self.nat_again = {}, {}
+        persist_ok = _capturing() and _capture['init_zero'] is not None
         sizes = []
         for k in plan.kinds:
             D, H, W = dims[k]
-            sizes.append(D * H * W * 32 if (self.need_grid[k] and k not in plan.vm) else 0)
+            sizes.append(D * H * W * 32 if (self.need_grid[k] and k not in plan.vm and not self.native[k]) else 0)
         for k in plan.kinds:
             sizes.append(_lib_size('enslam_packed_grad_floats', k) if self.need_par[k] else 0)
         sizes.append(6 * N if self.need_rays else 0)
+        pers = []
+        for i, k in enumerate(plan.kinds):
+            D, H, W = dims[k]
+            n = D * H * W * 32 if self.native[k] else 0
+            if n and persist_ok:
+                if grid_ids[i] in _capture['persist']:
+                    self.nat_again[k] = grid_ids[i]
+                else:
+                    pers.append((i, k, n))
+                    n = 0
+            sizes.append(n)
         offs = [0]
         for n in sizes:
             offs.append(offs[-1] + n)
@@ -733,6 +782,26 @@ class _Accumulators:
         self.n_zero = self.tail + 4
         self.zbuf = torch.empty(self.n_zero, dtype=torch.float32, device=dev)
         self.clean = False          # set by the launch that cleared them; a backward consumes it
+        self.pv_flat = None
+        if pers:
+            nblk = [(n // 32 + 63) // 64 for _i, _k, n in pers]
+            self.pv_flat = torch.empty(sum(nblk), dtype=torch.uint8, device=dev)
+            _capture['init_zero'].append(self.pv_flat.untyped_storage())
+            for (i, k, n), pv in zip(pers, self.pv_flat.split(nblk)):
+                g = torch.empty(n, dtype=torch.float32, device=dev)
+                _capture['init_zero'].append(g.untyped_storage())
+                _capture['persist'][grid_ids[i]] = (g.data_ptr(), pv)
+                _persist_prev[g.data_ptr()] = pv
+                self.nat_persist[k] = (g, pv)
+
+    def native_grad(self, plan, k):
+        """flat [V*32] gradient buffer of native grid kind k"""
+        if k in self.nat_persist:
+            return self.nat_persist[k][0]
+        i = plan.kinds.index(k)
+        j = 2 * len(plan.kinds) + 1 + i
+        o = self.offs[j] - self.n_grid
+        return self.zbuf[o:o + self.sizes[j]]
 
     def counter(self):
         return self.zbuf[self.tail:self.tail + 1].view(torch.int32)
@@ -742,11 +811,13 @@ class _Accumulators:
 
     def zero_args(self, plan, flags):
         """(n, dsts, n_voxels, need flags) of the grid accumulators for enslam_zero_blocks / enslam_step_prepare."""
-        zl = [(i, k) for i, k in enumerate(plan.kinds) if self.need_grid[k] and k not in plan.vm]
-        n = len(zl)
+        zl = [(i, k) for i, k in enumerate(plan.kinds) if self.need_grid[k] and k not in plan.vm and not self.native[k]]
+        n = len(zl) + len(self.nat_persist)
         dsts, vs, nd = (ctypes.c_void_p * max(n, 1))(), (ctypes.c_int64 * max(n, 1))(), (ctypes.c_void_p * max(n, 1))()
         for j, (i, k) in enumerate(zl):
             dsts[j], vs[j], nd[j] = self.gbuf.data_ptr() + 4 * self.offs[i], self.sizes[i] // 32, flags[i].data_ptr()
+        for j, (g, pv) in enumerate(self.nat_persist.values()):      # persistent native gradients: the blocks touched one replay ago
+            dsts[len(zl) + j], vs[len(zl) + j], nd[len(zl) + j] = g.data_ptr(), g.numel() // 32, pv.data_ptr()
         return n, dsts, vs, nd
 
 
@@ -784,7 +855,9 @@ class _RenderFn(torch.autograd.Function):
         dims = {k: (vmg[k].dims if k in vmg else tuple(g.shape[2:])) for k, g in zip(plan.kinds, grids)}
         # grids without gradient (tracker, render_img, Mesher): one full conversion per grid version, cached -- the map
         # does not change between the camera iterations of a frame, so nothing is marked or converted per call
-        static = [(i, k) for i, k in enumerate(plan.kinds) if k not in vmg and not ctx.needs_input_grad[5 + i]]
+        # grids in the kernels' own layout (channels_last_3d tensors): read where they lie, never converted
+        native = {k for i, k in enumerate(plan.kinds) if k not in vmg and is_native_grid(grids[i])}
+        static = [(i, k) for i, k in enumerate(plan.kinds) if k not in vmg and k not in native and not ctx.needs_input_grad[5 + i]]
         dense = [(i, k) for i, k in enumerate(plan.kinds) if k not in vmg and ctx.needs_input_grad[5 + i]]
         nblk = [(dims[k][0] * dims[k][1] * dims[k][2] + 63) // 64 for _, k in dense]
         # A captured training step (fused render + loss: its backward always follows) needs no zero-fill node at all: the
@@ -796,21 +869,40 @@ class _RenderFn(torch.autograd.Function):
         arena = _ZeroArena(dev, 2 * sum(nblk) + 4 * sum(_lib_size('enslam_packed_floats', k) for k in plan.kinds) + 256 + 32, persistent=cap)
         flags = [None] * nk
         grids_vm, packed = {k: vmg[k].vm for k in vmg}, {}
+        for i, k in enumerate(plan.kinds):
+            if k in native:
+                _check_grid(grids[i])
+                grids_vm[k] = grids[i].detach()
         state = plan.state
         _latest_state[0] = state
         state.flags = {}
+        accum = None
+        if any(ctx.needs_input_grad):
+            accum = _Accumulators(plan, dims, ctx.needs_input_grad, N, dev, lib, native, [id(g) for g in grids])
         msc, fptr = None, None
+        flag_move = None                # (flags, prev flags) of the persistent native gradients: one contiguous range each
         if dense:                       # the sampler marks the blocks of the samples it places
+            # the flags of persistent native gradients sit together, in the order of their `prev` flags (the finish launch moves
+            # them there as one range)
+            order = [j for j, (_i, k) in enumerate(dense) if k in accum.nat_persist] + \
+                    [j for j, (_i, k) in enumerate(dense) if k not in accum.nat_persist]
             flag_buf = arena.take(sum(nblk), torch.uint8)
             fptr = (ctypes.c_void_p * 4)()
             msc = L.Scene()
             msc.bound, msc.coarse_bound = plan.bound6, plan.coarse_bound6
-            for (i, k), fl in zip(dense, flag_buf.split(nblk)):
+            for j, fl in zip(order, flag_buf.split([nblk[j] for j in order])):
+                i, k = dense[j]
                 flags[i] = fl
                 fptr[k] = fl.data_ptr()
                 msc.grids[k].D, msc.grids[k].H, msc.grids[k].W = dims[k]
                 state.flags[id(grids[i])] = fl
-        if plan.z_given is None:
+            if accum.pv_flat is not None:
+                flag_move = (flag_buf[:accum.pv_flat.numel()], accum.pv_flat)
+        conv = [(i, k) for i, k in dense if k not in native]
+        merged = plan.z_given is None and not conv        # nothing to convert: the sampler and the prepare roles in one launch
+        if merged:
+            pass
+        elif plan.z_given is None:
             L.check(lib.enslam_sample_rays(N, plan.n_lin, plan.n_surf, _ptr(ro), _ptr(rd), _ptr(gd), plan.bound6,
                                            _ptr(plan.t_lin), _ptr(plan.t_surf), plan.lindisp, _ptr(t_rand),
                                            _ptr(scratch), int(plan.depth_max is not None), _ptr(z), L.STAGE[plan.stage],
@@ -823,10 +915,10 @@ class _RenderFn(torch.autograd.Function):
             for (i, k), vm in zip(static, _grid_cache.get_many([grids[i] for i, _ in static])):
                 grids_vm[k] = vm
         conv_args = None
-        if dense:
-            dense_grids = [grids[i] for i, _ in dense]
-            vms, conv_args = _grid_cache.get_many_sparse(dense_grids, [flags[i] for i, _ in dense], arena, defer=True, fresh=cap)
-            for (i, k), vm in zip(dense, vms):
+        if conv:
+            conv_grids = [grids[i] for i, _ in conv]
+            vms, conv_args = _grid_cache.get_many_sparse(conv_grids, [flags[i] for i, _ in conv], arena, defer=True, fresh=cap)
+            for (i, k), vm in zip(conv, vms):
                 grids_vm[k] = vm
         po, items = nk, []
         for k in plan.kinds:
@@ -836,11 +928,20 @@ class _RenderFn(torch.autograd.Function):
         for k, pk in zip(plan.kinds, pks):
             packed[k] = pk
         # ONE launch: pack the stale decoders, convert the touched blocks, clear the backward's accumulators
-        accum = _Accumulators(plan, dims, ctx.needs_input_grad, N, dev, lib) if any(ctx.needs_input_grad) else None
         nd_, kinds_, structs_, ptrs_ = pack_args if pack_args is not None else (0, None, None, None)
         nc_, srcs_, dsts_, vs_, needs_, valids_, keep_ = conv_args if conv_args is not None else (0, None, None, None, None, None, None)
         nz_, zd_, zv_, zn_ = accum.zero_args(plan, flags) if accum is not None else (0, None, None, None)
-        if nd_ or nc_ or accum is not None:
+        if merged:
+            L.check(lib.enslam_sample_prepare(N, plan.n_lin, plan.n_surf, _ptr(ro), _ptr(rd), _ptr(gd), plan.bound6,
+                                              _ptr(plan.t_lin), _ptr(plan.t_surf), plan.lindisp, _ptr(t_rand),
+                                              _ptr(scratch), int(plan.depth_max is not None), _ptr(z), L.STAGE[plan.stage],
+                                              ctypes.byref(msc) if msc is not None else None, fptr, 64, None,
+                                              nd_, kinds_, structs_, ptrs_, nz_, zd_, zv_, zn_,
+                                              _ptr(accum.zbuf) if accum is not None else None,
+                                              accum.n_zero if accum is not None else 0, st), "enslam_sample_prepare")
+            if accum is not None:
+                accum.clean = True
+        elif nd_ or nc_ or accum is not None:
             L.check(lib.enslam_step_prepare(nd_, kinds_, structs_, ptrs_, nc_, srcs_, dsts_, vs_, needs_, valids_, nz_, zd_, zv_, zn_,
                                             _ptr(accum.zbuf) if accum is not None else None,
                                             accum.n_zero if accum is not None else 0, st), "enslam_step_prepare")
@@ -893,6 +994,19 @@ class _RenderFn(torch.autograd.Function):
             ctx.sv = (SV, raw_v, z_v)
         ctx.plan, ctx.S, ctx.dims, ctx.act_light, ctx.accum = plan, S, dims, act_light, accum
         ctx.cap_arena = cap
+        ctx.flag_move = flag_move
+        if accum is not None:
+            for i, k in enumerate(plan.kinds):
+                if k in accum.nat_persist:
+                    _capture['persist_need'][id(grids[i])] = flags[i]
+                elif k in accum.nat_again:
+                    # a second render of this grid inside one captured step: its gradient is a fresh buffer that AccumulateGrad adds
+                    # into the first call's persistent one, so the blocks it touches must reach that buffer's `prev` flags whatever the
+                    # order of the two backwards -- joined to the first call's flags here (moved to `prev` by its finish launch if
+                    # that is still to come) and to `prev` itself after this call's backward
+                    need_first = _capture['persist_need'].get(id(grids[i]))
+                    if need_first is not None:
+                        torch.maximum(need_first, flags[i], out=need_first)
         ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act, flags)
         ctx.rgb = rgb if plan.loss is not None else None
         ctx.d_raw_unit = d_raw_unit if plan.loss is not None else None
@@ -949,16 +1063,30 @@ class _RenderFn(torch.autograd.Function):
             if need_grid[k] and k in vmg:
                 gg[k].data = vmg[k].grad_vm.data_ptr()
                 vmg[k].has_grad = True
-        gbase, zbase = gbuf.data_ptr(), zbuf.data_ptr() - 4 * n_grid
+        gbase = gbuf.data_ptr()
         g_grids_vm, g_packed = {}, {}
         for i, k in enumerate(plan.kinds):
             if need_grid[k] and k not in vmg:
                 g_grids_vm[k] = gbase + 4 * offs[i]
                 gg[k].data = g_grids_vm[k]
+        nat = accum.native
         if not accum.clean:
+            # a repeated backward of this call (retain_graph): the flat buffer of the first one backs tensors it returned (ray
+            # gradients, native grid gradients) -- this one adds into a fresh, zero-filled buffer
+            if accum.nat_persist:
+                raise L.EnslamError("a second backward through the same render call inside one captured step is not supported for "
+                                    "channels_last_3d feature grids (their gradient buffer is the graph's own)")
+            zbuf = accum.zbuf = torch.zeros(accum.n_zero, dtype=torch.float32, device=dev)
             n, dsts, vs, need_ptrs = accum.zero_args(plan, flags)
-            L.check(lib.enslam_zero_blocks(n, dsts, vs, need_ptrs, _ptr(zbuf), n_flat, st), "enslam_zero_blocks")
+            if n:
+                L.check(lib.enslam_zero_blocks(n, dsts, vs, need_ptrs, None, 0, st), "enslam_zero_blocks")
         accum.clean = False
+        zbase = zbuf.data_ptr() - 4 * n_grid
+        nat_buf = {}
+        for k in plan.kinds:
+            if nat[k]:
+                nat_buf[k] = accum.native_grad(plan, k)
+                gg[k].data = nat_buf[k].data_ptr()
         # decoder-parameter gradients leave the backward kernel as per-workgroup partial images (summed by the finish launch)
         # instead of 4.4 M float atomics at its tail; ENSLAM_DW_PARTIALS=0 restores the atomics (A/B aid)
         gpart, part_keep = (ctypes.c_void_p * 4)(), {}
@@ -1007,7 +1135,7 @@ class _RenderFn(torch.autograd.Function):
         # cost the mapper step's backward 15 us to save 11 in the finish launch), else computed by the decoder kernel itself at
         # the end of each round -- a tracker iteration (fixed map and decoders) then has no finish launch at all: 104 -> 100 us.
         # ENSLAM_INLINE_RAY_GRAD = 1 / 0 forces one or the other.
-        finish_needed = any((need_grid[k] and k not in plan.vm) or need_par[k] for k in plan.kinds)
+        finish_needed = any((need_grid[k] and k not in plan.vm and not nat[k]) or need_par[k] for k in plan.kinds) or bool(accum.nat_persist)
         inline_rays = (not finish_needed) if INLINE_RAY_GRAD is None else INLINE_RAY_GRAD
         dgw = None
         if act is not None and need_rays and not inline_rays:
@@ -1027,8 +1155,14 @@ class _RenderFn(torch.autograd.Function):
         out = [None, g_ro if needs[1] else None, g_rd if needs[2] else None, None, None]
         # ONE launch: grid gradients back to the callers' [1,32,D,H,W] layout + decoder gradients unpacked into views of
         # one flat buffer shaped like the parameters
-        conv = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k] and k not in vmg]
+        conv = [(i, k) for i, k in enumerate(plan.kinds) if need_grid[k] and k not in vmg and not nat[k]]
         grid_out = {}
+        for i, k in enumerate(plan.kinds):
+            if nat[k]:                                      # (the buffer the backward kernel has just added into)
+                grid_out[k] = _native_grad_view(nat_buf[k], ctx.dims[k])
+                if k in accum.nat_persist:
+                    plan.state.flags[ctx.grid_ids[i]] = accum.nat_persist[k][1]     # readers use `prev` from the finish launch on
+        del nat_buf
         nc = len(conv)
         srcs, dsts, vs = (ctypes.c_void_p * max(nc, 1))(), (ctypes.c_void_p * max(nc, 1))(), (ctypes.c_int64 * max(nc, 1))()
         need_ptrs = (ctypes.c_void_p * max(nc, 1))()
@@ -1086,17 +1220,23 @@ class _RenderFn(torch.autograd.Function):
                 kind_arr[j], pk_arr[j] = k, g_packed[k]
                 part_arr[j] = gpart[k]
                 structs[j], base = _flat_params_struct(k, like_by_kind[k], base)
-        if nc or npk or ray_pending:
-            L.check(lib.enslam_step_finish_partials(nc, srcs, dsts, vs, need_ptrs, prev_ptrs, npk, kind_arr, pk_arr, part_arr, structs,
-                                                    L.STAGE[plan.stage], N if ray_pending else 0, S, _ptr(ro), _ptr(rd), _ptr(z),
-                                                    ctypes.byref(sc), _ptr(dgw) if ray_pending else None, p_ro, p_rd, _ptr(work),
-                                                    _ptr(wcount), st), "enslam_step_finish")
-        for i, k in conv:
-            if ctx.grid_ids[i] in again:                    # (captured: runs at every replay, after the finish launch)
-                pv_first = _capture['persist'][ctx.grid_ids[i]][1]
-                torch.maximum(pv_first, flags[i], out=pv_first)
-                if ctx.cap_arena:
-                    flags[i].zero_()                        # no fill node re-zeroes a captured step's arena
+        mv = ctx.flag_move
+        if nc or npk or ray_pending or mv is not None:
+            L.check(lib.enslam_step_finish_native(nc, srcs, dsts, vs, need_ptrs, prev_ptrs, npk, kind_arr, pk_arr, part_arr, structs,
+                                                  L.STAGE[plan.stage], N if ray_pending else 0, S, _ptr(ro), _ptr(rd), _ptr(z),
+                                                  ctypes.byref(sc), _ptr(dgw) if ray_pending else None, p_ro, p_rd, _ptr(work),
+                                                  _ptr(wcount), _ptr(mv[0]) if mv is not None else None,
+                                                  _ptr(mv[1]) if mv is not None else None, mv[0].numel() if mv is not None else 0, st),
+                    "enslam_step_finish")
+        for i, k in enumerate(plan.kinds):
+            gid = ctx.grid_ids[i]
+            if (need_grid[k] and k not in vmg and not nat[k] and gid in again) or k in accum.nat_again:
+                # (captured: runs at every replay, after the finish launch)
+                pv_first = _capture['persist'][gid][1] if _capture['persist'] is not None and gid in _capture['persist'] else None
+                if pv_first is not None:
+                    torch.maximum(pv_first, flags[i], out=pv_first)
+                    if ctx.cap_arena:
+                        flags[i].zero_()                    # no fill node re-zeroes a captured step's arena
         for k in plan.kinds:
             out += views_by_kind.get(k, [None] * plan.n_params[k])
         return tuple(out)       # (the saved buffers go with the graph; kept so that retain_graph backwards work)

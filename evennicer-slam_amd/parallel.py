@@ -81,6 +81,9 @@ def allreduce_gradients(tensors, group=None, compact_grids=True, block_flags=Non
         return _allreduce_hip(tensors, group, compact_grids, block_flags, prepared)
     if any(isinstance(t, VoxelMajorGrid) for t in tensors):
         raise TypeError("VoxelMajorGrid gradients live on a HIP device")
+    for t in tensors:                       # (CPU route: block views need the [C, V] order)
+        if not t.grad.is_contiguous():
+            t.grad = t.grad.contiguous()
     grid_ids = [i for i, t in enumerate(tensors) if compact_grids and t.dim() == 5 and t.shape[0] == 1]
     plans = {}
     if grid_ids:
@@ -141,9 +144,13 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags, prepared=None):
         if isinstance(t, VoxelMajorGrid):
             g, V, c, layout = t.grad_vm, t.grad_vm.shape[0], t.grad_vm.shape[1], 1
         elif compact_grids and t.dim() == 5 and t.shape[0] == 1:
-            if not t.grad.is_contiguous():
-                t.grad = t.grad.contiguous()
-            g, V, c, layout = t.grad, t.shape[2] * t.shape[3] * t.shape[4], t.shape[1], 0
+            if t.grad.is_contiguous(memory_format=torch.channels_last_3d) and not t.grad.is_contiguous():
+                # gradient of a channels_last_3d grid: its storage is [V][C] (functional.is_native_grid), a block is one run
+                g, V, c, layout = t.grad, t.shape[2] * t.shape[3] * t.shape[4], t.shape[1], 1
+            else:
+                if not t.grad.is_contiguous():
+                    t.grad = t.grad.contiguous()
+                g, V, c, layout = t.grad, t.shape[2] * t.shape[3] * t.shape[4], t.shape[1], 0
         else:
             if not t.grad.is_contiguous():
                 t.grad = t.grad.contiguous()
@@ -159,7 +166,7 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags, prepared=None):
         fbs = next((b for b in (64, 32, 16, 8) if f is not None and f.numel() == (V + b - 1) // b), None)
         if fbs is None or (bs is not None and fbs != bs):
             fbs = bs or 64
-            g2 = g.reshape(c, V) if layout == 0 else g
+            g2 = g.reshape(c, V) if layout == 0 else (g.permute(0, 2, 3, 4, 1).reshape(V, c) if g.dim() == 5 else g)
             nfull = V // fbs
             if layout == 0:
                 f = (g2[:, :nfull * fbs].reshape(c, nfull, fbs) != 0).any(dim=2).any(dim=0).to(torch.uint8)
@@ -210,7 +217,7 @@ def _allreduce_hip(tensors, group, compact_grids, block_flags, prepared=None):
     if grid_items:
         from .functional import note_foreign_blocks
         for gi, ((g, _V, layout, f), seg) in enumerate(zip(grid_items, allf.split([it[3].numel() for it in grid_items]))):
-            if layout == 0:
+            if layout == 0 or g.dim() == 5:
                 if bs != 64:                # the finish launch keeps its flags per 64 voxels: any finer block set -> its 64-block
                     pre_c = getattr(prepared, 'coarse', None) if (prepared is not None and allf is prepared.allf) else None
                     seg = pre_c[gi] if pre_c is not None else _coarsen(seg, 64 // bs)

@@ -251,6 +251,35 @@ int enslam_step_finish_partials(int32_t n_conv, const float *const *src, float *
                                 float *dgrid_ws, float *g_rays_o, float *g_rays_d, const int32_t *work_list,
                                 const int32_t *work_count, void *stream);
 
+/* enslam_step_finish_partials plus the flag hand-over for gradients that live in the kernels' own layout (feature grids given
+ * as channels_last_3d tensors: their storage IS [V][32], nothing is converted on the way in and the gradient buffer the backward
+ * adds into IS the tensor autograd receives, so no transposed-back copy exists whose launch could carry the flags): for the
+ * n_move block flags at move_need (uint8, the flags this step's sampler marked, all such grids back to back) the launch does
+ * move_prev[b] = move_need[b]; move_need[b] = 0.  `move_prev` is what the next step's enslam_sample_prepare clears the
+ * persistent gradient by (zero_need) and what the gradient bucket reads.  n_move = 0: enslam_step_finish_partials. */
+int enslam_step_finish_native(int32_t n_conv, const float *const *src, float *const *dst, const int64_t *n_voxels,
+                              const uint8_t *const *need, uint8_t *const *prev, int32_t n_dec, const int32_t *kinds,
+                              const float *const *packed_grads, const float *const *grad_partials,
+                              const enslam_mlp_params *grads, int32_t stage, int32_t n_rays, int32_t n_samples,
+                              const float *rays_o, const float *rays_d, const double *z_vals, const enslam_scene *scene,
+                              float *dgrid_ws, float *g_rays_o, float *g_rays_d, const int32_t *work_list,
+                              const int32_t *work_count, uint8_t *move_need, uint8_t *move_prev, int64_t n_move, void *stream);
+
+/* enslam_sample_rays_g and enslam_step_prepare (without its conversion role) as ONE launch, for render calls whose
+ * feature grids all arrive in the kernels' own layout: with nothing to convert, no prepare role waits for the sampler's
+ * block marks, and the decoder packing / accumulator clearing run under the sampler's latency (a ray's wave is one dependent
+ * chain of float64 divisions and a 21-step shuffle sort).  Arguments: enslam_sample_rays_g's, then enslam_step_prepare's
+ * (n_dec .. packed, n_zero .. n_flat).  n_rays = 0 runs the prepare roles alone.
+ *   Replaces Renderer.render_batch_ray lines 83-171 (sampling) of the reference; the prepare roles replace nothing. */
+int enslam_sample_prepare(int32_t n_rays, int32_t n_lin, int32_t n_surf, const float *rays_o, const float *rays_d,
+                          const float *gt_depth, const double *bound_host, const float *t_lin, const double *t_surf,
+                          int32_t lindisp, const float *t_rand, float *scratch, int32_t depth_max_given, double *z_vals,
+                          int32_t mark_stage, const enslam_scene *mark_scene, uint8_t *const *mark_flags,
+                          int32_t mark_block_voxels, uint8_t *const *mark_flags64, int32_t n_dec, const int32_t *kinds,
+                          const enslam_mlp_params *params, float *const *packed, int32_t n_zero, float *const *zero_dst,
+                          const int64_t *zero_voxels, const uint8_t *const *zero_need, float *flat, int64_t n_flat,
+                          void *stream);
+
 /* Sample distances along rays (mark_scene / mark_flags non-NULL: also does enslam_mark_blocks' work for stage mark_stage
  * on the samples it has just placed -- one launch less per render call).
  *   Replaces Renderer.render_batch_ray lines 83-171

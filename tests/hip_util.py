@@ -45,3 +45,13 @@ def tiny_on_gpu():
     grids = {k: torch.from_numpy(s[k].copy()).to(DEV) for k in GRID_KEYS}
     rays = {k: torch.from_numpy(s[k].copy()).to(DEV) for k in ('rays_o', 'rays_d', 'gt_depth', 'gt_color')}
     return s, bound, model, grids, rays, renderer_for(bound)
+
+
+def as_layout(t, layout):
+    """a detached copy of grid `t` ([1,32,D,H,W]) in the reference's contiguous layout or in torch.channels_last_3d -- the memory
+    format whose storage is the kernels' own [V][32] (functional.is_native_grid): same shape, values and indexing"""
+    t = t.detach().clone()
+    return t.contiguous(memory_format=torch.channels_last_3d) if layout == 'channels_last_3d' else t
+
+
+LAYOUTS = ['contiguous', 'channels_last_3d']

@@ -119,14 +119,16 @@ def test_render_img_rescale_and_render_img_shapes(room0):
         renderer.H, renderer.W = 680, 1200
 
 
-def test_graphed_step_matches_eager(room0):
+@pytest.mark.parametrize("layout", ['contiguous', 'channels_last_3d'])
+def test_graphed_step_matches_eager(room0, layout):
     """hipGraph capture of render + loss + backward replays to the same loss and gradients as the eager step."""
     import gc
     import bench
     import evennicer_slam_amd.functional as EF
     from evennicer_slam_amd.graph import GraphedStep
+    from tests.hip_util import as_layout
     sc, g, model, grids, renderer, rays = room0
-    leaves = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+    leaves = {k: as_layout(v, layout).requires_grad_(True) for k, v in grids.items()}
     ro = rays['rays_o'].clone().requires_grad_(True)
     rd = rays['rays_d'].clone().requires_grad_(True)
 
@@ -163,7 +165,8 @@ def test_graphed_step_matches_eager(room0):
     assert abs(l2 - loss_e) > 1e-6 * abs(loss_e)
 
 
-def test_persistent_dense_gradients_under_replay(room0):
+@pytest.mark.parametrize("layout", ['contiguous', 'channels_last_3d'])
+def test_persistent_dense_gradients_under_replay(room0, layout):
     """Under capture the dense grid gradients are the same memory at every replay and the finish launch only rewrites
     the blocks touched now or one replay earlier (enslam_step_finish_rays_prev).  Replays with DIFFERENT rays must leave
     exactly what an eager step on those rays produces: zeros where no ray came near -- also where the previous replay's
@@ -172,8 +175,9 @@ def test_persistent_dense_gradients_under_replay(room0):
     import bench
     import evennicer_slam_amd.functional as EF
     from evennicer_slam_amd.graph import GraphedStep
+    from tests.hip_util import as_layout
     sc, g, model, grids, renderer, rays = room0
-    leaves = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+    leaves = {k: as_layout(v, layout).requires_grad_(True) for k, v in grids.items()}
     eager = {k: v.clone().requires_grad_(True) for k, v in grids.items()}   # (own leaves: the replayed step's .grad stay attached)
     static = [t.clone() for t in (rays['rays_o'], rays['rays_d'], rays['gt_depth'], rays['gt_color'])]
 
@@ -198,7 +202,9 @@ def test_persistent_dense_gradients_under_replay(room0):
             dst.copy_(src)
         loss_g = gs.replay().item()
         torch.cuda.synchronize()
-        got = {k: leaves[k].grad.clone() for k in names}
+        got = {k: leaves[k].grad.contiguous() for k in names}
+        if layout == 'channels_last_3d':
+            assert all(leaves[k].grad.is_contiguous(memory_format=torch.channels_last_3d) for k in names)
         loss_e = run(eager, *new).item()
         assert abs(loss_g - loss_e) < 1e-6 * abs(loss_e)
         nz = {}
@@ -240,14 +246,16 @@ def test_fused_rgbd_loss_matches_torch(room0):
             assert torch.allclose(a, b.to(a.dtype), rtol=1e-6, atol=1e-7)
 
 
-def test_two_backwards_into_one_grid_inside_a_captured_step():
+@pytest.mark.parametrize("order", ['interleaved', 'forwards_first'])
+@pytest.mark.parametrize("layout", ['contiguous', 'channels_last_3d'])
+def test_two_backwards_into_one_grid_inside_a_captured_step(layout, order):
     """AccumulateGrad adds a second backward's gradient into the first one's persistent buffer; the blocks only
     the second call touched must be cleared by the next replay as well."""
     import evennicer_slam_amd as E
     from evennicer_slam_amd.graph import GraphedStep
-    from tests.hip_util import DEV, tiny_on_gpu
+    from tests.hip_util import DEV, as_layout, tiny_on_gpu
     s, bound, model, grids, rays, renderer = tiny_on_gpu()
-    g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+    g = {k: as_layout(v, layout).requires_grad_(True) for k, v in grids.items()}
     ro, rd, gd, gc = [rays[k].clone() for k in ('rays_o', 'rays_d', 'gt_depth', 'gt_color')]
     base = [t.clone() for t in (ro, rd, gd, gc)]
     leaves = [g[k] for k in ('grid_middle', 'grid_fine', 'grid_color')]
@@ -255,9 +263,14 @@ def test_two_backwards_into_one_grid_inside_a_captured_step():
     def step():
         for t in leaves:
             t.grad = None
+        losses = []
         for sl in (slice(0, 32), slice(32, 64)):
             d, v, c = renderer.render_batch_ray(g, model, rd[sl], ro[sl], DEV, 'color', gt_depth=gd[sl])
-            E.losses.rgbd_loss(d, c, gd[sl], gc[sl], 0.2).backward()
+            losses.append(E.losses.rgbd_loss(d, c, gd[sl], gc[sl], 0.2))
+            if order == 'interleaved':                      # forward 1, backward 1, forward 2, backward 2
+                losses.pop().backward()
+        if losses:                                          # forward 1, forward 2, then one backward through both
+            (losses[0] + losses[1]).backward()
 
     gs = GraphedStep(step)
     for it in range(4):
@@ -265,7 +278,7 @@ def test_two_backwards_into_one_grid_inside_a_captured_step():
             t.copy_(torch.roll(b, 16 * it, 0) if it < 3 else b)
         gs.replay()
         torch.cuda.synchronize()
-        got = [t.grad.clone() for t in leaves]
+        got = [t.grad.contiguous().clone() for t in leaves]
         g2 = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
         for sl in (slice(0, 32), slice(32, 64)):
             d, v, c = renderer.render_batch_ray(g2, model, rd[sl], ro[sl], DEV, 'color', gt_depth=gd[sl])

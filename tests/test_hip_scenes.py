@@ -78,10 +78,11 @@ def _check_grads(g, model, cg, ro, rd):
         assert rel_err(gg[idx].cpu().numpy(), g[f"gval_{key}"]) < 1e-3, key
 
 
-def _leaves(model, grids, rays):
+def _leaves(model, grids, rays, layout='contiguous'):
+    from tests.hip_util import as_layout
     for p in model.parameters():
         p.grad = None
-    cg = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+    cg = {k: as_layout(v, layout).requires_grad_(True) for k, v in grids.items()}
     ro = rays['rays_o'].clone().requires_grad_(True)
     rd = rays['rays_d'].clone().requires_grad_(True)
     return cg, ro, rd
@@ -118,27 +119,32 @@ def test_decoder_outputs_of_256_rays(scene):
     assert np.all(np.abs(raw.cpu().numpy()[:, 3] - ref[:, 3]) <= 1e-4 * np.abs(ref[:, 3]) + 1e-5 * np.abs(ref[:, 3]).max())
 
 
-def test_autograd_path_against_reference(scene):
-    """render_batch_ray + the mapper loss in torch ops + backward (what a caller of the reference API runs)."""
+@pytest.mark.parametrize("layout", ['contiguous', 'channels_last_3d'])
+def test_autograd_path_against_reference(scene, layout):
+    """render_batch_ray + the mapper loss in torch ops + backward (what a caller of the reference API runs); with the feature
+    grids in the reference's contiguous layout and as channels_last_3d tensors (read in place, gradients in the same format)."""
     import bench
     tag, sc, g, model, grids, renderer, rays = scene
-    cg, ro, rd = _leaves(model, grids, rays)
+    cg, ro, rd = _leaves(model, grids, rays, layout)
     depth, var, color = renderer.render_batch_ray(cg, model, rd, ro, 'cuda:0', 'color', gt_depth=rays['gt_depth'])
     loss = bench.mapper_loss(depth, color, rays['gt_depth'], rays['gt_color'], 'color')
     loss.backward()
     _check_outputs(g, depth, var, color, loss.item())
     _check_grads(g, model, cg, ro, rd)
+    if layout == 'channels_last_3d':
+        for k in ('grid_middle', 'grid_fine', 'grid_color'):
+            assert cg[k].grad.is_contiguous(memory_format=torch.channels_last_3d) and cg[k].grad.shape == cg[k].shape, k
 
 
-@pytest.mark.parametrize("work_list", [True, False])
-def test_bench_step_against_reference(scene, work_list):
+@pytest.mark.parametrize("work_list,layout", [(True, 'contiguous'), (False, 'contiguous'), (True, 'channels_last_3d')])
+def test_bench_step_against_reference(scene, work_list, layout):
     """The exact step bench.py times: caches cleared, render_batch_ray_rgbd_loss (loss folded into the compositing
     launches, backward starting at the decoders from unit gradients), work list of non-zero tiles, captured in ONE
     hipGraph and replayed -- loss and every gradient against the reference fixture, with the work list on and off."""
     import evennicer_slam_amd.functional as EF
     from evennicer_slam_amd.graph import GraphedStep
     tag, sc, g, model, grids, renderer, rays = scene
-    cg, ro, rd = _leaves(model, grids, rays)
+    cg, ro, rd = _leaves(model, grids, rays, layout)
     leaves = list(cg.values()) + [ro, rd] + list(model.parameters())
     out = {}
     one = {}
