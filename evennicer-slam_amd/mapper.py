@@ -16,7 +16,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .functional import VoxelMajorGrid, _ptr, _require_hip, _stream, note_raw_write
+from .functional import VoxelMajorGrid, _native_vm, _ptr, _require_hip, _stream, is_native_grid, note_raw_write
 
 GRID_KEYS = ('grid_coarse', 'grid_middle', 'grid_fine', 'grid_color')
 
@@ -35,6 +35,7 @@ class MaskedGridOptimizer:
         self.c, self.keys = c, tuple(keys)
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
         self.grids, self.mask, self.mask5, self.m, self.v = {}, {}, {}, {}, {}
+        self.native = set()
         masks = masks or {}
         dev = None
         for key in self.keys:
@@ -45,9 +46,16 @@ class MaskedGridOptimizer:
             dev = g.device
             D, H, W = (int(x) for x in g.shape[2:])
             V = D * H * W
-            vm = torch.empty((V, 32), dtype=torch.float32, device=dev)
-            L.check(lib.enslam_grid_to_voxel_major(_ptr(g.detach().contiguous()), _ptr(vm), V, _stream()),
-                    "enslam_grid_to_voxel_major")
+            if is_native_grid(g):
+                # a channels_last_3d grid IS [V,32] in memory: the optimiser works on the caller's tensor itself (its masked
+                # voxels change in place every step, as `val[mask] = val_grad; c[key] = val` does in the reference's loop,
+                # Mapper.py:448-458) and write_back() has nothing left to copy
+                vm = _native_vm(g)
+                self.native.add(key)
+            else:
+                vm = torch.empty((V, 32), dtype=torch.float32, device=dev)
+                L.check(lib.enslam_grid_to_voxel_major(_ptr(g.detach().contiguous()), _ptr(vm), V, _stream()),
+                        "enslam_grid_to_voxel_major")
             self.grids[key] = VoxelMajorGrid((D, H, W), vm, torch.zeros((V, 32), dtype=torch.float32, device=dev))
             mk = masks.get(key)
             if mk is not None:
@@ -114,10 +122,14 @@ class MaskedGridOptimizer:
             st[i] = self.step_t.data_ptr() + 4 * i
         L.check(lib.enslam_adam_masked(n, p, g, m, v, mk, vs, lr, st, self.betas[0], self.betas[1], self.eps, _stream()),
                 "enslam_adam_masked")
+        if self.native:                                 # the caller's own tensors have just changed in place
+            note_raw_write([self.c[k] for k in self.keys if k in self.native])
 
     def grid(self, key):
         """Current values of one grid as a fresh float32 [1,32,D,H,W] tensor (layout conversion; for inspection)."""
         G = self.grids[key]
+        if key in self.native:
+            return self.c[key].detach().contiguous()
         out = torch.empty((1, 32) + G.dims, dtype=torch.float32, device=G.vm.device)
         L.check(L.lib().enslam_grid_from_voxel_major(_ptr(G.vm), _ptr(out), G.vm.shape[0], _stream()),
                 "enslam_grid_from_voxel_major")
@@ -127,6 +139,8 @@ class MaskedGridOptimizer:
         """val[mask] = val_grad (Mapper.py:596-602): optimised voxels into the caller's tensors, in place."""
         with torch.no_grad():
             for k in self.keys:
+                if k in self.native:
+                    continue                            # (optimised in place)
                 new = self.grid(k)
                 if self.mask5[k] is None:
                     self.c[k].copy_(new)

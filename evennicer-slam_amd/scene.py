@@ -29,8 +29,13 @@ def grid_shapes(bound, grid_len, coarse_bound_enlarge=2):
     return out
 
 
-def grid_init(bound, grid_len, c_dim=32, coarse_bound_enlarge=2, device='cpu', std=None):
-    """Feature grids [1,c_dim,D,H,W] ~ N(0, std): 0.01 (fine: 1e-4) as EvenNICER_SLAM.py:248-272."""
+def grid_init(bound, grid_len, c_dim=32, coarse_bound_enlarge=2, device='cpu', std=None, memory_format=None):
+    """Feature grids [1,c_dim,D,H,W] ~ N(0, std): 0.01 (fine: 1e-4) as EvenNICER_SLAM.py:248-272.
+    memory_format=torch.channels_last_3d: the same tensors (shape, values, indexing) stored voxel-major -- the layout the HIP
+    kernels gather from, so nothing is converted per render call (functional.is_native_grid)."""
     std = std or {'grid_coarse': 0.01, 'grid_middle': 0.01, 'grid_fine': 0.0001, 'grid_color': 0.01}
     shapes = grid_shapes(bound, grid_len, coarse_bound_enlarge)
-    return {k: torch.zeros([1, c_dim, *shapes[k]]).normal_(mean=0, std=std[k]).to(device) for k in GRID_KEYS}
+    out = {k: torch.zeros([1, c_dim, *shapes[k]]).normal_(mean=0, std=std[k]).to(device) for k in GRID_KEYS}
+    if memory_format is not None:
+        out = {k: v.contiguous(memory_format=memory_format) for k, v in out.items()}
+    return out

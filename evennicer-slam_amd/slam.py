@@ -88,7 +88,11 @@ class SLAM:
         for name in ('middle_decoder', 'fine_decoder', 'color_decoder'):
             getattr(self.shared_decoders, name).bound = self.bound
         self.shared_decoders.coarse_decoder.bound = self.bound * cfg['model']['coarse_bound_enlarge']
-        self.shared_c = grid_init(self.bound, cfg['grid_len'], cfg['model']['c_dim'], cfg['model']['coarse_bound_enlarge'], device)
+        # channels_last_3d: the reference's grid tensors stored voxel-major (read in place by the kernels; cfg['grid_memory_format']
+        # = 'contiguous' keeps the reference's strides)
+        mf = None if (cfg.get('grid_memory_format', 'channels_last_3d') == 'contiguous' or str(device) == 'cpu') else torch.channels_last_3d
+        self.shared_c = grid_init(self.bound, cfg['grid_len'], cfg['model']['c_dim'], cfg['model']['coarse_bound_enlarge'], device,
+                                  memory_format=mf)
         n = len(dataset)
         self.n_img = n
         self.estimate_c2w_list = torch.zeros((n, 4, 4))

@@ -146,7 +146,7 @@ def test_two_rank_allreduce_of_hip_gradients():
         assert o['nbytes'] == 4 * (32 * 64 * (3 + 2) + 10)
 
 
-def _shard_worker(rank, world, port, q, block_voxels=64):
+def _shard_worker(rank, world, port, q, block_voxels=64, layout='contiguous'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
@@ -154,10 +154,10 @@ def _shard_worker(rank, world, port, q, block_voxels=64):
     try:
         import evennicer_slam_amd as E
         from evennicer_slam_amd import parallel as PAR
-        from tests.hip_util import DEV, tiny_on_gpu
+        from tests.hip_util import DEV, as_layout, tiny_on_gpu
         from tests.util import GRID_KEYS
         s, bound, model, grids, rays, renderer = tiny_on_gpu()
-        g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+        g = {k: as_layout(v, layout).requires_grad_(True) for k, v in grids.items()}
         ro, rd, gd, gc = rays['rays_o'], rays['rays_d'], rays['gt_depth'], rays['gt_color']
         leaves = [g[k] for k in ('grid_middle', 'grid_fine', 'grid_color')] + list(model.color_decoder.parameters())
         # every rank holds the whole batch: union of the touched blocks and the bucket layout before the local step
@@ -180,8 +180,8 @@ def _shard_worker(rank, world, port, q, block_voxels=64):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("block_voxels", [64, 16])
-def test_two_rank_sharded_step_with_local_union_flags_matches_unsharded(block_voxels):
+@pytest.mark.parametrize("block_voxels,layout", [(64, 'contiguous'), (16, 'contiguous'), (16, 'channels_last_3d')])
+def test_two_rank_sharded_step_with_local_union_flags_matches_unsharded(block_voxels, layout):
     """Ray-sharded step on HIP tensors, 2 ranks: the union of touched blocks marked locally over the whole batch
     (batch_block_flags, at 64 or 16 voxels per block), bucket layout prepared before the step (PreparedFlags), ONE
     collective -- the summed gradients equal the unsharded step's."""
@@ -191,7 +191,8 @@ def test_two_rank_sharded_step_with_local_union_flags_matches_unsharded(block_vo
     world, port = 2, 37500 + (os.getpid() % 2000)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shard_worker, args=(r, world, port + block_voxels, q, block_voxels)) for r in range(world)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port + block_voxels + (7 if layout != 'contiguous' else 0), q, block_voxels, layout))
+             for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=600) for _ in range(world)], key=lambda o: o['rank'])
@@ -213,7 +214,7 @@ def test_two_rank_sharded_step_with_local_union_flags_matches_unsharded(block_vo
         assert np.array_equal(a, b)                         # replicas hold identical sums
 
 
-def _replay_worker(rank, world, port, q):
+def _replay_worker(rank, world, port, q, layout='contiguous'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
@@ -222,9 +223,9 @@ def _replay_worker(rank, world, port, q):
         import evennicer_slam_amd as E
         from evennicer_slam_amd import parallel as PAR
         from evennicer_slam_amd.graph import GraphedStep
-        from tests.hip_util import DEV, tiny_on_gpu
+        from tests.hip_util import DEV, as_layout, tiny_on_gpu
         s, bound, model, grids, rays, renderer = tiny_on_gpu()
-        g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+        g = {k: as_layout(v, layout).requires_grad_(True) for k, v in grids.items()}
         ro, rd, gd, gc = [rays[k].clone() for k in ('rays_o', 'rays_d', 'gt_depth', 'gt_color')]
         base = [t.clone() for t in (ro, rd, gd, gc)]
         leaves = [g[k] for k in ('grid_middle', 'grid_fine', 'grid_color')] + list(model.color_decoder.parameters())
@@ -252,7 +253,8 @@ def _replay_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_graph_replay_with_allreduce_keeps_foreign_blocks_clean():
+@pytest.mark.parametrize("layout", ['contiguous', 'channels_last_3d'])
+def test_two_rank_graph_replay_with_allreduce_keeps_foreign_blocks_clean(layout):
     """under hipGraph replay the dense grid gradients are persistent buffers of which the finish launch
     rewrites only the blocks this rank touched now or one replay earlier; the all-reduce's unpack writes the union over ranks
     into the same buffers.  Four replays with changing rays + allreduce_gradients after each must equal the unsharded eager
@@ -263,7 +265,7 @@ def test_two_rank_graph_replay_with_allreduce_keeps_foreign_blocks_clean():
     world, port = 2, 39500 + (os.getpid() % 2000)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_replay_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_replay_worker, args=(r, world, port + (11 if layout != 'contiguous' else 0), q, layout)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=900) for _ in range(world)], key=lambda o: o['rank'])

@@ -12,12 +12,13 @@ KEYS = ('grid_middle', 'grid_fine', 'grid_color')
 STAGE_LR = {'middle': (0.0, 0.1, 0.0, 0.0), 'fine': (0.0, 0.005, 0.005, 0.0), 'color': (0.005, 0.005, 0.005, 0.005)}
 
 
-def _run(graph_free=True):
+def _run(graph_free=True, layout='contiguous'):
     import evennicer_slam_amd as E
     from evennicer_slam_amd.mapper import MaskedGridOptimizer
-    from tests.hip_util import DEV, tiny_on_gpu
+    from tests.hip_util import DEV, as_layout, tiny_on_gpu
     g = load("tiny_mapper_iters")
     s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    grids = {k: as_layout(v, layout) for k, v in grids.items()}
     masks = {k: torch.from_numpy(g['mask_' + k]).to(DEV) for k in KEYS}
     before = {k: grids[k].clone() for k in KEYS}
     opt = MaskedGridOptimizer(grids, masks, keys=KEYS)
@@ -47,8 +48,11 @@ def _run(graph_free=True):
     return g, s, grids, before, model, losses, opt
 
 
-def test_mapper_iterations_match_reference_fixture():
-    g, s, grids, before, model, losses, opt = _run()
+@pytest.mark.parametrize("layout", ['contiguous', 'channels_last_3d'])
+def test_mapper_iterations_match_reference_fixture(layout):
+    """layout channels_last_3d: the optimiser works on the caller's tensors themselves (their storage is the device layout)"""
+    g, s, grids, before, model, losses, opt = _run(layout=layout)
+    assert opt.native == (set(KEYS) if layout == 'channels_last_3d' else set())
     assert np.abs(np.array(losses) - g['losses']).max() <= 1e-4 * np.abs(g['losses']).max()
     for k in KEYS:
         ref = g['final_' + k]
