@@ -65,6 +65,9 @@ _SIGS = {
     "enslam_adam_tensors": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                            POINTER(c_int64), c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, c_void_p]),
+    "enslam_adam_tensors_step": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                           POINTER(c_int64), c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_double, c_void_p]),
     "enslam_bucket_pack": (ctypes.c_int, [c_int32, POINTER(c_void_p), c_int32, POINTER(c_int64), POINTER(c_int32), c_void_p,
                                           c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64), c_int64, c_void_p, c_void_p]),
     "enslam_bucket_unpack": (ctypes.c_int, [c_int32, POINTER(c_void_p), c_int32, POINTER(c_int64), POINTER(c_int32), c_void_p,
@@ -149,6 +152,15 @@ _SIGS = {
                                              c_int32, POINTER(c_int32), POINTER(MlpParams), POINTER(c_void_p),
                                              c_int32, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), c_void_p, c_int64,
                                              c_void_p]),
+    "enslam_tracker_rays": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                           ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, POINTER(c_double), c_int32,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int32, c_void_p]),
+    "enslam_tracker_tail_max_rays": (ctypes.c_int, []),
+    "enslam_render_tracker_loss_fwd": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(Scene),
+                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                                      ctypes.c_float, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                      c_void_p, c_void_p]),
     "enslam_rgbd_loss_fwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,
                                             c_void_p]),
     "enslam_rgbd_loss_bwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,

@@ -495,14 +495,27 @@ int enslam_adam_masked(int32_t n, float* const* param, float* const* grad, float
     return ens_launch_adam(job, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
 
+static int adam_tensors_impl(int32_t n, float* const* param, const float* const* grad, float* const* exp_avg,
+                             float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int32_t* step,
+                             double beta1, double beta2, double eps, void* stream, int self_inc);
 int enslam_adam_tensors(int32_t n, float* const* param, const float* const* grad, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int32_t* step,
                         double beta1, double beta2, double eps, void* stream) {
+    return adam_tensors_impl(n, param, grad, exp_avg, exp_avg_sq, numel, lr, step, beta1, beta2, eps, stream, 0);
+}
+int enslam_adam_tensors_step(int32_t n, float* const* param, const float* const* grad, float* const* exp_avg,
+                             float* const* exp_avg_sq, const int64_t* numel, const double* lr, int32_t* step,
+                             double beta1, double beta2, double eps, void* stream) {
+    return adam_tensors_impl(n, param, grad, exp_avg, exp_avg_sq, numel, lr, step, beta1, beta2, eps, stream, 1);
+}
+static int adam_tensors_impl(int32_t n, float* const* param, const float* const* grad, float* const* exp_avg,
+                             float* const* exp_avg_sq, const int64_t* numel, const double* lr, const int32_t* step,
+                             double beta1, double beta2, double eps, void* stream, int self_inc) {
     if (n == 0) return ENSLAM_OK;
     if (n < 0 || n > ENS_ADAM_MAX_TENSORS) return ENSLAM_EUNSUPPORTED;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !numel || !lr || !step) return ENSLAM_EINVAL;
     AdamTensorsJob job;
-    job.n = n; job.beta1 = beta1; job.beta2 = beta2; job.eps = eps; job.lr = lr; job.step = step;
+    job.n = n; job.beta1 = beta1; job.beta2 = beta2; job.eps = eps; job.lr = lr; job.step = step; job.self_inc = self_inc;
     int64_t blocks = 0;
     for (int i = 0; i < n; ++i) {
         if (!param[i] || !grad[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 0 || numel[i] > 0x7fffffff) return ENSLAM_EINVAL;
@@ -513,6 +526,7 @@ int enslam_adam_tensors(int32_t n, float* const* param, const float* const* grad
         if (blocks > 0x7fffffff) return ENSLAM_EUNSUPPORTED;
     }
     job.block_begin[n] = (int)blocks;
+    if (self_inc && blocks != 1) return ENSLAM_EUNSUPPORTED;   // the count is read and replaced inside ONE workgroup
     return ens_launch_adam_tensors(job, (hipStream_t)stream) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
 }
 
@@ -728,6 +742,48 @@ int enslam_render_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, con
                                          (hipStream_t)stream, &ls, work_list ? &wl : nullptr);
     return rc == 0 ? ENSLAM_OK : (rc == -1 ? ENSLAM_EUNSUPPORTED : ENSLAM_ELAUNCH);
 }
+int enslam_render_tracker_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
+                                   const double* z_vals, const enslam_scene* scene, double* depth, double* var, float* rgb,
+                                   float* raw_out, float* act_ws, int32_t act_light, const float* gt_depth, const float* gt_color,
+                                   float w_color, const uint8_t* inside, int32_t handle_dynamic, double* tmp_scratch, int32_t* ticket,
+                                   double* loss, float* d_raw_unit, int32_t* work_list, int32_t* work_count, void* stream) {
+    if (n_rays < 0) return ENSLAM_EINVAL;
+    if (n_rays == 0) return ENSLAM_OK;
+    if (!samples_ok(n_samples) || n_rays > ENS_TRACKER_TAIL_MAX_RAYS || stage == ENSLAM_STAGE_COARSE) return ENSLAM_EUNSUPPORTED;
+    DevScene d;
+    if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
+    if (!rays_o || !rays_d || !z_vals || !depth || !var || !rgb || !raw_out || !gt_depth || !loss || !tmp_scratch || (handle_dynamic && !ticket))
+        return ENSLAM_EINVAL;
+    if (act_ws != nullptr)
+        for (int k = 1; k < 4; ++k)
+            if (d.grid[k].data && (int64_t)d.grid[k].D * d.grid[k].H * d.grid[k].W >= ACT_MAX_VOXELS) return ENSLAM_EUNSUPPORTED;
+    const LossSpec ls{gt_depth, gt_color, w_color, loss, nullptr, d_raw_unit};
+    const TrackerSpec ts{inside, handle_dynamic != 0 ? 1 : 0, tmp_scratch, ticket};
+    WorkList wl;
+    if (!work_list_of(work_list, work_count, wl) || (work_list && !d_raw_unit)) return ENSLAM_EINVAL;
+    const int rc = ens_launch_render_fwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, nullptr, 0, 1, d, depth, var, rgb,
+                                         raw_out, act_ws, act_light != 0, (hipStream_t)stream, &ls, work_list ? &wl : nullptr, &ts);
+    return rc == 0 ? ENSLAM_OK : (rc == -1 ? ENSLAM_EUNSUPPORTED : ENSLAM_ELAUNCH);
+}
+int enslam_tracker_tail_max_rays(void) { return ENS_TRACKER_TAIL_MAX_RAYS; }
+
+int enslam_tracker_rays(int32_t n, const float* camera_tensor, const int64_t* pixel_index, int32_t H0, int32_t W0, int32_t window_w,
+                        int32_t image_w, int32_t image_h, const float* depth_image, const void* color_image, int32_t color_is_f64, float fx, float fy,
+                        float cx, float cy, const double* bound_host, int32_t prefilter, float* pix_i, float* pix_j, float* rays_o,
+                        float* rays_d, float* gt_depth, float* gt_color, uint8_t* inside, float* depth_max, int32_t* draw_counter,
+                        int32_t n_draws, void* stream) {
+    if (n < 0 || window_w <= 0 || image_w <= 0 || image_h <= 0 || H0 < 0 || W0 < 0 || W0 + window_w > image_w || H0 >= image_h ||
+        (draw_counter && n_draws < 1))
+        return ENSLAM_EINVAL;
+    if (n == 0) return ENSLAM_OK;
+    if (!camera_tensor || !pixel_index || !depth_image || !color_image || !bound_host || !pix_i || !pix_j || !rays_o || !rays_d ||
+        !gt_depth || !gt_color || !depth_max || (prefilter && !inside))
+        return ENSLAM_EINVAL;
+    return ens_launch_tracker_rays(n, camera_tensor, pixel_index, H0, W0, window_w, image_w, image_h, depth_image, color_image, color_is_f64, fx, fy,
+                                   cx, cy, bound_host, pix_i, pix_j, rays_o, rays_d, gt_depth, gt_color, prefilter ? inside : nullptr,
+                                   depth_max, (hipStream_t)stream, draw_counter, n_draws) == 0 ? ENSLAM_OK : ENSLAM_ELAUNCH;
+}
+
 int enslam_composite_loss_bwd(int32_t n_rays, int32_t n_samples, const float* raw, const double* z_vals,
                               const double* depth, const float* rgb, const float* gt_depth, const float* gt_color,
                               float w_color, const double* g_loss, float* d_raw, int32_t* work_list, int32_t* work_count,

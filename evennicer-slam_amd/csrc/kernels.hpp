@@ -15,6 +15,14 @@ struct LossSpec {
     float* d_raw_unit;           // forward (optional): d(loss)/d(raw) for g_loss = 1, [N*S,4] -- lets the backward start at the
                                  // decoders (ens_launch_decoder_bwd's draw_scale = g_loss) without a compositing launch
 };
+// Tracker's RGB-D loss (Tracker.py:176-195) folded into the compositing launch: the LossSpec fields gd / gc / w / loss /
+// d_raw_unit as for the mapper loss, plus what only the tracker has
+struct TrackerSpec {
+    const uint8_t* inside;       // [N] rays the in-bound prefilter keeps (Tracker.py:164-174, applied as a mask) or null: all
+    int dynamic;                 // handle_dynamic (:180-182): keep rays with tmp < 10 * median(tmp over the kept rays)
+    double* tmp;                 // [N + 1] scratch: |gd - depth| / sqrt(var + 1e-10), then the median
+    int* ticket;                 // [1] workgroup counter, 0 on entry, left at 0 (dynamic only)
+};
 // Work list of the saved-activation backward: the 16-sample tiles (ray * ntl + tl) whose d_raw is not all zero, appended
 // ray by ray (a ray's tiles stay adjacent) by the kernel that produces d_raw; count[0] must be zero before that kernel.
 // Behind a converged surface the transmittance underflows to 0 and the far tiles of most rays drop out.
@@ -63,7 +71,8 @@ struct AdamTensorsJob {          // torch.optim.Adam over a list of small dense 
     int n;
     double beta1, beta2, eps;
     const double* lr;            // device scalar
-    const int* step;             // device scalar (already incremented)
+    const int* step;             // device scalar (already incremented; self_inc: the count BEFORE this step)
+    int self_inc;                // single-workgroup jobs only: use step[0] + 1 and store it back (no separate increment launch)
 };
 // Gradient bucket of the ray-sharded step (parallel.py): the touched 64-voxel blocks of up to 4 feature-grid gradients
 // followed by up to ENS_ADAM_MAX_TENSORS small dense tensors, packed into / unpacked from one flat all-reduce buffer.
@@ -152,10 +161,17 @@ int ens_launch_sincos(int64_t n, const float* x, float* s, float* c, hipStream_t
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
                           double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st,
-                          const LossSpec* ls = nullptr, const WorkList* wl = nullptr);
+                          const LossSpec* ls = nullptr, const WorkList* wl = nullptr, const TrackerSpec* ts = nullptr);
 int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* z, double* depth, double* var,
                              float* rgb, float* weights, hipStream_t st, const LossSpec* ls = nullptr,
                              const WorkList* wl = nullptr);
+constexpr int ENS_TRACKER_TAIL_MAX_RAYS = 4096;       // one workgroup sorts the batch in LDS for the median
+int ens_launch_tracker_tail(int n_rays, int S, const float* raw, const double* z, double* depth, double* var, float* rgb,
+                            const LossSpec& ls, const TrackerSpec& ts, const WorkList* wl, hipStream_t st);
+int ens_launch_tracker_rays(int n, const float* ct, const int64_t* idx, int H0, int W0, int ww, int Wimg, int Himg, const float* depth,
+                            const void* color, int color_f64, float fx, float fy, float cx, float cy, const double* bound,
+                            float* oi, float* oj, float* ro, float* rd, float* gd, float* gc, uint8_t* inside, float* dmax,
+                            hipStream_t st, int* iter = nullptr, int iter_count = 0);
 int ens_launch_composite_bwd(int n_rays, int S, const float* raw, const double* z, const double* depth,
                              const double* g_depth, const double* g_var, const float* g_rgb, float* d_raw,
                              hipStream_t st, const LossSpec* ls = nullptr, const float* rgb = nullptr,

@@ -722,6 +722,218 @@ __global__ __launch_bounds__(1024) void composite_fwd_kernel(int n_rays, int S, 
     }
 }
 
+// The tracker's RGB-D loss on top of the compositing, forward and backward, in TWO launches of 16 rays per workgroup (batches of
+// up to ENS_TRACKER_TAIL_MAX_RAYS rays):
+//   tracker_composite_kernel: raw2outputs_nerf_color per ray (one wave per ray) and
+//       tmp = |gd - depth| / sqrt(var + 1e-10)                               (Tracker.py:179-181, float64 like the reference);
+//     the workgroup that finishes LAST (a ticket counter) sorts tmp over the inside rays in LDS and leaves the median
+//     (torch.median: the lower middle element) behind tmp's n entries -- no second launch and no waiting for it
+//   tracker_loss_kernel:
+//       keep = inside & (tmp < 10 * median)                                   (:164-174 as a mask, :180-182)
+//       loss = sum_{keep & gd > 0} tmp + w * sum_{keep & gd > 0} |gc - color| (:187-195)
+//     and d(loss)/d(raw) for a unit loss gradient (the variance is detached, :179), the work list of active tiles appended on
+//     the way.
+// The torch formulation of the same tail is 25-30 launches (sort, gather, where, two loss kernels, compositing backward).  (One
+// single-workgroup launch for everything was 60 us at 200 rays: 13 dependent rounds of 16 rays, each a chain of global loads, a
+// returning atomic and two barriers.)
+__global__ __launch_bounds__(1024) void tracker_composite_kernel(int n_rays, int S, const float* __restrict__ raw,
+                                                                 const double* __restrict__ z_vals, double* __restrict__ depth,
+                                                                 double* __restrict__ var, float* __restrict__ rgb,
+                                                                 const float* __restrict__ gd, TrackerSpec ts) {
+    __shared__ double srt[ENS_TRACKER_TAIL_MAX_RAYS];
+    __shared__ int s_last, s_cnt[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool valid = lane < S;
+    const int ray = blockIdx.x * 16 + wave;
+    if (ray < n_rays) {
+        const int64_t sidx = (int64_t)ray * S + lane;
+        const f32x4 rw = valid ? *reinterpret_cast<const f32x4*>(raw + sidx * 4) : splat4(0.f);
+        const double zk = valid ? z_vals[sidx] : 0.0;
+        const float alpha = valid ? 1.f / (1.f + expf(-(10.f * rw[3]))) : 0.f;
+        const float m = valid ? (1.f - alpha) + 1e-10f : 1.f;
+        float incl = m;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float t = __shfl_up(incl, off);
+            incl = lane >= off ? incl * t : incl;
+        }
+        float T = __shfl_up(incl, 1);
+        T = lane == 0 ? 1.f : T;
+        const float w = alpha * T;
+        const float cr = wave_sum(w * rw[0]), cg = wave_sum(w * rw[1]), cb = wave_sum(w * rw[2]);
+        const double dep = wave_sum((double)w * zk);
+        const double d0 = zk - dep;
+        const double vr = wave_sum(((double)w * d0) * d0);
+        if (lane == 0) {
+            depth[ray] = dep;
+            var[ray] = vr;
+            rgb[ray * 3 + 0] = cr; rgb[ray * 3 + 1] = cg; rgb[ray * 3 + 2] = cb;
+            ts.tmp[ray] = fabs((double)gd[ray] - dep) / sqrt(vr + 1e-10);
+        }
+    }
+    if (!ts.dynamic) return;                             // (uniform over the launch)
+    __threadfence();                                     // this workgroup's tmp entries are visible before its ticket is
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(ts.ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last workgroup: median of tmp over the inside rays
+    __threadfence();
+    int P = 64;
+    while (P < n_rays) P <<= 1;
+    int kept = 0;
+    for (int i = threadIdx.x; i < P; i += 1024) {
+        const bool in = i < n_rays && (ts.inside == nullptr || ts.inside[i] != 0);
+        srt[i] = in ? __builtin_nontemporal_load(ts.tmp + i) : INFINITY;
+        kept += in ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+    if (lane == 0) s_cnt[wave] = kept;
+    __syncthreads();
+    int c = 0;
+    for (int w = 0; w < 16; ++w) c += s_cnt[w];
+    if (n_rays <= 1024) {
+        // small batch: the element of rank (c - 1) / 2 by counting (every thread ranks its own entry against all others: broadcast
+        // LDS reads, one barrier) instead of a 36-78-step sorting network with a barrier per step (12 us at 200 rays)
+        if (threadIdx.x == 0) { ts.tmp[n_rays] = INFINITY; *ts.ticket = 0; }
+        __syncthreads();                                 // (the default is in memory before the one thread that may overwrite it runs on)
+        // 1024 / P adjacent lanes share one entry, each ranks it against a slice of the others (eight LDS reads in flight; one
+        // thread per entry walking all of them was a 200-step chain of dependent-latency reads: 9 us)
+        const int parts = 1024 / P, i = threadIdx.x / parts, part = threadIdx.x - i * parts;
+        const int per = (n_rays + parts - 1) / parts, j0 = part * per, j1 = min(j0 + per, n_rays);
+        const double mine = srt[i];
+        int rank = 0;
+        int j = j0;
+        for (; j + 8 <= j1; j += 8) {
+            double o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = srt[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += (o[u] < mine || (o[u] == mine && j + u < i)) ? 1 : 0;
+        }
+        for (; j < j1; ++j) {
+            const double o = srt[j];
+            rank += (o < mine || (o == mine && j < i)) ? 1 : 0;
+        }
+        for (int o = 1; o < parts; o <<= 1) rank += __shfl_xor(rank, o);          // (parts is a power of two <= 16: lanes of one wave)
+        // (+inf entries: rays outside the mask, never the median unless nothing finite is kept -- then the default stands)
+        if (part == 0 && i < n_rays && mine != INFINITY && c > 0 && rank == ((c - 1) >> 1)) ts.tmp[n_rays] = mine;
+        return;
+    }
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += 1024) {
+                const int o = i ^ j;
+                if (o > i) {
+                    const double a = srt[i], b = srt[o];
+                    const bool asc = (i & k) == 0;
+                    if ((a > b) == asc) { srt[i] = b; srt[o] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        ts.tmp[n_rays] = c > 0 ? srt[(c - 1) >> 1] : INFINITY;
+        *ts.ticket = 0;                                  // ready for the next call (the counter is never cleared by anyone else)
+    }
+}
+
+// COMPOSITE: handle_dynamic off -- no median, so the compositing (outputs, tmp) happens here too: one launch
+template <bool COMPOSITE>
+__global__ __launch_bounds__(1024) void tracker_loss_kernel(int n_rays, int S, const float* __restrict__ raw,
+                                                            const double* __restrict__ z_vals, double* __restrict__ depth,
+                                                            double* __restrict__ var, float* __restrict__ rgb,
+                                                            LossSpec ls, TrackerSpec ts, WorkList wk) {
+    __shared__ double red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool valid = lane < S;
+    const int ray_raw = blockIdx.x * 16 + wave;
+    const bool rvalid = ray_raw < n_rays;
+    const int ray = rvalid ? ray_raw : n_rays - 1;
+    const int64_t sidx = (int64_t)ray * S + lane;
+    const double med = ts.dynamic ? ts.tmp[n_rays] : INFINITY;
+    const f32x4 rw = valid ? *reinterpret_cast<const f32x4*>(raw + sidx * 4) : splat4(0.f);
+    const double zk = valid ? z_vals[sidx] : 0.0;
+    const float alpha = valid ? 1.f / (1.f + expf(-(10.f * rw[3]))) : 0.f;
+    const float m = valid ? (1.f - alpha) + 1e-10f : 1.f;
+    float incl = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(incl, off);
+        incl = lane >= off ? incl * t : incl;
+    }
+    float T = __shfl_up(incl, 1);
+    T = lane == 0 ? 1.f : T;
+    const float w = alpha * T;
+    const float g = ls.gd[ray];
+    double dep, vr, tmp;
+    float cc[3];
+    if constexpr (COMPOSITE) {
+        cc[0] = wave_sum(w * rw[0]); cc[1] = wave_sum(w * rw[1]); cc[2] = wave_sum(w * rw[2]);
+        dep = wave_sum((double)w * zk);
+        const double d0 = zk - dep;
+        vr = wave_sum(((double)w * d0) * d0);
+        tmp = fabs((double)g - dep) / sqrt(vr + 1e-10);
+        if (lane == 0 && rvalid) {
+            depth[ray] = dep;
+            var[ray] = vr;
+            rgb[ray * 3 + 0] = cc[0]; rgb[ray * 3 + 1] = cc[1]; rgb[ray * 3 + 2] = cc[2];
+            ts.tmp[ray] = tmp;
+        }
+    } else {
+        dep = depth[ray]; vr = var[ray]; tmp = ts.tmp[ray];
+        cc[0] = rgb[ray * 3 + 0]; cc[1] = rgb[ray * 3 + 1]; cc[2] = rgb[ray * 3 + 2];
+    }
+    const bool in = ts.inside == nullptr || ts.inside[ray] != 0;
+    const bool on = rvalid && in && (!ts.dynamic || tmp < 10.0 * med) && g > 0.f;
+    const double isd = 1.0 / sqrt(vr + 1e-10);
+    double term = 0.0;
+    if (on && lane == 0) {
+        term = tmp;
+        if (ls.gc != nullptr)
+            term += (double)ls.w * (double)((fabsf(ls.gc[ray * 3] - cc[0]) + fabsf(ls.gc[ray * 3 + 1] - cc[1])) + fabsf(ls.gc[ray * 3 + 2] - cc[2]));
+    }
+    if (ls.d_raw_unit != nullptr) {                      // (uniform over the launch)
+        const double diff = (double)g - dep;
+        const double gD = on ? (diff > 0.0 ? -isd : (diff < 0.0 ? isd : 0.0)) : 0.0;
+        float gcl[3] = {0.f, 0.f, 0.f};
+        if (ls.gc != nullptr && on) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float d = ls.gc[ray * 3 + a] - cc[a];
+                gcl[a] = -ls.w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            }
+        }
+        float gw = (float)(gD * zk);
+        gw += gcl[0] * rw[0] + gcl[1] * rw[1] + gcl[2] * rw[2];
+        gw = valid ? gw : 0.f;
+        const float gww = gw * w;
+        float suf = gww;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float tt = __shfl_down(suf, off);
+            suf = lane + off < 64 ? suf + tt : suf;
+        }
+        suf -= gww;
+        const float ga = gw * T - suf / m;
+        const float gocc = ga * (1.f - alpha) * alpha * 10.f;
+        const f32x4 dr = f32x4{gcl[0] * w, gcl[1] * w, gcl[2] * w, gocc};
+        if (valid && rvalid) *reinterpret_cast<f32x4*>(ls.d_raw_unit + sidx * 4) = dr;
+        if (wk.tiles != nullptr)
+            append_active_tiles_wg(wk.tiles, wk.count, ray, S / 16, rvalid,
+                                   valid && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f));
+    }
+    if (lane == 0) red[wave] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        atomicAdd(ls.loss, t);
+    }
+}
+
 template <int STAGE>
 int launch_stage(int ntl, int64_t n_units, const float* ro, const float* rd, const double* z, const double* pts,
                  int64_t n_points, int apply_mask, int tpr, float* act_ws, int wl, const DevScene& sc, double* depth, double* var, float* rgb, float* raw,
@@ -751,10 +963,28 @@ int ens_launch_composite_fwd(int n_rays, int S, const float* raw, const double* 
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+int ens_launch_tracker_tail(int n_rays, int S, const float* raw, const double* z, double* depth, double* var, float* rgb,
+                            const LossSpec& ls, const TrackerSpec& ts, const WorkList* wl, hipStream_t st) {
+    if (n_rays <= 0) return 0;
+    if (n_rays > ENS_TRACKER_TAIL_MAX_RAYS || S < 1 || S > 64 || !ls.gd || !ls.loss || !ts.tmp) return -1;
+    WorkList wk{nullptr, nullptr};
+    if (wl != nullptr && ls.d_raw_unit != nullptr) wk = *wl;
+    if (wk.tiles != nullptr && S % 16 != 0) return -1;
+    if (ts.dynamic && !ts.ticket) return -1;
+    const dim3 grid((n_rays + 15) / 16), block(1024);
+    if (ts.dynamic) {
+        tracker_composite_kernel<<<grid, block, 0, st>>>(n_rays, S, raw, z, depth, var, rgb, ls.gd, ts);
+        tracker_loss_kernel<false><<<grid, block, 0, st>>>(n_rays, S, raw, z, depth, var, rgb, ls, ts, wk);
+    } else {
+        tracker_loss_kernel<true><<<grid, block, 0, st>>>(n_rays, S, raw, z, depth, var, rgb, ls, ts, wk);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, const float* rd, const double* z,
                           const double* pts, int64_t n_points, int apply_mask, const DevScene& sc, double* depth,
                           double* var, float* rgb, float* raw, float* act_ws, int act_light, hipStream_t st,
-                          const LossSpec* ls, const WorkList* wl) {
+                          const LossSpec* ls, const WorkList* wl, const TrackerSpec* ts) {
     // Ray mode with raw requested: tile-per-wave decoders through the LDS weight ring + separate compositing.  (Round 1 sent
     // batches above 32768 rays to the one-wave-per-ray kernel; since the ring kernel lost its LDS bank conflicts it is the
     // faster one at every size: render_img 680 x 1200 55.9 -> 50.8 ms.  ENSLAM_TILE_MODE_MAX_RAYS restores a limit.)
@@ -797,8 +1027,11 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
         else render_fwd_ring_kernel<3><<<grid, block, fwd_ring_lds_bytes(3), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag, pts, n_points, apply_mask);
         if (hipGetLastError() != hipSuccess) return -2;
         if (pts_ring) return 0;
+        if (ts != nullptr && ls != nullptr)             // the tracker's loss (median mask included) in place of the compositing launch
+            return ens_launch_tracker_tail((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, *ls, *ts, wl, st);
         return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st, ls, wl);
     }
+    if (ts != nullptr) return -1;
     switch (stage) {
         case 0: rc = launch_stage<0>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, act_light, sc, depth, var, rgb, raw, st); break;
         case 1: rc = launch_stage<1>(ntl, n_units, ro, rd, z, pts, n_points, apply_mask, tpr, act_ws, act_light, sc, depth, var, rgb, raw, st); break;

@@ -275,10 +275,12 @@ __global__ __launch_bounds__(1024) void pose_rays_bwd_kernel(int n, const float*
                                                              const float* __restrict__ g_ro, const float* __restrict__ g_rd,
                                                              float* __restrict__ g_ct) {
     __shared__ double red[16][12];
+    __shared__ double tot[12];
     double acc[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) acc[e] = 0.0;
-    for (int k = threadIdx.x; k < n; k += 1024) {
+    const int nthr = (int)blockDim.x, nw = nthr >> 6;
+    for (int k = threadIdx.x; k < n; k += nthr) {
         const double d[3] = {(double)((pi[k] - cx) / fx), (double)(-(pj[k] - cy) / fy), -1.0};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -298,12 +300,16 @@ __global__ __launch_bounds__(1024) void pose_rays_bwd_kernel(int n, const float*
         for (int e = 0; e < 12; ++e) red[threadIdx.x >> 6][e] = acc[e];
     }
     __syncthreads();
+    if (threadIdx.x < 12) {                              // (twelve lanes sum the waves' partials side by side)
+        double v = 0.0;
+        for (int w = 0; w < nw; ++w) v += red[w][threadIdx.x];
+        tot[threadIdx.x] = v;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         double G[3][3], gT[3];
         for (int e = 0; e < 12; ++e) {
-            double v = 0.0;
-            for (int w = 0; w < 16; ++w) v += red[w][e];
-            if (e < 9) G[e / 3][e % 3] = v; else gT[e - 9] = v;
+            if (e < 9) G[e / 3][e % 3] = tot[e]; else gT[e - 9] = tot[e];
         }
         const double qr = ct[0], qi = ct[1], qj = ct[2], qk = ct[3];
         const double nn = qr * qr + qi * qi + qj * qj + qk * qk, s = 2.0 / nn;
@@ -525,7 +531,11 @@ __global__ __launch_bounds__(256) void adam_tensors_kernel(AdamTensorsJob job) {
         if ((int)blockIdx.x >= job.block_begin[mid]) lo = mid; else hi = mid;
     }
     const int t = lo;
-    const int step = job.step[0];
+    const int step = job.step[0] + (job.self_inc ? 1 : 0);
+    if (job.self_inc) {                                  // (one workgroup: every thread has read the old count before it is replaced)
+        __syncthreads();
+        if (threadIdx.x == 0) const_cast<int*>(job.step)[0] = step;
+    }
     if (step <= 0) return;
     const double bc1 = 1.0 - pow(job.beta1, (double)step), bc2 = 1.0 - pow(job.beta2, (double)step);
     const float step_size = (float)(job.lr[0] / bc1), bc2_sqrt = (float)sqrt(bc2);
@@ -952,12 +962,91 @@ int ens_launch_gather_pixels(int n, const int64_t* idx, int H0, int W0, int ww, 
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// The head of the tracker's camera iteration in one single-workgroup launch (Tracker.py:160-174): the pixels of the batch
+// (get_sample_uv behind the single randint draw: gather_pixels_kernel), their rays from the camera tensor
+// (pose_rays_fwd_kernel), the in-bound prefilter  t = min_axis max_side((bound - o) / d) >= gt_depth  in float64 as a mask
+// and the sampler's batch maxima of gt_depth over the rays that mask keeps -- gather + pose + ~12 tiny torch launches before.
+template <typename C>
+__global__ __launch_bounds__(1024) void tracker_rays_kernel(int n, const float* __restrict__ ct, const int64_t* __restrict__ idx,
+                                                            int H0, int W0, int ww, int Wimg, int Himg, const float* __restrict__ depth,
+                                                            const C* __restrict__ color, float fx, float fy, float cx, float cy,
+                                                            double lo0, double hi0, double lo1, double hi1, double lo2, double hi2,
+                                                            float* __restrict__ oi, float* __restrict__ oj, float* __restrict__ ro,
+                                                            float* __restrict__ rd, float* __restrict__ gd, float* __restrict__ gc,
+                                                            uint8_t* __restrict__ inside, float* __restrict__ dmax,
+                                                            int* __restrict__ iter, int iter_count) {
+    __shared__ float red[16];
+    if (iter != nullptr) {                               // pre-drawn indices of a whole frame: this call takes row iter[0] % iter_count
+        const int k = iter[0];
+        idx += (int64_t)(k % iter_count) * n;
+        __syncthreads();                                 // (one workgroup: everyone has read the count before it moves on)
+        if (threadIdx.x == 0) iter[0] = k + 1;
+    }
+    const PoseR R = pose_rotation(ct);
+    const double lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+    float m = 0.f;                                   // max over the kept rays of gt_depth (0 when none: torch.where(inside, gd, 0).max())
+    for (int t = threadIdx.x; t < n; t += 1024) {
+        int64_t k = idx[t];
+        const int64_t kmax = (int64_t)(Himg - H0) * ww - 1;            // (an index outside the window's rows never leaves the image)
+        k = k < 0 ? 0 : (k > kmax ? kmax : k);
+        const int row = (int)(k / ww), col = (int)(k - (int64_t)row * ww);
+        const int64_t at = (int64_t)(H0 + row) * Wimg + (W0 + col);
+        const float pi = (float)(W0 + col), pj = (float)(H0 + row), g = depth[at];
+        oi[t] = pi; oj[t] = pj; gd[t] = g;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) gc[(int64_t)t * 3 + a] = (float)color[at * 3 + a];
+        const float d0 = (pi - cx) / fx, d1 = -(pj - cy) / fy, d2 = -1.f;
+        double tmin = INFINITY;
+        bool nan = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float dv = (d0 * R.r[a][0] + d1 * R.r[a][1]) + d2 * R.r[a][2], ov = ct[4 + a];
+            rd[t * 3 + a] = dv;
+            ro[t * 3 + a] = ov;
+            const double t0 = (lo[a] - (double)ov) / (double)dv, t1 = (hi[a] - (double)ov) / (double)dv;
+            const double tm = t0 > t1 ? t0 : t1;
+            nan = nan || t0 != t0 || t1 != t1;           // (torch.max / torch.min propagate NaN: the comparison below is then False)
+            tmin = tm < tmin ? tm : tmin;
+        }
+        bool in = true;
+        if (inside != nullptr) {
+            in = !nan && tmin >= (double)g;
+            inside[t] = in ? 1 : 0;
+        }
+        if (in) m = fmaxf(m, g);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        m = red[threadIdx.x];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (threadIdx.x == 0) { dmax[0] = m; dmax[1] = m * 1.2f; }
+    }
+}
+int ens_launch_tracker_rays(int n, const float* ct, const int64_t* idx, int H0, int W0, int ww, int Wimg, int Himg, const float* depth,
+                            const void* color, int color_f64, float fx, float fy, float cx, float cy, const double* b,
+                            float* oi, float* oj, float* ro, float* rd, float* gd, float* gc, uint8_t* inside, float* dmax,
+                            hipStream_t st, int* iter, int iter_count) {
+    if (n <= 0) return 0;
+    if ((iter != nullptr && iter_count < 1) || ww < 1 || W0 < 0 || H0 < 0 || W0 + ww > Wimg || H0 >= Himg) return -1;
+    if (color_f64) tracker_rays_kernel<double><<<1, 1024, 0, st>>>(n, ct, idx, H0, W0, ww, Wimg, Himg, depth, (const double*)color, fx, fy, cx, cy,
+                                                                   b[0], b[1], b[2], b[3], b[4], b[5], oi, oj, ro, rd, gd, gc, inside, dmax, iter, iter_count);
+    else tracker_rays_kernel<float><<<1, 1024, 0, st>>>(n, ct, idx, H0, W0, ww, Wimg, Himg, depth, (const float*)color, fx, fy, cx, cy,
+                                                        b[0], b[1], b[2], b[3], b[4], b[5], oi, oj, ro, rd, gd, gc, inside, dmax, iter, iter_count);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int ens_launch_pose_rays(int n, const float* ct, const float* pi, const float* pj, float fx, float fy, float cx, float cy,
                          const float* g_ro, const float* g_rd, float* ro, float* rd, float* g_ct, hipStream_t st) {
     if (g_ct == nullptr) {
         if (n > 0) pose_rays_fwd_kernel<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(n, ct, pi, pj, fx, fy, cx, cy, ro, rd);
     } else {
-        pose_rays_bwd_kernel<<<1, 1024, 0, st>>>(n, ct, pi, pj, fx, fy, cx, cy, g_ro, g_rd, g_ct);
+        // (as many waves as the batch has 64-ray slices, at most 16: fewer partials to reduce, same summation order per wave count)
+        const int thr = n <= 64 ? 64 : (n <= 256 ? 256 : 1024);
+        pose_rays_bwd_kernel<<<1, thr, 0, st>>>(n, ct, pi, pj, fx, fy, cx, cy, g_ro, g_rd, g_ct);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -821,6 +821,21 @@ class _Accumulators:
         return n, dsts, vs, nd
 
 
+_tickets = {}
+
+
+def _tracker_ticket(dev):
+    """One int32 per device that the tracker's compositing launch counts its workgroups in and leaves at 0 again (the launches of
+    one stream are ordered; callers on different streams of one device would need their own)."""
+    t = _tickets.get(dev)
+    if t is None:
+        if _capturing():
+            raise L.EnslamError("the tracker's fused loss needs one eager call before it is captured (its ticket counter is allocated "
+                                "and cleared outside the graph)")
+        t = _tickets[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
 class _RenderFn(torch.autograd.Function):
     """inputs: plan, rays_o, rays_d, gt_depth|None, t_rand|None, then for each kind in plan.kinds: grid,
     then for each kind: its parameters.  Outputs depth f64 [N], var f64 [N], rgb f32 [N,3]; with plan.loss the
@@ -974,16 +989,28 @@ class _RenderFn(torch.autograd.Function):
                                           _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, st),
                     "enslam_render_fwd")
         else:
-            lgd, lgc, lw = plan.loss
+            lgd, lgc, lw = plan.loss[:3]
             loss = accum.loss_slot() if accum is not None else arena.take(1, torch.float64)
             # the compositing launch also leaves d(loss)/d(raw) for a unit loss gradient: the backward starts at the decoders
             d_raw_unit = torch.empty((N * S, 4), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
-            L.check(lib.enslam_render_loss_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
-                                               _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, _ptr(lgd),
-                                               _ptr(lgc), ctypes.c_float(lw), _ptr(loss), _ptr(d_raw_unit),
-                                               _ptr(work) if d_raw_unit is not None else None,
-                                               _ptr(wcount) if d_raw_unit is not None else None, st),
-                    "enslam_render_loss_fwd")
+            if len(plan.loss) > 3:              # the tracker's loss (Tracker.py:176-195): (gd, gc, w, inside mask | None, handle_dynamic, 'tracker')
+                linside, ldyn = plan.loss[3], plan.loss[4]
+                tmp = torch.empty(N + 1, dtype=torch.float64, device=dev)
+                ticket = _tracker_ticket(dev)
+                L.check(lib.enslam_render_tracker_loss_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
+                                                           _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, _ptr(lgd),
+                                                           _ptr(lgc), ctypes.c_float(lw), _ptr(linside), int(bool(ldyn)), _ptr(tmp),
+                                                           _ptr(ticket), _ptr(loss), _ptr(d_raw_unit),
+                                                           _ptr(work) if d_raw_unit is not None else None,
+                                                           _ptr(wcount) if d_raw_unit is not None else None, st),
+                        "enslam_render_tracker_loss_fwd")
+            else:
+                L.check(lib.enslam_render_loss_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
+                                                   _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, _ptr(lgd),
+                                                   _ptr(lgc), ctypes.c_float(lw), _ptr(loss), _ptr(d_raw_unit),
+                                                   _ptr(work) if d_raw_unit is not None else None,
+                                                   _ptr(wcount) if d_raw_unit is not None else None, st),
+                        "enslam_render_loss_fwd")
         ctx.sv = None
         if SV is not None:
             # compositing over the real samples only (the kernels above composited the padded rays): contiguous [N, SV] views
@@ -1114,6 +1141,8 @@ class _RenderFn(torch.autograd.Function):
             d_raw, d_scale = ctx.d_raw_unit, gL             # unit gradients from the forward, scaled inside the decoder backward
         elif gL is not None:
             d_raw = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
+            if len(plan.loss) > 3:
+                raise L.EnslamError("the tracker's fused loss keeps its unit gradients from the forward; none were kept")
             lgd, lgc, lw = plan.loss
             L.check(lib.enslam_composite_loss_bwd(N, S, _ptr(raw), _ptr(z), _ptr(depth), _ptr(ctx.rgb), _ptr(lgd), _ptr(lgc),
                                                   ctypes.c_float(lw), _ptr(gL), _ptr(d_raw), _ptr(work), _ptr(wcount), st),

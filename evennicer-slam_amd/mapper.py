@@ -199,10 +199,14 @@ class FusedAdam:
             g = g if g.is_contiguous() else g.contiguous()
             P[i], G[i], M[i], V[i] = p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
             numel[i] = p.numel()
-        self.step_t += 1
         # raw kernel writes: tell torch (and the packed-decoder cache) they changed -- now, and on every replay when
         # this call is being captured (graph.GraphedStep.replay)
         note_raw_write(self.params)
+        if n == 1 and numel[0] <= 1024:                 # one workgroup (a camera tensor): the launch counts the step itself
+            L.check(L.lib().enslam_adam_tensors_step(n, P, G, M, V, numel, _ptr(self.lr_t), _ptr(self.step_t), self.betas[0],
+                                                     self.betas[1], self.eps, _stream()), "enslam_adam_tensors_step")
+            return
+        self.step_t += 1
         L.check(L.lib().enslam_adam_tensors(n, P, G, M, V, numel, _ptr(self.lr_t), _ptr(self.step_t), self.betas[0],
                                             self.betas[1], self.eps, _stream()), "enslam_adam_tensors")
 

@@ -84,6 +84,32 @@ class Renderer(object):
             return loss, depth.detach(), var.detach(), color.detach()
         return self._render(c, decoders, rays_d, rays_o, device, stage, gt_depth, (gd, gc, float(w_color)))
 
+    def tracker_loss_ok(self, n_rays, gt_depth):
+        """whether render_batch_ray_tracker_loss serves this batch (else: render_batch_ray + losses.tracker_loss)"""
+        S = self.N_samples + self.N_surface
+        return (gt_depth is not None and 0 < n_rays <= min(self.FUSED_LOSS_MAX_RAYS, L.lib().enslam_tracker_tail_max_rays())
+                and self.N_importance == 0 and S % 16 == 0 and S <= 64)
+
+    def render_batch_ray_tracker_loss(self, c, decoders, rays_d, rays_o, device, stage, gt_depth, gt_color, w_color=0.5, inside=None,
+                                      handle_dynamic=True, use_color=True):
+        """`render_batch_ray` and the TRACKER's RGB-D loss on its outputs (Tracker.py:176-195) with the loss, its median mask and
+        its gradient folded into one launch behind the decoders:
+            tmp  = |gt_depth - depth| / sqrt(uncertainty.detach() + 1e-10)
+            keep = inside & (tmp < 10 * median(tmp[inside]))     (handle_dynamic; `inside`: uint8 / bool mask of the rays the
+                                                                  in-bound prefilter of :164-174 keeps, None = every ray)
+            loss = tmp[keep & (gt_depth > 0)].sum() + w_color * |gt_color - color|[keep & (gt_depth > 0)].sum()   (use_color)
+        Returns (loss f64 scalar, depth, uncertainty, color); only the loss carries gradient.  Batches of up to 4096 rays, colour
+        / fine / middle stage (`tracker_loss_ok`)."""
+        if stage == 'coarse' or not self.tracker_loss_ok(rays_o.shape[0], gt_depth):
+            raise ValueError("render_batch_ray_tracker_loss: batch not served (see tracker_loss_ok); use render_batch_ray + losses.tracker_loss")
+        gd = gt_depth.detach().contiguous().float().reshape(-1)
+        gc = gt_color.detach().contiguous().float().reshape(-1, 3) if (use_color and stage == 'color' and gt_color is not None) else None
+        ins = None
+        if inside is not None:
+            ins = inside.detach().reshape(-1)
+            ins = (ins if ins.dtype == torch.uint8 else ins.to(torch.uint8)).contiguous()
+        return self._render(c, decoders, rays_d, rays_o, device, stage, gt_depth, (gd, gc, float(w_color), ins, bool(handle_dynamic), 'tracker'))
+
     def _render(self, c, decoders, rays_d, rays_o, device, stage, gt_depth, loss, z_given=None, s_valid=None):
         if self.N_importance > 0 and z_given is None:
             if loss is not None:

@@ -10,11 +10,17 @@ and its autograd are ~200 launches on tensors of 1-9 elements -- several times t
 draw); `losses.tracker_loss` is the fused loss.  The plain-torch route (`common.get_camera_from_tensor` +
 `common.get_samples`) stays available and gives the same numbers."""
 import ctypes
+import os
 
 import torch
 
 from . import _lib as L
 from .functional import _ptr, _require_hip, _stream
+
+
+# the RGB-D term of a camera iteration through the fused launches (TrackerIteration._rgbd_loss_fused); ENSLAM_TRACKER_FUSED=0 keeps
+# the launch-per-step route (gather, pose, prefilter and median in torch ops, losses.tracker_loss) -- same numbers
+FUSED_ITERATION = os.environ.get('ENSLAM_TRACKER_FUSED', '1') == '1'
 
 
 class _PoseRays(torch.autograd.Function):
@@ -48,6 +54,52 @@ class _PoseRays(torch.autograd.Function):
                                              ctypes.c_float(cx), ctypes.c_float(cy), _ptr(gro), _ptr(grd), _ptr(g), _stream()),
                 "enslam_pose_rays_bwd")
         return g.reshape(shape), None, None, None, None, None, None
+
+
+class _TrackerRays(torch.autograd.Function):
+    """Head of the camera iteration in one launch (enslam_tracker_rays): pixel samples of the drawn indices, rays of the camera
+    tensor, in-bound mask and the sampler's batch maxima; backward = enslam_pose_rays_bwd (ray gradients -> the 7 numbers)."""
+
+    @staticmethod
+    def forward(ctx, camera_tensor, idx, H0, W0, ww, depth, color, fx, fy, cx, cy, bound6, prefilter, draw_counter=None):
+        _require_hip(camera_tensor, "camera_tensor")
+        ct = camera_tensor.detach().contiguous().float().reshape(-1)
+        if ct.numel() != 7:
+            raise L.EnslamError(f"camera tensor must have 7 elements (quaternion, translation), got {tuple(camera_tensor.shape)}")
+        # idx: int64 [n] -- or, with draw_counter (int32 [1] on the device), [n_draws, n] drawn ahead: row counter % n_draws is used
+        n_draws = int(idx.shape[0]) if draw_counter is not None else 0
+        n, dev = int(idx.shape[-1]), ct.device
+        if idx.dtype != torch.int64 or idx.dim() != (2 if draw_counter is not None else 1):
+            raise L.EnslamError(f"pixel indices must be int64 [n] (or [n_draws, n] with a draw counter), got {tuple(idx.shape)} {idx.dtype}")
+        depth, color, idx = depth.contiguous(), color.contiguous(), idx.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        flat = torch.empty(2 * n + 6 * n + n + 3 * n + 2, **f32)            # one allocation: pix_i | pix_j | ro | rd | gd | gc | dmax
+        pi, pj, ro, rd, gd, gc, dmax = flat.split([n, n, 3 * n, 3 * n, n, 3 * n, 2])
+        ro, rd, gc = ro.view(n, 3), rd.view(n, 3), gc.view(n, 3)
+        inside = torch.empty(n, dtype=torch.uint8, device=dev) if prefilter else None
+        L.check(L.lib().enslam_tracker_rays(n, _ptr(ct), _ptr(idx), int(H0), int(W0), int(ww), int(depth.shape[1]), int(depth.shape[0]), _ptr(depth), _ptr(color),
+                                            int(color.dtype == torch.float64), ctypes.c_float(fx), ctypes.c_float(fy), ctypes.c_float(cx),
+                                            ctypes.c_float(cy), bound6, int(bool(prefilter)), _ptr(pi), _ptr(pj), _ptr(ro), _ptr(rd), _ptr(gd),
+                                            _ptr(gc), _ptr(inside), _ptr(dmax), _ptr(draw_counter), n_draws, _stream()), "enslam_tracker_rays")
+        ctx.keep = (ct, pi, pj, float(fx), float(fy), float(cx), float(cy), tuple(camera_tensor.shape))
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(gd, gc, dmax)
+        if inside is not None:
+            ctx.mark_non_differentiable(inside)
+        return ro, rd, gd, gc, inside, dmax
+
+    @staticmethod
+    def backward(ctx, g_ro, g_rd, *_unused):
+        ct, pi, pj, fx, fy, cx, cy, shape = ctx.keep
+        if g_ro is None and g_rd is None:
+            return (None,) * 14
+        gro = g_ro.detach().contiguous().float() if g_ro is not None else None
+        grd = g_rd.detach().contiguous().float() if g_rd is not None else None
+        g = torch.empty(7, dtype=torch.float32, device=ct.device)
+        L.check(L.lib().enslam_pose_rays_bwd(pi.numel(), _ptr(ct), _ptr(pi), _ptr(pj), ctypes.c_float(fx), ctypes.c_float(fy),
+                                             ctypes.c_float(cx), ctypes.c_float(cy), _ptr(gro), _ptr(grd), _ptr(g), _stream()),
+                "enslam_pose_rays_bwd")
+        return (g.reshape(shape),) + (None,) * 13
 
 
 def rays_from_camera_tensor(camera_tensor, i, j, fx, fy, cx, cy):
@@ -102,6 +154,22 @@ class TrackerIteration(object):
         self.unblurred_weight = e['unblurred_weight']
         self.c = None
         self.decoders = None
+        # (int64 [n_draws, n] pixel indices, int32 [1] counter) when the draws of a frame are made ahead (GraphedCameraIteration)
+        self.draws = None
+
+    def draw_ahead(self, n_draws, batch_size, out=None):
+        """Pixel indices of n_draws coming iterations in ONE torch.randint (the same distribution as the per-iteration draw of
+        common.get_sample_uv, a different consumption of the generator's stream) + a device counter starting at 0."""
+        n_pix = (self.H - 2 * self.ignore_edge_H) * (self.W - 2 * self.ignore_edge_W)
+        if out is None:
+            out = (torch.empty((n_draws, batch_size), dtype=torch.int64, device=self.device),
+                   torch.zeros(1, dtype=torch.int32, device=self.device))
+        draw = torch.randint(n_pix, tuple(out[0].shape), device=out[0].device)
+        if tuple(draw.shape) != tuple(out[0].shape):    # (an injected draw of one iteration's size: the same pixels every iteration)
+            draw = draw.reshape(-1, out[0].shape[1]).expand_as(out[0])
+        out[0].copy_(draw)
+        out[1].zero_()
+        return out
 
     def _render_rescaled(self, camera_tensor, gt_depth, scale_factor):
         """`renderer.render_img_rescale(c, decoders, get_camera_from_tensor(camera_tensor), ...)`'s colour image."""
@@ -141,6 +209,8 @@ class TrackerIteration(object):
         device = self.device
         H, W, fx, fy, cx, cy = self.H, self.W, self.fx, self.fy, self.cx, self.cy
         Wedge, Hedge = self.ignore_edge_W, self.ignore_edge_H
+        if FUSED_ITERATION and self._fused_ok(camera_tensor, gt_color, gt_depth, batch_size):
+            return self._rgbd_loss_fused(camera_tensor, gt_color, gt_depth, batch_size)
         ro, rd, b_depth, b_color = get_samples_from_camera_tensor(Hedge, H - Hedge, Wedge, W - Wedge, batch_size, H, W,
                                                                   fx, fy, cx, cy, camera_tensor, gt_depth, gt_color, device)
         inside = None
@@ -176,6 +246,42 @@ class TrackerIteration(object):
         gd_loss = b_depth if keep is None else torch.where(keep, b_depth, torch.zeros_like(b_depth))   # the loss keeps gt_depth > 0
         return tracker_loss(depth, uncertainty, color, gd_loss, b_color, self.w_color_loss,
                             use_color=self.use_color_in_tracking)                                   # :187-195
+
+    def _fused_ok(self, camera_tensor, gt_color, gt_depth, batch_size):
+        from . import functional as EF
+        return (camera_tensor.is_cuda and camera_tensor.numel() == 7 and torch.is_tensor(gt_depth) and torch.is_tensor(gt_color)
+                and gt_depth.is_cuda and gt_color.is_cuda and gt_depth.dtype == torch.float32 and gt_depth.dim() == 2
+                and gt_color.dim() == 3 and gt_color.shape[2] == 3 and tuple(gt_color.shape[:2]) == tuple(gt_depth.shape)
+                and gt_color.dtype in (torch.float32, torch.float64) and not gt_depth.requires_grad and not gt_color.requires_grad
+                and self.renderer.tracker_loss_ok(batch_size, gt_depth) and self.renderer.depth_max_override is None)
+
+    def _rgbd_loss_fused(self, camera_tensor, gt_color, gt_depth, batch_size):
+        """The RGB-D term (Tracker.py:160-195) in five launches forward -- the randint draw, enslam_tracker_rays (pixels, rays,
+        in-bound mask, batch maxima), sampler, decoders, enslam_render_tracker_loss_fwd's tail (compositing + median mask + loss +
+        unit gradients) -- and two backward (light decoder backward with the ray gradients, pose chain).  Same numbers as the
+        route below it: the rays the reference drops are rendered but masked, the sampler's maxima and the median are taken over
+        the kept rays."""
+        from . import functional as EF
+        H, W = self.H, self.W
+        We, He = self.ignore_edge_W, self.ignore_edge_H
+        ww = (W - We) - We
+        counter = None
+        if self.draws is not None and self.draws[0].shape[1] == batch_size:     # indices of the whole frame drawn ahead (captured iterations)
+            idx, counter = self.draws
+        else:
+            idx = torch.randint(((H - He) - He) * ww, (batch_size,), device=camera_tensor.device)   # the draw of common.get_sample_uv
+        ro, rd, gd, gc, inside, dmax = _TrackerRays.apply(camera_tensor, idx, He, We, ww, gt_depth, gt_color, self.fx, self.fy, self.cx,
+                                                          self.cy, EF.bound6(self.bound), bool(self.nice), counter)
+        prev = self.renderer.depth_max_override
+        self.renderer.depth_max_override = dmax
+        try:
+            loss, _d, _u, _c = self.renderer.render_batch_ray_tracker_loss(self.c, self.decoders, rd, ro, self.device, 'color', gd, gc,
+                                                                           self.w_color_loss, inside=inside,
+                                                                           handle_dynamic=self.handle_dynamic,
+                                                                           use_color=self.use_color_in_tracking)
+        finally:
+            self.renderer.depth_max_override = prev
+        return loss
 
     def iteration_losses(self, camera_tensor, gt_color, gt_depth, frame, batch_size, rgbd=True, event=True,
                          scale_factor=0.1, static_shapes=False):
@@ -241,13 +347,18 @@ class GraphedCameraIteration(object):
     prepares the event-resolution ground truth; per iteration: `step()` returns the (device) loss tensors."""
 
     def __init__(self, trk, camera_tensor, optimizer, gt_color, gt_depth, gt_event=None, gt_mask=None, pre_gt_color=None,
-                 batch_size=200, rgbd=True, event=True, scale_factor=0.1, warmup=3):
+                 batch_size=200, rgbd=True, event=True, scale_factor=0.1, warmup=3, n_draws=None):
         from .graph import GraphedStep
         self.trk, self.event, self.scale_factor = trk, event, scale_factor
         self.gt_color, self.gt_depth = gt_color.clone(), gt_depth.clone()
         self.frame = None
         if event:
             self.frame = tuple(t.clone() for t in trk.prepare_event_frame(gt_event, gt_mask, pre_gt_color, scale_factor))
+        # pixel draws of a whole frame made ahead, eagerly, in set_frame(): a randint inside the graph costs its launch and two
+        # fill launches per replay (torch refreshes the captured generator's seed and offset in front of every replay)
+        self.n_draws = int(n_draws if n_draws is not None else trk.cfg['tracking'].get('iters', 10))
+        self._draws = trk.draw_ahead(self.n_draws, batch_size) if (rgbd and FUSED_ITERATION) else None
+        self._zero = None
 
         def it():
             optimizer.zero_grad()
@@ -257,10 +368,17 @@ class GraphedCameraIteration(object):
                 self.one = torch.ones_like(o['total'])
             o['total'].backward(gradient=self.one)
             optimizer.step()
-            z = o['total'].new_zeros(())
-            return tuple(z if o[k] is None else o[k].detach() for k in ('rgbd', 'event', 'mask'))
+            if self._zero is None:
+                self._zero = o['total'].new_zeros(())
+            return tuple(self._zero if o[k] is None else o[k].detach() for k in ('rgbd', 'event', 'mask'))
 
-        self.graph = GraphedStep(it, warmup=warmup)
+        trk.draws = self._draws                          # (only while the iteration is recorded: eager calls keep their own draw)
+        try:
+            self.graph = GraphedStep(it, warmup=warmup)
+        finally:
+            trk.draws = None
+        if self._draws is not None:
+            self._draws[1].zero_()                       # (the warm-up iterations consumed rows)
         # The captured iteration reads the device-side forms (voxel-major copies, packed decoders) of exactly these
         # objects: the graph owns them from here on (refresh_map copies a replaced map INTO them).
         self._map_c = {k: trk.c[k] for k in ('grid_middle', 'grid_fine', 'grid_color')}
@@ -269,6 +387,8 @@ class GraphedCameraIteration(object):
     def set_frame(self, gt_color, gt_depth, gt_event=None, gt_mask=None, pre_gt_color=None):
         self.gt_color.copy_(gt_color)
         self.gt_depth.copy_(gt_depth)
+        if self._draws is not None:
+            self.trk.draw_ahead(self.n_draws, self._draws[0].shape[1], out=self._draws)      # fresh pixels for the new frame
         if self.event:
             for dst, src in zip(self.frame, self.trk.prepare_event_frame(gt_event, gt_mask, pre_gt_color, self.scale_factor)):
                 dst.copy_(src)

@@ -185,6 +185,12 @@ int enslam_adam_masked(int32_t n, float *const *param, float *const *grad, float
 int enslam_adam_tensors(int32_t n, float *const *param, const float *const *grad, float *const *exp_avg,
                         float *const *exp_avg_sq, const int64_t *numel, const double *lr, const int32_t *step,
                         double beta1, double beta2, double eps, void *stream);
+/* enslam_adam_tensors for jobs of ONE workgroup (at most 1024 parameters in one tensor -- a camera tensor): *step holds the count
+ * BEFORE this step; the launch uses *step + 1 and stores it back, so no separate increment launch precedes it.  More than one
+ * workgroup: ENSLAM_EUNSUPPORTED. */
+int enslam_adam_tensors_step(int32_t n, float *const *param, const float *const *grad, float *const *exp_avg,
+                             float *const *exp_avg_sq, const int64_t *numel, const double *lr, int32_t *step, double beta1,
+                             double beta2, double eps, void *stream);
 
 /* Gradient bucket of the ray-sharded step (new functionality, SURVEY.md 8e: the reference has no multi-GPU path; the
  * tensors are the leaf gradients of Mapper.py:573-575).  Packs into / unpacks from one flat all-reduce buffer:
@@ -279,6 +285,45 @@ int enslam_sample_prepare(int32_t n_rays, int32_t n_lin, int32_t n_surf, const f
                           const enslam_mlp_params *params, float *const *packed, int32_t n_zero, float *const *zero_dst,
                           const int64_t *zero_voxels, const uint8_t *const *zero_need, float *flat, int64_t n_flat,
                           void *stream);
+
+/* Head of the tracker's camera iteration in one launch (one workgroup; any n): for the n window pixels `pixel_index` (int64,
+ * row-major inside the window that starts at (H0, W0) and is window_w wide -- the single torch.randint draw of
+ * common.get_sample_uv) it writes their column / row as floats (pix_i, pix_j), their depth and colour samples (gt_depth,
+ * gt_color as float32 [n,3]), their rays from the camera tensor [qr,qi,qj,qk,tx,ty,tz] (rays_o, rays_d: enslam_pose_rays_fwd's
+ * arithmetic) and -- prefilter != 0 -- the in-bound mask  inside[k] = min_axis max_side((bound - o) / d) >= gt_depth[k]  in
+ * float64, with depth_max = {max over the inside rays of gt_depth (0 if none), that * 1.2f}: the sampler's batch maxima when the
+ * rays the reference drops are rendered but masked (prefilter == 0: maxima over all rays, inside untouched).
+ * draw_counter (optional, int32 [1] on the device): pixel_index then holds n_draws rows of n indices drawn ahead (one
+ * torch.randint per frame instead of one per iteration -- under hipGraph replay every captured randint costs its launch plus two
+ * fill launches for the generator's seed and offset); the call takes row *draw_counter % n_draws and increments the counter.
+ * An index outside [0, (image_h - H0) * window_w) is clamped into it (no read ever leaves the images).
+ *   Replaces Tracker.optimize_cam_in_batch lines 160-174 (get_samples with the camera tensor's pose, the `inside_mask` filter)
+ *   and common.get_camera_from_tensor (common.py:189-229) for this use. */
+int enslam_tracker_rays(int32_t n, const float *camera_tensor, const int64_t *pixel_index, int32_t H0, int32_t W0,
+                        int32_t window_w, int32_t image_w, int32_t image_h, const float *depth_image, const void *color_image,
+                        int32_t color_is_f64, float fx, float fy, float cx, float cy, const double *bound_host,
+                        int32_t prefilter, float *pix_i, float *pix_j, float *rays_o, float *rays_d, float *gt_depth,
+                        float *gt_color, uint8_t *inside, float *depth_max, int32_t *draw_counter, int32_t n_draws,
+                        void *stream);
+
+/* enslam_render_loss_fwd with the TRACKER's loss in place of the mapper's (batches of up to enslam_tracker_tail_max_rays()
+ * rays; more: ENSLAM_EUNSUPPORTED): behind the decoder kernel two launches of 16 rays per workgroup -- compositing with
+ *   tmp = |gt_depth - depth| / sqrt(var + 1e-10)
+ * whose last-finishing workgroup takes the median of tmp over the inside rays (the lower median of torch.median, by a bitonic
+ * sort of the batch in LDS), then
+ *   keep = inside & (handle_dynamic ? tmp < 10 * median : 1),
+ *   loss += sum_{keep & gt_depth > 0} tmp + w_color * sum_{keep & gt_depth > 0} |gt_color - color|   (gt_color NULL: depth term)
+ * with d(loss)/d(raw) for a unit loss gradient in d_raw_unit and the work list of active tiles, the variance treated as a
+ * constant.  inside NULL: every ray.  tmp_scratch: float64 [n_rays + 1].  ticket: int32 [1], 0 on entry, left at 0 (needed
+ * with handle_dynamic).  *loss must be 0 on entry.
+ *   Replaces Tracker.optimize_cam_in_batch lines 176-195 around Renderer.render_batch_ray. */
+int enslam_tracker_tail_max_rays(void);
+int enslam_render_tracker_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
+                                   const double *z_vals, const enslam_scene *scene, double *depth, double *var, float *rgb,
+                                   float *raw_out, float *act_ws, int32_t act_light, const float *gt_depth,
+                                   const float *gt_color, float w_color, const uint8_t *inside, int32_t handle_dynamic,
+                                   double *tmp_scratch, int32_t *ticket, double *loss, float *d_raw_unit,
+                                   int32_t *work_list, int32_t *work_count, void *stream);
 
 /* Sample distances along rays (mark_scene / mark_flags non-NULL: also does enslam_mark_blocks' work for stage mark_stage
  * on the samples it has just placed -- one launch less per render call).

@@ -195,3 +195,114 @@ def test_tracking_loop_twin_against_the_oracle(monkeypatch):
     assert float((best.cpu() - o_traj[k_best]).abs().max()) <= 1e-4
     assert float((ct.detach().cpu() - oct.detach()).abs().max()) <= 1e-4        # after the last Adam step
     assert float((ct0 - oct.detach()).abs().max()) > 1e-3                       # (the pose really moved)
+
+
+def test_tracker_rays_entry_matches_the_torch_route():
+    """enslam_tracker_rays (pixels, rays, in-bound mask, batch maxima in one launch) against get_sample_uv + rays_from_camera_tensor
+    + the torch statements of Tracker.py:164-170 on the same indices."""
+    import evennicer_slam_amd as E
+    import evennicer_slam_amd.functional as EF
+    from evennicer_slam_amd.tracker import _TrackerRays
+    from tests.hip_util import DEV
+    torch.manual_seed(3)
+    H, W, He, We, n = 120, 160, 10, 12, 777
+    fx, fy, cx, cy = 150.0, 152.0, 79.5, 59.5
+    depth = (torch.rand(H, W, device=DEV) * 6.0)
+    depth[::7, ::5] = 0.0
+    bound = torch.tensor([[-2.0, 2.5], [-1.5, 2.0], [-1.0, 1.8]], dtype=torch.float64)
+    ct = torch.tensor([0.9, 0.1, -0.2, 0.05, 0.3, -0.2, 0.1], device=DEV, requires_grad=True)
+    ww = W - 2 * We
+    idx = torch.randint((H - 2 * He) * ww, (n,), device=DEV)
+    for dtype in (torch.float32, torch.float64):
+        color = torch.rand(H, W, 3, device=DEV, dtype=dtype)
+        ro, rd, gd, gc, inside, dmax = _TrackerRays.apply(ct, idx, He, We, ww, depth, color, fx, fy, cx, cy, EF.bound6(bound), True)
+        i, j, d2, c2 = EF.gather_pixels(idx, He, We, ww, depth, color)
+        ro2, rd2 = E.tracker.rays_from_camera_tensor(ct, i, j, fx, fy, cx, cy)
+        assert torch.equal(ro, ro2) and torch.equal(rd, rd2) and torch.equal(gd, d2) and torch.equal(gc, c2.float())
+        with torch.no_grad():
+            t = (bound.to(DEV).unsqueeze(0) - ro2.detach().unsqueeze(-1)) / rd2.detach().unsqueeze(-1)
+            t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
+            ins2 = t >= d2
+            m = torch.where(ins2, d2, d2.new_zeros(())).max().reshape(1)
+        assert torch.equal(inside.bool(), ins2) and 0 < int(ins2.sum()) < n
+        assert torch.equal(dmax, torch.cat([m, m * 1.2]))
+        g1 = torch.autograd.grad((rd * torch.arange(3, device=DEV)).sum() + ro.sum(), ct)[0]
+        g2 = torch.autograd.grad((rd2 * torch.arange(3, device=DEV)).sum() + ro2.sum(), ct)[0]
+        assert torch.equal(g1, g2)
+    # without the prefilter: no mask, maxima over every ray
+    ro, rd, gd, gc, inside, dmax = _TrackerRays.apply(ct, idx, He, We, ww, depth, color, fx, fy, cx, cy, EF.bound6(bound), False)
+    assert inside is None and float(dmax[0]) == float(gd.max())
+
+
+@pytest.mark.parametrize("n_rep", [1, 3, 13, 20])          # 64, 192, 832 rays (median by counting, 16 / 4 / 1 lanes per entry) / 1280 rays (sorting network)
+@pytest.mark.parametrize("dynamic,use_color,masked", [(True, True, True), (True, True, False), (False, True, True), (True, False, False)])
+def test_fused_tracker_loss_matches_the_torch_statements(n_rep, dynamic, use_color, masked):
+    """Renderer.render_batch_ray_tracker_loss against render_batch_ray + Tracker.py:176-195 written in torch ops (median mask over
+    the kept rays included): loss, outputs and the gradient to the rays."""
+    from tests.hip_util import DEV, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    torch.manual_seed(5)
+    ro0, rd0 = rays['rays_o'].repeat(n_rep, 1), rays['rays_d'].repeat(n_rep, 1)
+    gd, gc = rays['gt_depth'].repeat(n_rep).clone(), rays['gt_color'].repeat(n_rep, 1)
+    n = ro0.shape[0]
+    rd0 = rd0 + 0.01 * torch.randn_like(rd0) * (torch.arange(n, device=DEV) >= 64)[:, None]     # (the copies look elsewhere)
+    gd[torch.arange(n, device=DEV) % 11 == 3] = 0.0
+    inside = (torch.arange(n, device=DEV) % 5 != 1) if masked else None
+    w = 0.5
+    for p in model.parameters():
+        p.requires_grad_(False)
+    try:
+        ro, rd = ro0.clone().requires_grad_(True), rd0.clone().requires_grad_(True)
+        loss, depth, unc, color = renderer.render_batch_ray_tracker_loss(grids, model, rd, ro, DEV, 'color', gd, gc, w, inside=inside,
+                                                                         handle_dynamic=dynamic, use_color=use_color)
+        g_ro, g_rd = torch.autograd.grad(loss * 1.5, [ro, rd])
+        ro2, rd2 = ro0.clone().requires_grad_(True), rd0.clone().requires_grad_(True)
+        d2, u2, c2 = renderer.render_batch_ray(grids, model, rd2, ro2, DEV, 'color', gt_depth=gd)
+        u2 = u2.detach()
+        tmp = torch.abs(gd - d2) / torch.sqrt(u2 + 1e-10)
+        keep = torch.ones(n, dtype=torch.bool, device=DEV) if inside is None else inside.clone()
+        if dynamic:
+            med = tmp.detach()[keep].median()
+            keep = keep & (tmp.detach() < 10 * med)
+        mask = keep & (gd > 0)
+        ref = tmp[mask].sum()
+        if use_color:
+            ref = ref + w * torch.abs(gc - c2)[mask].sum()
+        r_ro, r_rd = torch.autograd.grad(ref * 1.5, [ro2, rd2])
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(True)
+    assert torch.equal(depth, d2.detach()) and torch.equal(unc, u2) and torch.equal(color, c2.detach())
+    assert 0 < int(mask.sum()) < n
+    assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())          # (the colour term is a float32 sum in the torch statements)
+    for a, b in ((g_ro, r_ro), (g_rd, r_rd)):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())           # (float atomics into the ray gradients)
+
+
+def test_fused_adam_counts_its_own_step_for_a_camera_tensor():
+    """one-workgroup FusedAdam jobs (a 7-number camera tensor): the launch increments the step count itself; same updates as
+    torch.optim.Adam over five steps"""
+    from evennicer_slam_amd.mapper import FusedAdam
+    from tests.hip_util import DEV
+    torch.manual_seed(2)
+    a = torch.randn(7, device=DEV).requires_grad_(True)
+    b = a.detach().clone().requires_grad_(True)
+    oa, ob = FusedAdam([a], lr=2e-3), torch.optim.Adam([b], lr=2e-3)
+    for k in range(5):
+        g = torch.randn(7, device=DEV)
+        a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+        assert int(oa.step_t.item()) == k + 1
+        assert float((a - b).abs().max()) <= 1e-6
+
+
+def test_tracker_loss_entry_refuses_batches_beyond_its_limit():
+    import evennicer_slam_amd._lib as L
+    from tests.hip_util import tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    assert L.lib().enslam_tracker_tail_max_rays() == 4096
+    assert not renderer.tracker_loss_ok(5000, rays['gt_depth']) and renderer.tracker_loss_ok(4096, rays['gt_depth'])
+    with pytest.raises(ValueError):
+        renderer.render_batch_ray_tracker_loss(grids, model, rays['rays_d'].repeat(80, 1), rays['rays_o'].repeat(80, 1), 'cuda:0', 'color',
+                                               rays['gt_depth'].repeat(80), rays['gt_color'].repeat(80, 1))
