@@ -745,20 +745,19 @@ int enslam_render_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, con
 int enslam_render_tracker_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float* rays_o, const float* rays_d,
                                    const double* z_vals, const enslam_scene* scene, double* depth, double* var, float* rgb,
                                    float* raw_out, float* act_ws, int32_t act_light, const float* gt_depth, const float* gt_color,
-                                   float w_color, const uint8_t* inside, int32_t handle_dynamic, double* tmp_scratch, int32_t* ticket,
-                                   double* loss, float* d_raw_unit, int32_t* work_list, int32_t* work_count, void* stream) {
+                                   float w_color, const uint8_t* inside, int32_t handle_dynamic, double* tmp_scratch, double* loss,
+                                   float* d_raw_unit, int32_t* work_list, int32_t* work_count, void* stream) {
     if (n_rays < 0) return ENSLAM_EINVAL;
     if (n_rays == 0) return ENSLAM_OK;
     if (!samples_ok(n_samples) || n_rays > ENS_TRACKER_TAIL_MAX_RAYS || stage == ENSLAM_STAGE_COARSE) return ENSLAM_EUNSUPPORTED;
     DevScene d;
     if (!to_dev_scene(scene, d) || !stage_ok(stage, d)) return ENSLAM_EINVAL;
-    if (!rays_o || !rays_d || !z_vals || !depth || !var || !rgb || !raw_out || !gt_depth || !loss || !tmp_scratch || (handle_dynamic && !ticket))
-        return ENSLAM_EINVAL;
+    if (!rays_o || !rays_d || !z_vals || !depth || !var || !rgb || !raw_out || !gt_depth || !loss || !tmp_scratch) return ENSLAM_EINVAL;
     if (act_ws != nullptr)
         for (int k = 1; k < 4; ++k)
             if (d.grid[k].data && (int64_t)d.grid[k].D * d.grid[k].H * d.grid[k].W >= ACT_MAX_VOXELS) return ENSLAM_EUNSUPPORTED;
     const LossSpec ls{gt_depth, gt_color, w_color, loss, nullptr, d_raw_unit};
-    const TrackerSpec ts{inside, handle_dynamic != 0 ? 1 : 0, tmp_scratch, ticket};
+    const TrackerSpec ts{inside, handle_dynamic != 0 ? 1 : 0, tmp_scratch};
     WorkList wl;
     if (!work_list_of(work_list, work_count, wl) || (work_list && !d_raw_unit)) return ENSLAM_EINVAL;
     const int rc = ens_launch_render_fwd(stage, n_samples / 16, n_rays, rays_o, rays_d, z_vals, nullptr, 0, 1, d, depth, var, rgb,

@@ -20,8 +20,7 @@ struct LossSpec {
 struct TrackerSpec {
     const uint8_t* inside;       // [N] rays the in-bound prefilter keeps (Tracker.py:164-174, applied as a mask) or null: all
     int dynamic;                 // handle_dynamic (:180-182): keep rays with tmp < 10 * median(tmp over the kept rays)
-    double* tmp;                 // [N + 1] scratch: |gd - depth| / sqrt(var + 1e-10), then the median
-    int* ticket;                 // [1] workgroup counter, 0 on entry, left at 0 (dynamic only)
+    double* tmp;                 // [N] scratch: |gd - depth| / sqrt(var + 1e-10)
 };
 // Work list of the saved-activation backward: the 16-sample tiles (ray * ntl + tl) whose d_raw is not all zero, appended
 // ray by ray (a ray's tiles stay adjacent) by the kernel that produces d_raw; count[0] must be zero before that kernel.

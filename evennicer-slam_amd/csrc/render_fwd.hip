@@ -725,11 +725,9 @@ __global__ __launch_bounds__(1024) void composite_fwd_kernel(int n_rays, int S, 
 // The tracker's RGB-D loss on top of the compositing, forward and backward, in TWO launches of 16 rays per workgroup (batches of
 // up to ENS_TRACKER_TAIL_MAX_RAYS rays):
 //   tracker_composite_kernel: raw2outputs_nerf_color per ray (one wave per ray) and
-//       tmp = |gd - depth| / sqrt(var + 1e-10)                               (Tracker.py:179-181, float64 like the reference);
-//     the workgroup that finishes LAST (a ticket counter) sorts tmp over the inside rays in LDS and leaves the median
-//     (torch.median: the lower middle element) behind tmp's n entries -- no second launch and no waiting for it
+//       tmp = |gd - depth| / sqrt(var + 1e-10)                               (Tracker.py:179-181, float64 like the reference)
 //   tracker_loss_kernel:
-//       keep = inside & (tmp < 10 * median)                                   (:164-174 as a mask, :180-182)
+//       keep = inside & (tmp < 10 * median(tmp over the inside rays))         (:164-174 as a mask, :180-182; tracker_median_wg)
 //       loss = sum_{keep & gd > 0} tmp + w * sum_{keep & gd > 0} |gc - color| (:187-195)
 //     and d(loss)/d(raw) for a unit loss gradient (the variance is detached, :179), the work list of active tiles appended on
 //     the way.
@@ -740,8 +738,6 @@ __global__ __launch_bounds__(1024) void tracker_composite_kernel(int n_rays, int
                                                                  const double* __restrict__ z_vals, double* __restrict__ depth,
                                                                  double* __restrict__ var, float* __restrict__ rgb,
                                                                  const float* __restrict__ gd, TrackerSpec ts) {
-    __shared__ double srt[ENS_TRACKER_TAIL_MAX_RAYS];
-    __shared__ int s_last, s_cnt[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool valid = lane < S;
     const int ray = blockIdx.x * 16 + wave;
@@ -771,35 +767,32 @@ __global__ __launch_bounds__(1024) void tracker_composite_kernel(int n_rays, int
             ts.tmp[ray] = fabs((double)gd[ray] - dep) / sqrt(vr + 1e-10);
         }
     }
-    if (!ts.dynamic) return;                             // (uniform over the launch)
-    __threadfence();                                     // this workgroup's tmp entries are visible before its ticket is
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(ts.ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
-    __syncthreads();
-    if (!s_last) return;
-    // ---- the last workgroup: median of tmp over the inside rays
-    __threadfence();
+}
+
+// median of tmp over the inside rays (torch.median: the lower middle element), computed by EVERY workgroup of the loss launch for
+// itself from the n values the compositing launch left in memory: redundant, but parallel, and it needs neither a launch of its
+// own nor a hand-over between workgroups of one launch (a "last workgroup done" ticket was tried: its two device-scope fences
+// write back / invalidate the XCD's L2 and made the compositing launch 16 us instead of 5).  Up to 1024 rays by counting ranks
+// (1024 / P adjacent lanes share one entry and rank it against a slice of the others, eight LDS reads in flight); above that a
+// bitonic network in LDS.  Every thread of the workgroup must call this.
+ENS_DEV double tracker_median_wg(const TrackerSpec& ts, int n_rays, double* srt, int* s_cnt, double* s_med) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int P = 64;
     while (P < n_rays) P <<= 1;
     int kept = 0;
     for (int i = threadIdx.x; i < P; i += 1024) {
         const bool in = i < n_rays && (ts.inside == nullptr || ts.inside[i] != 0);
-        srt[i] = in ? __builtin_nontemporal_load(ts.tmp + i) : INFINITY;
+        srt[i] = in ? ts.tmp[i] : INFINITY;
         kept += in ? 1 : 0;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
     if (lane == 0) s_cnt[wave] = kept;
+    if (threadIdx.x == 0) *s_med = INFINITY;
     __syncthreads();
     int c = 0;
     for (int w = 0; w < 16; ++w) c += s_cnt[w];
     if (n_rays <= 1024) {
-        // small batch: the element of rank (c - 1) / 2 by counting (every thread ranks its own entry against all others: broadcast
-        // LDS reads, one barrier) instead of a 36-78-step sorting network with a barrier per step (12 us at 200 rays)
-        if (threadIdx.x == 0) { ts.tmp[n_rays] = INFINITY; *ts.ticket = 0; }
-        __syncthreads();                                 // (the default is in memory before the one thread that may overwrite it runs on)
-        // 1024 / P adjacent lanes share one entry, each ranks it against a slice of the others (eight LDS reads in flight; one
-        // thread per entry walking all of them was a 200-step chain of dependent-latency reads: 9 us)
         const int parts = 1024 / P, i = threadIdx.x / parts, part = threadIdx.x - i * parts;
         const int per = (n_rays + parts - 1) / parts, j0 = part * per, j1 = min(j0 + per, n_rays);
         const double mine = srt[i];
@@ -818,8 +811,9 @@ __global__ __launch_bounds__(1024) void tracker_composite_kernel(int n_rays, int
         }
         for (int o = 1; o < parts; o <<= 1) rank += __shfl_xor(rank, o);          // (parts is a power of two <= 16: lanes of one wave)
         // (+inf entries: rays outside the mask, never the median unless nothing finite is kept -- then the default stands)
-        if (part == 0 && i < n_rays && mine != INFINITY && c > 0 && rank == ((c - 1) >> 1)) ts.tmp[n_rays] = mine;
-        return;
+        if (part == 0 && i < n_rays && mine != INFINITY && c > 0 && rank == ((c - 1) >> 1)) *s_med = mine;
+        __syncthreads();
+        return *s_med;
     }
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -834,10 +828,7 @@ __global__ __launch_bounds__(1024) void tracker_composite_kernel(int n_rays, int
             __syncthreads();
         }
     }
-    if (threadIdx.x == 0) {
-        ts.tmp[n_rays] = c > 0 ? srt[(c - 1) >> 1] : INFINITY;
-        *ts.ticket = 0;                                  // ready for the next call (the counter is never cleared by anyone else)
-    }
+    return c > 0 ? srt[(c - 1) >> 1] : INFINITY;
 }
 
 // COMPOSITE: handle_dynamic off -- no median, so the compositing (outputs, tmp) happens here too: one launch
@@ -847,13 +838,19 @@ __global__ __launch_bounds__(1024) void tracker_loss_kernel(int n_rays, int S, c
                                                             double* __restrict__ var, float* __restrict__ rgb,
                                                             LossSpec ls, TrackerSpec ts, WorkList wk) {
     __shared__ double red[16];
+    __shared__ double srt[COMPOSITE ? 1 : ENS_TRACKER_TAIL_MAX_RAYS];
+    __shared__ int s_cnt[16];
+    __shared__ double s_med;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool valid = lane < S;
     const int ray_raw = blockIdx.x * 16 + wave;
     const bool rvalid = ray_raw < n_rays;
     const int ray = rvalid ? ray_raw : n_rays - 1;
     const int64_t sidx = (int64_t)ray * S + lane;
-    const double med = ts.dynamic ? ts.tmp[n_rays] : INFINITY;
+    double med = INFINITY;
+    if constexpr (!COMPOSITE) {
+        if (ts.dynamic) med = tracker_median_wg(ts, n_rays, srt, s_cnt, &s_med);
+    }
     const f32x4 rw = valid ? *reinterpret_cast<const f32x4*>(raw + sidx * 4) : splat4(0.f);
     const double zk = valid ? z_vals[sidx] : 0.0;
     const float alpha = valid ? 1.f / (1.f + expf(-(10.f * rw[3]))) : 0.f;
@@ -970,7 +967,6 @@ int ens_launch_tracker_tail(int n_rays, int S, const float* raw, const double* z
     WorkList wk{nullptr, nullptr};
     if (wl != nullptr && ls.d_raw_unit != nullptr) wk = *wl;
     if (wk.tiles != nullptr && S % 16 != 0) return -1;
-    if (ts.dynamic && !ts.ticket) return -1;
     const dim3 grid((n_rays + 15) / 16), block(1024);
     if (ts.dynamic) {
         tracker_composite_kernel<<<grid, block, 0, st>>>(n_rays, S, raw, z, depth, var, rgb, ls.gd, ts);

@@ -821,21 +821,6 @@ class _Accumulators:
         return n, dsts, vs, nd
 
 
-_tickets = {}
-
-
-def _tracker_ticket(dev):
-    """One int32 per device that the tracker's compositing launch counts its workgroups in and leaves at 0 again (the launches of
-    one stream are ordered; callers on different streams of one device would need their own)."""
-    t = _tickets.get(dev)
-    if t is None:
-        if _capturing():
-            raise L.EnslamError("the tracker's fused loss needs one eager call before it is captured (its ticket counter is allocated "
-                                "and cleared outside the graph)")
-        t = _tickets[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
-    return t
-
-
 class _RenderFn(torch.autograd.Function):
     """inputs: plan, rays_o, rays_d, gt_depth|None, t_rand|None, then for each kind in plan.kinds: grid,
     then for each kind: its parameters.  Outputs depth f64 [N], var f64 [N], rgb f32 [N,3]; with plan.loss the
@@ -995,12 +980,11 @@ class _RenderFn(torch.autograd.Function):
             d_raw_unit = torch.empty((N * S, 4), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
             if len(plan.loss) > 3:              # the tracker's loss (Tracker.py:176-195): (gd, gc, w, inside mask | None, handle_dynamic, 'tracker')
                 linside, ldyn = plan.loss[3], plan.loss[4]
-                tmp = torch.empty(N + 1, dtype=torch.float64, device=dev)
-                ticket = _tracker_ticket(dev)
+                tmp = torch.empty(N, dtype=torch.float64, device=dev)
                 L.check(lib.enslam_render_tracker_loss_fwd(L.STAGE[plan.stage], N, S, _ptr(ro), _ptr(rd), _ptr(z), ctypes.byref(sc),
                                                            _ptr(depth), _ptr(var), _ptr(rgb), _ptr(raw), _ptr(act), act_light, _ptr(lgd),
                                                            _ptr(lgc), ctypes.c_float(lw), _ptr(linside), int(bool(ldyn)), _ptr(tmp),
-                                                           _ptr(ticket), _ptr(loss), _ptr(d_raw_unit),
+                                                           _ptr(loss), _ptr(d_raw_unit),
                                                            _ptr(work) if d_raw_unit is not None else None,
                                                            _ptr(wcount) if d_raw_unit is not None else None, st),
                         "enslam_render_tracker_loss_fwd")

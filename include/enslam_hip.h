@@ -307,23 +307,23 @@ int enslam_tracker_rays(int32_t n, const float *camera_tensor, const int64_t *pi
                         void *stream);
 
 /* enslam_render_loss_fwd with the TRACKER's loss in place of the mapper's (batches of up to enslam_tracker_tail_max_rays()
- * rays; more: ENSLAM_EUNSUPPORTED): behind the decoder kernel two launches of 16 rays per workgroup -- compositing with
- *   tmp = |gt_depth - depth| / sqrt(var + 1e-10)
- * whose last-finishing workgroup takes the median of tmp over the inside rays (the lower median of torch.median, by a bitonic
- * sort of the batch in LDS), then
+ * rays; more: ENSLAM_EUNSUPPORTED): behind the decoder kernel two launches of 16 rays per workgroup (one without
+ * handle_dynamic) -- compositing with
+ *   tmp = |gt_depth - depth| / sqrt(var + 1e-10),
+ * then, every workgroup taking the median of tmp over the inside rays for itself (the lower median of torch.median; by counting
+ * ranks in LDS up to 1024 rays, a bitonic network above),
  *   keep = inside & (handle_dynamic ? tmp < 10 * median : 1),
  *   loss += sum_{keep & gt_depth > 0} tmp + w_color * sum_{keep & gt_depth > 0} |gt_color - color|   (gt_color NULL: depth term)
  * with d(loss)/d(raw) for a unit loss gradient in d_raw_unit and the work list of active tiles, the variance treated as a
- * constant.  inside NULL: every ray.  tmp_scratch: float64 [n_rays + 1].  ticket: int32 [1], 0 on entry, left at 0 (needed
- * with handle_dynamic).  *loss must be 0 on entry.
+ * constant.  inside NULL: every ray.  tmp_scratch: float64 [n_rays].  *loss must be 0 on entry.
  *   Replaces Tracker.optimize_cam_in_batch lines 176-195 around Renderer.render_batch_ray. */
 int enslam_tracker_tail_max_rays(void);
 int enslam_render_tracker_loss_fwd(int32_t stage, int32_t n_rays, int32_t n_samples, const float *rays_o, const float *rays_d,
                                    const double *z_vals, const enslam_scene *scene, double *depth, double *var, float *rgb,
                                    float *raw_out, float *act_ws, int32_t act_light, const float *gt_depth,
                                    const float *gt_color, float w_color, const uint8_t *inside, int32_t handle_dynamic,
-                                   double *tmp_scratch, int32_t *ticket, double *loss, float *d_raw_unit,
-                                   int32_t *work_list, int32_t *work_count, void *stream);
+                                   double *tmp_scratch, double *loss, float *d_raw_unit, int32_t *work_list,
+                                   int32_t *work_count, void *stream);
 
 /* Sample distances along rays (mark_scene / mark_flags non-NULL: also does enslam_mark_blocks' work for stage mark_stage
  * on the samples it has just placed -- one launch less per render call).
