@@ -36,7 +36,7 @@ model = copy.deepcopy(sc['model']).to(dev); bench.attach_bounds(model, sc['bound
 for name in ('coarse_decoder', 'middle_decoder', 'fine_decoder'):          # fix_fine: True; middle / coarse never optimised
     for p in getattr(model, name).parameters():
         p.requires_grad_(False)
-grids = {k: v.to(dev).clone() for k, v in sc['grids'].items()}
+grids = {k: v.to(dev).contiguous(memory_format=torch.channels_last_3d if os.environ.get('LAYOUT', 'channels_last_3d') == 'channels_last_3d' else torch.contiguous_format) for k, v in sc['grids'].items()}
 masks = {}
 for k in KEYS:
     D, Hh, Ww = grids[k].shape[2:]
