@@ -381,15 +381,42 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
         dmax_static = PAR.global_depth_max(gd_all if whole_batch else gd, force=force_comm and not whole_batch)
         renderer.depth_max_override = dmax_static
     prep = {'flags': None, 'prepared': None}
+    # The pre-step of iteration k + 1 (batch maxima, block marking of the WHOLE batch, prefix sum, bucket-size read) depends on
+    # nothing iteration k computes: it runs on a side stream under iteration k's gradient collective (two sets of flag buffers;
+    # it waits for k's local step, whose sampler still reads the batch maxima, and k + 1's local step waits for it).
+    # OFF by default (ENSLAM_BENCH_OVERLAP_PRE=1 switches it on): in the 1-rank RCCL rehearsal, where the collective is 31 us of
+    # pack / unpack glue and hides nothing, the two cross-stream waits cost more than the 48 us pre-step they move (0.334 vs
+    # 0.314 ms per step, two alternating pairs); with a real collective of 45-130 us it should pay -- unmeasured.
+    overlap_pre = whole_batch and os.environ.get('ENSLAM_BENCH_OVERLAP_PRE', '0') == '1'
+    pipe = {'side': torch.cuda.Stream() if overlap_pre else None, 'sets': [{'flags': None}, {'flags': None}], 'k': 0, 'ready': None}
+
+    def pre_body(slot):
+        torch.amax(gd_all, dim=0, keepdim=True, out=dmax_static[0:1])
+        torch.mul(dmax_static[0:1], 1.2, out=dmax_static[1:2])
+        slot['flags'] = PAR.batch_block_flags(renderer, grids, model, ro_all, rd_all, gd_all, stage, out=slot['flags'],
+                                              block_voxels=BUCKET_BLOCK)
+        slot['prepared'] = PAR.PreparedFlags([slot['flags'][id(t)] for t in leaves if t.dim() == 5], block_voxels=BUCKET_BLOCK,
+                                             coarse=[slot['flags'][('c64', id(t))] for t in leaves if t.dim() == 5] if BUCKET_BLOCK != 64 else None)
+
+    def pre_launch_next():      # (called right behind the local step of the current iteration)
+        nxt = pipe['sets'][(pipe['k'] + 1) & 1]
+        pipe['side'].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(pipe['side']):
+            pre_body(nxt)
+            pipe['ready'] = torch.cuda.Event()
+            pipe['ready'].record()
 
     def pre():          # what precedes the local step, outside the graph
-        if whole_batch:
-            torch.amax(gd_all, dim=0, keepdim=True, out=dmax_static[0:1])
-            torch.mul(dmax_static[0:1], 1.2, out=dmax_static[1:2])
-            prep['flags'] = PAR.batch_block_flags(renderer, grids, model, ro_all, rd_all, gd_all, stage, out=prep['flags'],
-                                                  block_voxels=BUCKET_BLOCK)
-            prep['prepared'] = PAR.PreparedFlags([prep['flags'][id(t)] for t in leaves if t.dim() == 5], block_voxels=BUCKET_BLOCK,
-                                                 coarse=[prep['flags'][('c64', id(t))] for t in leaves if t.dim() == 5] if BUCKET_BLOCK != 64 else None)
+        if overlap_pre:
+            if pipe['ready'] is None:           # first iteration: nothing was launched ahead
+                pre_body(pipe['sets'][pipe['k'] & 1])
+            else:
+                pipe['k'] += 1
+                torch.cuda.current_stream().wait_event(pipe['ready'])
+            cur = pipe['sets'][pipe['k'] & 1]
+            prep['flags'], prep['prepared'] = cur['flags'], cur['prepared']
+        elif whole_batch:
+            pre_body(prep)
         elif dmax_static is not None:       # batch-global sampler maxima over all shards (tiny MAX all-reduce)
             PAR.global_depth_max(gd, force=force_comm, out=dmax_static)
 
@@ -427,6 +454,8 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
     def step():
         pre()
         loss = local_step()
+        if overlap_pre:
+            pre_launch_next()
         post()
         return loss
 
@@ -521,6 +550,8 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
                 if phases is None:
                     pre()
                     out = gstep.replay()
+                    if overlap_pre:
+                        pre_launch_next()
                     post()
                     return out
                 # diagnostic: host-synchronised time of the three phases (changes the timing; not a measurement)
@@ -559,9 +590,13 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
     if comm_on:
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(20)]
         local = (lambda: gstep.replay()) if (mode == 'hipgraph' and gstep is not None) else local_step
-        for e in ev:
+        torch.cuda.synchronize()
+        for e in ev:                # (the three parts in line, one after the other: the pre-step is NOT overlapped here)
             e[0].record()
-            pre()
+            if whole_batch:
+                pre_body(prep)
+            else:
+                pre()
             e[1].record()
             local()
             e[2].record()
@@ -597,6 +632,7 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
     if comm_on:
         out["comm"] = dict(comm_ms, bucket_bytes=int(comm['bytes']), mode=mode,
                            flags="marked locally from the whole batch" if whole_batch else "MAX all-reduce of per-rank flags",
+                           pre_step="side stream, under the previous iteration's collective" if overlap_pre else "in line",
                            bucket_block_voxels=BUCKET_BLOCK if whole_batch else 64)
     if events:
         dur = np.array([a.elapsed_time(b) for a, b in events]) * 1e-3          # seconds
