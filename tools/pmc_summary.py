@@ -8,7 +8,7 @@ for f in glob.glob(O + "/pmc_*/**/*counter_collection.csv", recursive=True):
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, cs in sorted(acc.items()):
-    if not any(s in k for s in ("decoder_bwd", "render_fwd", "grid_bwd", "convert_kernel", "step_kernel", "composite", "sample_kernel")):
+    if not any(s in k for s in ("decoder_bwd", "render_fwd", "grid_bwd", "convert_kernel", "step_kernel", "composite", "sample_kernel", "sample_prepare", "tracker_")):
         continue
     d = {c: round(sum(v) / len(v), 1) for c, v in cs.items()}
     d["dispatches"] = max(len(v) for v in cs.values())
