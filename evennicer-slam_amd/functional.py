@@ -104,6 +104,7 @@ def end_capture(ok=True):
         for ptr, _pv in (_capture['persist'] or {}).values():
             _persist_prev.pop(ptr, None)
         _capture['persist'] = None
+        _capture['persist_need'] = {}
         end_capture.persist_keys = []
         return []
     for storage in init:
