@@ -306,3 +306,51 @@ def test_tracker_loss_entry_refuses_batches_beyond_its_limit():
     with pytest.raises(ValueError):
         renderer.render_batch_ray_tracker_loss(grids, model, rays['rays_d'].repeat(80, 1), rays['rays_o'].repeat(80, 1), 'cuda:0', 'color',
                                                rays['gt_depth'].repeat(80), rays['gt_color'].repeat(80, 1))
+
+
+@pytest.mark.parametrize("dynamic", [True, False])
+def test_fused_and_launch_per_step_routes_of_the_rgbd_term_agree(monkeypatch, dynamic):
+    """TrackerIteration._rgbd_loss through the fused launches (enslam_tracker_rays + enslam_render_tracker_loss_fwd) and through
+    the launch-per-step route (ENSLAM_TRACKER_FUSED=0: gather, pose, prefilter and median as torch ops, losses.tracker_loss) on
+    the same pixel draw: same loss, same gradient to the camera tensor."""
+    import types
+    import evennicer_slam_amd as E
+    from tests.hip_util import DEV, cfg_like, tiny_on_gpu
+    g = load("tiny_tracker_iter")
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    H, W, fx, fy, cx, cy = [float(x) for x in g['cam']]
+    H, W = int(H), int(W)
+    He, We = int(g['edge'][0]), int(g['edge'][1])
+    n = 96
+    idx = torch.randint((H - 2 * He) * (W - 2 * We), (n,), generator=torch.Generator().manual_seed(4)).to(DEV)
+    monkeypatch.setattr(torch, 'randint', lambda *a, **k: idx)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    try:
+        cfg = cfg_like()
+        cfg['tracking'] = {'device': DEV, 'w_color_loss': 0.5, 'ignore_edge_W': We, 'ignore_edge_H': He, 'handle_dynamic': dynamic,
+                           'use_color_in_tracking': True, 'lr': 1e-3, 'pixels': n, 'iters': 4}
+        cfg['event'] = {'activate_events': False, 'blur': False, 'kernel_sizes': [9], 'kernel_weights': [1], 'unblurred_weight': 0,
+                        'balancer': 0.025}
+        slam = types.SimpleNamespace(nice=True, bound=bound, renderer=renderer, event_net=None, low_gpu_mem=False, H=H, W=W, fx=fx,
+                                     fy=fy, cx=cx, cy=cy)
+        trk = E.tracker.TrackerIteration(cfg, None, slam)
+        trk.c, trk.decoders = grids, model
+        gd_img, gc_img = torch.from_numpy(g['gt_depth']).to(DEV), torch.from_numpy(g['gt_color']).to(DEV)
+        out = []
+        for fused in (True, False):
+            monkeypatch.setattr(E.tracker, 'FUSED_ITERATION', fused)
+            ct = torch.from_numpy(g['camera_tensor']).to(DEV).requires_grad_(True)
+            for static in ((True, False) if not fused else (False,)):
+                ct.grad = None
+                loss = trk._rgbd_loss(ct, gc_img, gd_img, n, static)
+                loss.backward()
+                out.append((loss.item(), ct.grad.clone()))
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(True)
+    (l0, g0) = out[0]
+    assert l0 > 0 and float(g0.abs().max()) > 0
+    for l1, g1 in out[1:]:
+        assert abs(l0 - l1) <= 1e-6 * abs(l1)
+        assert float((g0 - g1).abs().max()) <= 1e-4 * float(g1.abs().max())
