@@ -214,3 +214,48 @@ def test_sample_prepare_entry_equals_the_two_launches():
                                       None, 0, None, None, None, 0, None, None, None, EF._ptr(flat), 100, None), "sample_prepare")
     torch.cuda.synchronize()
     assert float(flat[:100].abs().sum()) == 0.0 and float(flat[100]) == 1.0
+
+
+def test_reference_mapper_formulation_on_native_grids():
+    """The reference's optimize_map statements around this renderer (Mapper.py:343-361, 448-458, 573-602: compact leaves
+    `val[mask]`, `val[mask] = val_grad` re-materialisation every iteration, torch.optim.Adam, write-back) with the shared grids in
+    channels_last_3d: the same optimised voxels as with contiguous grids (the grid handed to the renderer is then a NON-leaf
+    channels_last_3d tensor whose gradient flows on through IndexPutBackward)."""
+    import evennicer_slam_amd as E
+    from tests.hip_util import DEV, as_layout, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    try:
+        res = {}
+        for layout in ('contiguous', 'channels_last_3d'):
+            c = {k: as_layout(v, layout) for k, v in grids.items()}
+            gen = torch.Generator().manual_seed(9)
+            mask5, leaf = {}, {}
+            for k in KEYS:
+                m = (torch.rand(tuple(c[k].shape[2:]), generator=gen) < 0.6).to(DEV)
+                mask5[k] = m[None, None].repeat(1, 32, 1, 1, 1)
+                leaf[k] = c[k][mask5[k]].clone().requires_grad_(True)
+            opt = torch.optim.Adam([leaf[k] for k in KEYS], lr=0.01)
+            for _ in range(2):
+                for k in KEYS:
+                    val = c[k]
+                    val[mask5[k]] = leaf[k]
+                    c[k] = val
+                opt.zero_grad()
+                depth, var, color = renderer.render_batch_ray(c, model, rays['rays_d'], rays['rays_o'], DEV, 'color', gt_depth=rays['gt_depth'])
+                E.losses.rgbd_loss(depth, color, rays['gt_depth'], rays['gt_color'], 0.2).backward()
+                opt.step()
+                for k in KEYS:
+                    val = c[k].detach()
+                    val[mask5[k]] = leaf[k].clone().detach()
+                    c[k] = val
+            assert all(c[k].is_contiguous(memory_format=torch.channels_last_3d) == (layout == 'channels_last_3d') for k in KEYS)
+            res[layout] = {k: c[k].contiguous().clone() for k in KEYS}
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(True)
+    for k in KEYS:
+        a, b = res['contiguous'][k], res['channels_last_3d'][k]
+        assert float((a - grids[k]).abs().max()) > 1e-3                      # (something was optimised)
+        assert float((a - b).abs().max()) <= 1e-5 + 2e-4 * 0.01 * 2, k
