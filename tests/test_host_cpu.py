@@ -136,3 +136,35 @@ def test_sample_pdf_matches_reference_fixture():
         assert np.array_equal(sample_pdf(bins, w, n, det=True, device='cpu').numpy(), fx[f'c{case}_det'])
         torch.manual_seed(100 + case)
         assert np.array_equal(sample_pdf(bins, w, n, det=False, device='cpu').numpy(), fx[f'c{case}_rand'])
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every entry of _lib._SIGS takes as many arguments, of the same broad kind (integer / floating point / pointer), as the
+    declaration in include/enslam_hip.h -- an ABI drift between the header and the Python binding would otherwise only show as
+    garbage arguments on the GPU."""
+    import evennicer_slam_amd as E
+    header = open(os.path.join(ROOT, "include", "enslam_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    decls = dict(re.findall(r"\b(enslam_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S))
+    assert set(decls) >= set(E._lib._SIGS)
+
+    def kind_c(param):
+        p = " ".join(param.split())
+        if p in ("", "void"):
+            return None
+        if "*" in p:
+            return "ptr"
+        return "fp" if re.search(r"\b(float|double)\b", p) else "int"
+
+    def kind_py(t):
+        if t in (ctypes.c_float, ctypes.c_double):
+            return "fp"
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or getattr(t, "_type_", None) is not None and not isinstance(
+                getattr(t, "_type_"), str):
+            return "ptr"
+        return "int"
+
+    for name, (_res, args) in E._lib._SIGS.items():
+        want = [k for k in (kind_c(p) for p in decls[name].split(",")) if k is not None]
+        got = [kind_py(t) for t in args]
+        assert got == want, (name, got, want)
