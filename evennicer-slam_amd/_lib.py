@@ -29,6 +29,25 @@ class Scene(ctypes.Structure):
                 ("packed", c_void_p * 4)]
 
 
+class StepPlan(ctypes.Structure):             # enslam_step_plan
+    _fields_ = [("stage", c_int32), ("n_rays", c_int32), ("n_lin", c_int32), ("n_surf", c_int32), ("lindisp", c_int32),
+                ("act_light", c_int32), ("need_rays", c_int32), ("use_work_list", c_int32), ("loss_kind", c_int32), ("use_color", c_int32),
+                ("w_color", ctypes.c_float), ("grid_mode", c_int32 * 4), ("par_grad", c_int32 * 4),
+                ("grid_D", c_int32 * 4), ("grid_H", c_int32 * 4), ("grid_W", c_int32 * 4),
+                ("bound", c_double * 6), ("coarse_bound", c_double * 6), ("params", MlpParams * 4),
+                ("pgrad_off", (c_int64 * 23) * 4), ("pgrad_floats", c_int64), ("t_lin", c_void_p), ("t_surf", c_void_p)]
+
+
+class StepLayout(ctypes.Structure):           # enslam_step_layout
+    _fields_ = [("scratch_bytes", c_int64), ("grad_bytes", c_int64), ("out_bytes", c_int64), ("s_zero_bytes", c_int64),
+                ("s_flags", c_int64 * 4), ("s_packed", c_int64 * 4), ("s_z", c_int64), ("s_dmax", c_int64), ("s_raw", c_int64),
+                ("s_act", c_int64), ("s_work", c_int64), ("s_draw", c_int64), ("s_dgw", c_int64), ("s_vm", c_int64 * 4),
+                ("s_gacc", c_int64 * 4), ("g_flat", c_int64), ("g_flat_floats", c_int64), ("g_packed", c_int64 * 4),
+                ("g_ro", c_int64), ("g_rd", c_int64), ("g_counter", c_int64), ("g_nat", c_int64 * 4), ("g_params", c_int64),
+                ("g_dense", c_int64 * 4), ("o_depth", c_int64), ("o_var", c_int64), ("o_rgb", c_int64), ("o_loss", c_int64),
+                ("n_samples", c_int32), ("finish_needed", c_int32), ("inline_rays", c_int32), ("merged", c_int32)]
+
+
 class EnslamError(RuntimeError):
     pass
 
@@ -161,6 +180,12 @@ _SIGS = {
                                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                                       ctypes.c_float, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                       c_void_p]),
+    "enslam_plan_struct_bytes": (c_int64, [c_int32]),
+    "enslam_plan_layout": (ctypes.c_int, [POINTER(StepPlan), POINTER(StepLayout)]),
+    "enslam_plan_forward": (ctypes.c_int, [POINTER(StepPlan), POINTER(StepLayout), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
+    "enslam_plan_backward": (ctypes.c_int, [POINTER(StepPlan), POINTER(StepLayout), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "enslam_rgbd_loss_fwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,
                                             c_void_p]),
     "enslam_rgbd_loss_bwd": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p,
@@ -193,6 +218,9 @@ def lib():
             fn.argtypes = args
         if handle.enslam_abi_version() != 1:
             raise EnslamError("libenslam_hip.so ABI version mismatch")
+        if hasattr(handle, "enslam_plan_struct_bytes") and (handle.enslam_plan_struct_bytes(0) != ctypes.sizeof(StepPlan) or
+                                                           handle.enslam_plan_struct_bytes(1) != ctypes.sizeof(StepLayout)):
+            raise EnslamError("libenslam_hip.so: enslam_step_plan / enslam_step_layout do not have the sizes this binding declares")
         _lib = handle
     return _lib
 

@@ -962,3 +962,243 @@ int enslam_fourier_sincos(int64_t n, const float* x, float* sin_out, float* cos_
     if (!x || (!sin_out && !cos_out)) return ENSLAM_EINVAL;
     return ens_launch_sincos(n, x, sin_out, cos_out, (hipStream_t)stream);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// step plans (include/enslam_hip.h): the launches of one differentiable render call behind two entry points
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+int64_t plan_align(int64_t b) { return (b + 255) & ~(int64_t)255; }
+bool plan_ok(const enslam_step_plan* p) {
+    if (!p || p->stage < ENSLAM_STAGE_MIDDLE || p->stage > ENSLAM_STAGE_COLOR || p->n_rays <= 0 || p->n_lin < 1 || p->n_surf < 0) return false;
+    if (!samples_ok(p->n_lin + p->n_surf) || !p->t_lin || (p->n_surf > 0 && !p->t_surf)) return false;
+    for (int k = 1; k < 4; ++k) {
+        const bool used = k <= p->stage;
+        if (used != (p->grid_mode[k] != 0) || p->grid_mode[k] < 0 || p->grid_mode[k] > 3) return false;
+        if (used && (p->grid_D[k] < 1 || p->grid_H[k] < 1 || p->grid_W[k] < 1)) return false;
+        if (!used && p->par_grad[k]) return false;
+    }
+    if (p->grid_mode[0] != 0 || p->par_grad[0]) return false;
+    return p->loss_kind == 0 || p->loss_kind == 1;
+}
+int64_t plan_voxels(const enslam_step_plan* p, int k) { return (int64_t)p->grid_D[k] * p->grid_H[k] * p->grid_W[k]; }
+template <typename T> T* at(void* base, int64_t off) { return off < 0 ? nullptr : reinterpret_cast<T*>(static_cast<char*>(base) + off); }
+}  // namespace
+
+int64_t enslam_plan_struct_bytes(int32_t which) { return which == 0 ? (int64_t)sizeof(enslam_step_plan) : (int64_t)sizeof(enslam_step_layout); }
+
+int enslam_plan_layout(const enslam_step_plan* plan, enslam_step_layout* L) {
+    if (!plan_ok(plan) || !L) return ENSLAM_EINVAL;
+    const int N = plan->n_rays, S = plan->n_lin + plan->n_surf;
+    const int64_t ntiles = (int64_t)N * (S / 16);
+    bool any_par = false, any_m3 = false;
+    for (int k = 1; k < 4; ++k) { any_par = any_par || plan->par_grad[k]; any_m3 = any_m3 || plan->grid_mode[k] == 3; }
+    if ((plan->act_light != 0) == any_par) return ENSLAM_EINVAL;           // the light workspace iff no decoder parameter wants a gradient
+    L->n_samples = S;
+    L->finish_needed = (any_par || any_m3) ? 1 : 0;
+    L->inline_rays = L->finish_needed ? 0 : 1;
+    L->merged = any_m3 ? 0 : 1;
+    // ---- scratch blob
+    int64_t o = 0;
+    for (int k = 0; k < 4; ++k) {
+        L->s_flags[k] = -1;
+        if (plan->grid_mode[k] >= 2) { L->s_flags[k] = o; o = plan_align(o + (plan_voxels(plan, k) + 63) / 64); }
+    }
+    for (int k = 0; k < 4; ++k) {
+        L->s_packed[k] = -1;
+        if (plan->grid_mode[k] != 0) { L->s_packed[k] = o; o = plan_align(o + 4 * (int64_t)enslam_packed_floats(k)); }
+    }
+    L->s_zero_bytes = o;
+    L->s_z = o; o = plan_align(o + 8 * (int64_t)N * S);
+    L->s_dmax = o; o = plan_align(o + 8);
+    L->s_raw = o; o = plan_align(o + 16 * (int64_t)N * S);
+    L->s_act = o; o = plan_align(o + 4 * (int64_t)enslam_activation_floats(plan->stage, N, S, plan->act_light));
+    L->s_work = -1;
+    if (plan->use_work_list) { L->s_work = o; o = plan_align(o + 4 * ntiles); }
+    L->s_draw = o; o = plan_align(o + 16 * (int64_t)N * S);
+    L->s_dgw = -1;
+    if (plan->need_rays && !L->inline_rays) { L->s_dgw = o; o = plan_align(o + 4 * (int64_t)enslam_grid_handoff_floats(plan->stage, N, S)); }
+    for (int k = 0; k < 4; ++k) {
+        L->s_vm[k] = L->s_gacc[k] = -1;
+        if (plan->grid_mode[k] == 3) {
+            L->s_vm[k] = o; o = plan_align(o + 128 * plan_voxels(plan, k));
+            L->s_gacc[k] = o; o = plan_align(o + 128 * plan_voxels(plan, k));
+        }
+    }
+    L->scratch_bytes = o;
+    // ---- gradient blob: [flat range cleared by the forward | parameter gradients | dense channel-major grid gradients]
+    int64_t f = 0;                                                         // floats
+    for (int k = 0; k < 4; ++k) {
+        L->g_packed[k] = -1;
+        if (plan->par_grad[k]) { L->g_packed[k] = 4 * f; f += (int64_t)enslam_packed_grad_floats(k); f = (f + 3) & ~(int64_t)3; }
+    }
+    L->g_ro = L->g_rd = -1;
+    if (plan->need_rays) { L->g_ro = 4 * f; f += 3 * (int64_t)N; L->g_rd = 4 * f; f += 3 * (int64_t)N; f = (f + 3) & ~(int64_t)3; }
+    for (int k = 0; k < 4; ++k) {
+        L->g_nat[k] = -1;
+        if (plan->grid_mode[k] == 2) { L->g_nat[k] = 4 * f; f += 32 * plan_voxels(plan, k); }
+    }
+    f = (f + 3) & ~(int64_t)3;
+    L->g_counter = 4 * f; f += 4;                                          // int32 work-list counter (+ padding)
+    L->g_flat = 0;
+    L->g_flat_floats = f;
+    o = plan_align(4 * f);
+    L->g_params = -1;
+    if (any_par) { L->g_params = o; o = plan_align(o + 4 * plan->pgrad_floats); }
+    for (int k = 0; k < 4; ++k) {
+        L->g_dense[k] = -1;
+        if (plan->grid_mode[k] == 3) { L->g_dense[k] = o; o = plan_align(o + 128 * plan_voxels(plan, k)); }
+    }
+    L->grad_bytes = o;
+    // ---- outputs
+    o = 0;
+    L->o_depth = o; o = plan_align(o + 8 * (int64_t)N);
+    L->o_var = o; o = plan_align(o + 8 * (int64_t)N);
+    L->o_rgb = o; o = plan_align(o + 12 * (int64_t)N);
+    L->o_loss = o; o = plan_align(o + 8);
+    L->out_bytes = o;
+    return ENSLAM_OK;
+}
+
+namespace {
+// scene of a plan call: grid values (converted copy for mode 3), packed decoders
+void plan_scene(const enslam_step_plan* plan, const enslam_step_layout* L, void* scratch, const float* const* grid_values, enslam_scene& sc) {
+    for (int i = 0; i < 6; ++i) { sc.bound[i] = plan->bound[i]; sc.coarse_bound[i] = plan->coarse_bound[i]; }
+    for (int k = 0; k < 4; ++k) {
+        sc.grids[k].data = nullptr; sc.grids[k].D = sc.grids[k].H = sc.grids[k].W = 0; sc.packed[k] = nullptr;
+        if (plan->grid_mode[k] == 0) continue;
+        sc.grids[k].D = plan->grid_D[k]; sc.grids[k].H = plan->grid_H[k]; sc.grids[k].W = plan->grid_W[k];
+        sc.grids[k].data = plan->grid_mode[k] == 3 ? at<float>(scratch, L->s_vm[k]) : const_cast<float*>(grid_values[k]);
+        sc.packed[k] = at<float>(scratch, L->s_packed[k]);
+    }
+}
+}  // namespace
+
+int enslam_plan_forward(const enslam_step_plan* plan, const enslam_step_layout* L, void* scratch, void* grad, void* out,
+                        const float* rays_o, const float* rays_d, const float* gt_depth, const float* gt_color,
+                        const float* depth_max, const float* const* grid_values, void* stream) {
+    if (!plan_ok(plan) || !L || !scratch || !out || !rays_o || !rays_d || !gt_depth || !grid_values) return ENSLAM_EINVAL;
+    if (L->grad_bytes > 0 && !grad) return ENSLAM_EINVAL;
+    const int N = plan->n_rays, S = L->n_samples;
+    for (int k = 1; k < 4; ++k)
+        if (plan->grid_mode[k] != 0 && !grid_values[k]) return ENSLAM_EINVAL;
+    if (L->s_zero_bytes > 0 && hipMemsetAsync(scratch, 0, (size_t)L->s_zero_bytes, (hipStream_t)stream) != hipSuccess) return ENSLAM_ELAUNCH;
+    // block marking of the grids with gradient
+    enslam_scene msc;
+    for (int i = 0; i < 6; ++i) { msc.bound[i] = plan->bound[i]; msc.coarse_bound[i] = plan->coarse_bound[i]; }
+    uint8_t* fptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool marking = false;
+    for (int k = 0; k < 4; ++k) {
+        msc.grids[k].data = nullptr; msc.grids[k].D = msc.grids[k].H = msc.grids[k].W = 0; msc.packed[k] = nullptr;
+        if (plan->grid_mode[k] >= 2) {
+            msc.grids[k].D = plan->grid_D[k]; msc.grids[k].H = plan->grid_H[k]; msc.grids[k].W = plan->grid_W[k];
+            fptr[k] = at<uint8_t>(scratch, L->s_flags[k]);
+            marking = true;
+        }
+    }
+    // prepare roles: pack every decoder of the stage, clear the accumulators
+    int32_t kinds[3]; enslam_mlp_params structs[3]; float* packed[3]; int nd = 0;
+    for (int k = 1; k < 4; ++k)
+        if (plan->grid_mode[k] != 0) { kinds[nd] = k; structs[nd] = plan->params[k]; packed[nd] = at<float>(scratch, L->s_packed[k]); ++nd; }
+    float* zdst[4]; int64_t zvox[4]; const uint8_t* zneed[4]; int nz = 0;
+    const float* csrc[4]; float* cdst[4]; int64_t cvox[4]; const uint8_t* cneed[4]; int nc = 0;
+    for (int k = 1; k < 4; ++k)
+        if (plan->grid_mode[k] == 3) {
+            zdst[nz] = at<float>(scratch, L->s_gacc[k]); zvox[nz] = plan_voxels(plan, k); zneed[nz] = fptr[k]; ++nz;
+            csrc[nc] = grid_values[k]; cdst[nc] = at<float>(scratch, L->s_vm[k]); cvox[nc] = plan_voxels(plan, k); cneed[nc] = fptr[k]; ++nc;
+        }
+    float* flat = L->g_flat_floats > 0 ? at<float>(grad, L->g_flat) : nullptr;
+    float* dmax = depth_max ? const_cast<float*>(depth_max) : at<float>(scratch, L->s_dmax);
+    double* z = at<double>(scratch, L->s_z);
+    int rc;
+    if (L->merged) {
+        rc = enslam_sample_prepare(N, plan->n_lin, plan->n_surf, rays_o, rays_d, gt_depth, plan->bound, plan->t_lin, plan->t_surf, plan->lindisp,
+                                   nullptr, dmax, depth_max != nullptr, z, plan->stage, marking ? &msc : nullptr, marking ? fptr : nullptr, 64,
+                                   nullptr, nd, kinds, structs, packed, nz, zdst, zvox, zneed, flat, L->g_flat_floats, stream);
+        if (rc != ENSLAM_OK) return rc;
+    } else {
+        rc = enslam_sample_rays(N, plan->n_lin, plan->n_surf, rays_o, rays_d, gt_depth, plan->bound, plan->t_lin, plan->t_surf, plan->lindisp,
+                                nullptr, dmax, depth_max != nullptr, z, plan->stage, marking ? &msc : nullptr, marking ? fptr : nullptr, stream);
+        if (rc != ENSLAM_OK) return rc;
+        rc = enslam_step_prepare(nd, kinds, structs, packed, nc, csrc, cdst, cvox, cneed, nullptr, nz, zdst, zvox, zneed, flat,
+                                 L->g_flat_floats, stream);
+        if (rc != ENSLAM_OK) return rc;
+    }
+    enslam_scene sc;
+    plan_scene(plan, L, scratch, grid_values, sc);
+    float* act = at<float>(scratch, L->s_act);
+    if (plan->loss_kind == 0)
+        return enslam_render_fwd(plan->stage, N, S, rays_o, rays_d, z, &sc, at<double>(out, L->o_depth), at<double>(out, L->o_var),
+                                 at<float>(out, L->o_rgb), at<float>(scratch, L->s_raw), act, plan->act_light, stream);
+    if (hipMemsetAsync(at<double>(out, L->o_loss), 0, 8, (hipStream_t)stream) != hipSuccess) return ENSLAM_ELAUNCH;
+    const bool want_grad = L->grad_bytes > 0;
+    return enslam_render_loss_fwd(plan->stage, N, S, rays_o, rays_d, z, &sc, at<double>(out, L->o_depth), at<double>(out, L->o_var),
+                                  at<float>(out, L->o_rgb), at<float>(scratch, L->s_raw), act, plan->act_light, gt_depth,
+                                  plan->use_color ? gt_color : nullptr, plan->w_color, at<double>(out, L->o_loss),
+                                  want_grad ? at<float>(scratch, L->s_draw) : nullptr,
+                                  (want_grad && plan->use_work_list) ? at<int32_t>(scratch, L->s_work) : nullptr,
+                                  (want_grad && plan->use_work_list) ? at<int32_t>(grad, L->g_counter) : nullptr, stream);
+}
+
+int enslam_plan_backward(const enslam_step_plan* plan, const enslam_step_layout* L, void* scratch, void* grad, void* out,
+                         const float* rays_o, const float* rays_d, const float* gt_depth, const float* gt_color,
+                         const float* const* grid_values, const double* g_depth, const double* g_var, const float* g_rgb,
+                         const double* g_loss, void* stream) {
+    if (!plan_ok(plan) || !L || !scratch || !grad || !out || !rays_o || !rays_d || !grid_values) return ENSLAM_EINVAL;
+    (void)gt_depth; (void)gt_color;
+    const int N = plan->n_rays, S = L->n_samples;
+    enslam_scene sc;
+    plan_scene(plan, L, scratch, grid_values, sc);
+    double* z = at<double>(scratch, L->s_z);
+    int32_t* work = plan->use_work_list ? at<int32_t>(scratch, L->s_work) : nullptr;
+    int32_t* wcount = plan->use_work_list ? at<int32_t>(grad, L->g_counter) : nullptr;
+    float* d_raw = at<float>(scratch, L->s_draw);
+    const double* d_scale = nullptr;
+    int rc;
+    if (plan->loss_kind == 1) {
+        if (!g_loss) return ENSLAM_EINVAL;
+        d_scale = g_loss;                                   // unit gradients from the forward, scaled inside the decoder backward
+    } else {
+        rc = enslam_composite_bwd_list(N, S, at<float>(scratch, L->s_raw), z, at<double>(out, L->o_depth), g_depth, g_var, g_rgb, d_raw,
+                                       work, wcount, stream);
+        if (rc != ENSLAM_OK) return rc;
+    }
+    enslam_grid gg[4];
+    float* gpk[4]; float* gpart[4];
+    for (int k = 0; k < 4; ++k) {
+        gg[k].data = nullptr; gg[k].D = plan->grid_D[k]; gg[k].H = plan->grid_H[k]; gg[k].W = plan->grid_W[k];
+        gpk[k] = nullptr; gpart[k] = nullptr;
+        if (plan->grid_mode[k] == 2) gg[k].data = at<float>(grad, L->g_nat[k]);
+        else if (plan->grid_mode[k] == 3) gg[k].data = at<float>(scratch, L->s_gacc[k]);
+        if (plan->par_grad[k]) gpk[k] = at<float>(grad, L->g_packed[k]);
+    }
+    float* p_ro = plan->need_rays ? at<float>(grad, L->g_ro) : nullptr;
+    float* p_rd = plan->need_rays ? at<float>(grad, L->g_rd) : nullptr;
+    float* dgw = at<float>(scratch, L->s_dgw);
+    rc = enslam_decoder_bwd_partials(plan->stage, N, S, rays_o, rays_d, z, &sc, d_raw, d_scale, at<float>(scratch, L->s_act), plan->act_light,
+                                     dgw, gg, gpk, gpart, p_ro, p_rd, work, wcount, stream);
+    if (rc != ENSLAM_OK) return rc;
+    // finish launch: channel-major grid gradients, decoder gradients into the parameter region, ray gradients from the hand-off
+    const float* csrc[4]; float* cdst[4]; int64_t cvox[4]; const uint8_t* cneed[4]; int nc = 0;
+    for (int k = 1; k < 4; ++k)
+        if (plan->grid_mode[k] == 3) {
+            csrc[nc] = at<float>(scratch, L->s_gacc[k]); cdst[nc] = at<float>(grad, L->g_dense[k]); cvox[nc] = plan_voxels(plan, k);
+            cneed[nc] = at<uint8_t>(scratch, L->s_flags[k]); ++nc;
+        }
+    int32_t kinds[4]; const float* pk[4]; const float* parts[4]; enslam_mlp_params gs[4]; int npk = 0;
+    float* pbase = at<float>(grad, L->g_params);
+    for (int k = 1; k < 4; ++k)
+        if (plan->par_grad[k]) {
+            kinds[npk] = k; pk[npk] = gpk[k]; parts[npk] = nullptr;
+            enslam_mlp_params& g = gs[npk];
+            const int64_t* off = plan->pgrad_off[k];
+            int j = 0;
+            for (int i = 0; i < 5; ++i) { g.W[i] = pbase + off[j++]; g.b[i] = pbase + off[j++]; }
+            for (int i = 0; i < 5; ++i) { g.Wc[i] = pbase + off[j++]; g.bc[i] = pbase + off[j++]; }
+            g.Wo = pbase + off[j++]; g.bo = pbase + off[j++]; g.B = pbase + off[j++];
+            ++npk;
+        }
+    const bool ray_pending = dgw != nullptr;
+    if (nc == 0 && npk == 0 && !ray_pending) return ENSLAM_OK;
+    return enslam_step_finish_native(nc, csrc, cdst, cvox, cneed, nullptr, npk, kinds, pk, parts, gs, plan->stage, ray_pending ? N : 0, S, rays_o,
+                                     rays_d, z, &sc, ray_pending ? dgw : nullptr, p_ro, p_rd, work, wcount, nullptr, nullptr, 0, stream);
+}

@@ -1280,7 +1280,289 @@ except Exception:           # pragma: no cover
     _render_apply = None
 
 
+# ------------------------------------------------------------------------------------------------
+# step plans: the Python-driven call with its host work cached (include/enslam_hip.h, "Step plans")
+# ------------------------------------------------------------------------------------------------
+# A render call of a loop repeats with the same tensors (the optimiser changes their values in place): everything the host
+# derives from them -- which grids convert, where every buffer lies, the parameter pointer tables -- is built once into an
+# enslam_step_plan and found again by identity; a call then allocates three blobs and makes ONE library call per direction
+# (0.2 ms of Python per direction before).  Taken for plain calls only: sampled rays with gt_depth, whole 16-sample tiles, no
+# hipGraph capture of this library in progress (its persistent gradients are _RenderFn's), no VoxelMajorGrid, no given sample
+# distances, no per-kernel profiling.  ENSLAM_STEP_PLANS=0 switches it off (same numbers either way).
+STEP_PLANS = os.environ.get('ENSLAM_STEP_PLANS', '1') == '1'
+_N_PARAMS = 23
+
+
+class _PlanEntry:
+    __slots__ = ('plan', 'layout', 'tensors', 'ptrs', 'rgrad', 'kinds', 'modes', 'dims', 'par_grad', 'need_rays', 'like', 'keep',
+                 'n_in', 'flag_spec', 'ntiles')
+
+
+plan_stats = {'built': 0, 'hits': 0, 'declined': 0}      # (diagnostic counters; tests read them)
+_plan_entries = {}              # (stage, N, n_lin, n_surf, lindisp, loss key, work list, t_lin ptr, t_surf ptr, bound key) -> [entries]
+
+
+def _plan_build(rplan, N, rays_o, rays_d, grids, params_flat, loss_key):
+    lib = L.lib()
+    e = _PlanEntry()
+    P, kinds = L.StepPlan(), rplan.kinds
+    nk = len(kinds)
+    P.stage, P.n_rays, P.n_lin, P.n_surf, P.lindisp = L.STAGE[rplan.stage], N, rplan.n_lin, rplan.n_surf, rplan.lindisp
+    P.need_rays = int(rays_o.requires_grad or rays_d.requires_grad)
+    P.use_work_list = int(rplan.state.use_work_list)
+    P.loss_kind, P.use_color, P.w_color = loss_key
+    e.modes, e.dims, e.par_grad, like = {}, {}, {}, []
+    po = 0
+    off = 0
+    for i, k in enumerate(kinds):
+        g = grids[i]
+        _check_grid(g)
+        nat = is_native_grid(g)
+        e.modes[k] = (2 if nat else 3) if g.requires_grad else 1
+        e.dims[k] = tuple(int(x) for x in g.shape[2:])
+        P.grid_mode[k] = e.modes[k]
+        P.grid_D[k], P.grid_H[k], P.grid_W[k] = e.dims[k]
+        ps = params_flat[po:po + _N_PARAMS]
+        po += _N_PARAMS
+        _check_params(k, ps)
+        P.params[k] = _fill_params_struct(k, ps)
+        e.par_grad[k] = any(p.requires_grad for p in ps)
+        P.par_grad[k] = int(e.par_grad[k])
+        if e.par_grad[k]:
+            for j, t in enumerate(ps):
+                P.pgrad_off[k][j] = off
+                off += t.numel()
+            like += list(ps)
+    P.pgrad_floats = off
+    P.act_light = int(not any(e.par_grad.values()))
+    P.bound, P.coarse_bound = rplan.bound6, rplan.coarse_bound6
+    P.t_lin, P.t_surf = _ptr(rplan.t_lin), _ptr(rplan.t_surf)
+    Lay = L.StepLayout()
+    rc = lib.enslam_plan_layout(ctypes.byref(P), ctypes.byref(Lay))
+    if rc != 0:
+        return None
+    n_act = _lib_size('enslam_activation_floats', P.stage, N, Lay.n_samples, P.act_light)
+    if not (0 < n_act * 4 <= ACT_WORKSPACE_LIMIT_BYTES) or max(d[0] * d[1] * d[2] for d in e.dims.values()) >= (1 << 29):
+        return None
+    e.plan, e.layout, e.kinds, e.like, e.need_rays = P, Lay, kinds, like, bool(P.need_rays)
+    # (grids by weak reference: a cached plan must not keep a replaced 45 MB map alive; the decoders' parameters are small)
+    e.tensors = [weakref.ref(g) for g in grids] + list(params_flat)
+    e.ptrs = [t.data_ptr() for t in params_flat] + [rplan.t_lin.data_ptr(), rplan.t_surf.data_ptr() if rplan.t_surf is not None else 0]
+    e.rgrad = [t.requires_grad for t in [rays_o, rays_d] + list(grids) + list(params_flat)]
+    e.keep = (rplan.t_lin, rplan.t_surf)
+    e.n_in = 4 + nk + len(params_flat)
+    e.ntiles = N * (Lay.n_samples // 16)
+    return e
+
+
+def _plan_lookup(rplan, N, rays_o, rays_d, grids, params_flat, loss_key):
+    tl, ts = rplan.t_lin, rplan.t_surf
+    key = (rplan.stage, N, rplan.n_lin, rplan.n_surf, rplan.lindisp, loss_key, rplan.state.use_work_list, id(rplan.state),
+           tuple(rplan.bound6), tuple(rplan.coarse_bound6))
+    lst = _plan_entries.get(key)
+    tensors = [rays_o, rays_d] + list(grids) + list(params_flat)
+    nk = len(grids)
+    if lst is not None:
+        for e in lst:
+            t0 = e.tensors
+            # rays may be new tensors every step (only their gradient flag matters); grids and parameters are found by identity
+            if len(t0) + 2 == len(tensors) and all(r() is g for r, g in zip(t0[:nk], grids)) and \
+                    all(a is b for a, b in zip(t0[nk:], params_flat)) and \
+                    e.rgrad == [t.requires_grad for t in tensors] and \
+                    e.ptrs == [t.data_ptr() for t in params_flat] + [tl.data_ptr(), ts.data_ptr() if ts is not None else 0] and \
+                    all(tuple(g.shape[2:]) == e.dims[k] and ((e.modes[k] == 3) != is_native_grid(g) or e.modes[k] == 1)
+                        for g, k in zip(grids, rplan.kinds)):
+                plan_stats['hits'] += 1
+                return e
+    e = _plan_build(rplan, N, rays_o, rays_d, grids, params_flat, loss_key)
+    if e is None:
+        plan_stats['declined'] += 1
+        return None
+    plan_stats['built'] += 1
+    if len(_plan_entries) > 64:
+        _plan_entries.clear()
+    _plan_entries.setdefault(key, []).insert(0, e)
+    del _plan_entries[key][4:]
+    return e
+
+
+def _blob_view(blob, off, nbytes, dtype):
+    return blob[off:off + nbytes].view(dtype)
+
+
+class _PlanFn(torch.autograd.Function):
+    """_RenderFn for calls served by a step plan: inputs (entry, rplan, rays_o, rays_d, gt_depth, gt_color | None, *grids, *params)."""
+
+    @staticmethod
+    def forward(ctx, e, rplan, rays_o, rays_d, gt_depth, gt_color, *tensors):
+        lib = L.lib()
+        ctx.set_materialize_grads(False)
+        P, Lay = e.plan, e.layout
+        nk = len(e.kinds)
+        dev = rays_o.device
+        ro, rd = _f32c(rays_o), _f32c(rays_d)
+        gd = _f32c(gt_depth).reshape(-1)
+        gc = gt_color                               # (already detached contiguous float32 [N,3] or None: Renderer)
+        u8 = torch.uint8
+        scratch = torch.empty(Lay.scratch_bytes, dtype=u8, device=dev)
+        gradb = torch.empty(Lay.grad_bytes, dtype=u8, device=dev)
+        outb = torch.empty(Lay.out_bytes, dtype=u8, device=dev)
+        gv = (ctypes.c_void_p * 4)()
+        hold = []
+        static = [(i, k) for i, k in enumerate(e.kinds) if e.modes[k] == 1 and not is_native_grid(tensors[i])]
+        if static:
+            for (i, k), vm in zip(static, _grid_cache.get_many([tensors[i] for i, _ in static])):
+                gv[k] = vm.data_ptr()
+                hold.append(vm)
+        for i, k in enumerate(e.kinds):
+            if gv[k]:
+                continue
+            g = tensors[i].detach()
+            if e.modes[k] == 3 and not g.is_contiguous():
+                g = g.contiguous()
+            gv[k] = g.data_ptr()
+            hold.append(g)
+        st = _stream()
+        L.check(lib.enslam_plan_forward(ctypes.byref(P), ctypes.byref(Lay), scratch.data_ptr(), gradb.data_ptr(), outb.data_ptr(),
+                                        _ptr(ro), _ptr(rd), _ptr(gd), _ptr(gc), _ptr(rplan.depth_max), gv, st), "enslam_plan_forward")
+        N = P.n_rays
+        depth = _blob_view(outb, Lay.o_depth, 8 * N, torch.float64)
+        var = _blob_view(outb, Lay.o_var, 8 * N, torch.float64)
+        rgb = _blob_view(outb, Lay.o_rgb, 12 * N, torch.float32).view(N, 3)
+        state = rplan.state
+        _latest_state[0] = state
+        state.flags = {}
+        for i, k in enumerate(e.kinds):
+            if e.modes[k] >= 2:
+                state.flags[id(tensors[i])] = scratch[Lay.s_flags[k]:Lay.s_flags[k] + (e.dims[k][0] * e.dims[k][1] * e.dims[k][2] + 63) // 64]
+        state.work = (_blob_view(gradb, Lay.g_counter, 4, torch.int32), e.ntiles) if P.use_work_list else (None, 0)
+        ctx.e, ctx.rplan = e, rplan
+        ctx.keep = (ro, rd, gd, gc, scratch, gradb, outb, gv, hold)
+        ctx.calls = 0
+        if P.loss_kind == 1:
+            loss = _blob_view(outb, Lay.o_loss, 8, torch.float64)
+            ctx.mark_non_differentiable(depth, var, rgb)
+            return loss[0], depth, var, rgb
+        return depth, var, rgb
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        lib = L.lib()
+        e = ctx.e
+        P, Lay = e.plan, e.layout
+        ro, rd, gd, gc, scratch, gradb, outb, gv, hold = ctx.keep
+        N, dev = P.n_rays, ro.device
+        n_in = e.n_in + 2
+        if P.loss_kind == 1:
+            g_loss, g_depth, g_var, g_rgb = gouts[0], None, None, None
+        else:
+            g_loss = None
+            g_depth, g_var, g_rgb = gouts
+
+        def prep(g, dtype, shape):
+            if g is None:
+                return None
+            g = g.detach()
+            if g.dtype is not dtype:
+                g = g.to(dtype)
+            if tuple(g.shape) != shape:
+                g = g.expand(shape)
+            return g if g.is_contiguous() else g.contiguous()
+
+        gD, gV, gC = prep(g_depth, torch.float64, (N,)), prep(g_var, torch.float64, (N,)), prep(g_rgb, torch.float32, (N, 3))
+        gL = prep(g_loss, torch.float64, (1,))
+        if gD is None and gV is None and gC is None and gL is None:
+            return (None,) * n_in
+        st = _stream()
+        if ctx.calls > 0:
+            # a repeated backward of this call (retain_graph): the first one's gradient blob backs tensors it returned -- this
+            # one adds into a fresh, cleared blob (the work list of a fused-loss forward keeps its counter) and cleared
+            # channel-major accumulators
+            old = gradb
+            gradb = torch.zeros(Lay.grad_bytes, dtype=torch.uint8, device=dev)
+            if P.loss_kind == 1 and P.use_work_list:
+                gradb[Lay.g_counter:Lay.g_counter + 4].copy_(old[Lay.g_counter:Lay.g_counter + 4])
+            m3 = [k for k in e.kinds if e.modes[k] == 3]
+            if m3:
+                n = len(m3)
+                dsts, vs, nd = (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)(), (ctypes.c_void_p * n)()
+                for j, k in enumerate(m3):
+                    dsts[j] = scratch.data_ptr() + Lay.s_gacc[k]
+                    vs[j] = e.dims[k][0] * e.dims[k][1] * e.dims[k][2]
+                    nd[j] = scratch.data_ptr() + Lay.s_flags[k]
+                L.check(lib.enslam_zero_blocks(n, dsts, vs, nd, None, 0, st), "enslam_zero_blocks")
+        ctx.calls += 1
+        L.check(lib.enslam_plan_backward(ctypes.byref(P), ctypes.byref(Lay), scratch.data_ptr(), gradb.data_ptr(), outb.data_ptr(),
+                                         _ptr(ro), _ptr(rd), _ptr(gd), _ptr(gc), gv, _ptr(gD), _ptr(gV), _ptr(gC), _ptr(gL), st),
+                "enslam_plan_backward")
+        needs = ctx.needs_input_grad
+        out = [None, None, None, None, None, None]      # (entry, rplan, rays_o, rays_d, gt_depth, gt_color)
+        if e.need_rays:
+            if needs[2]:
+                out[2] = _blob_view(gradb, Lay.g_ro, 12 * N, torch.float32).view(N, 3)
+            if needs[3]:
+                out[3] = _blob_view(gradb, Lay.g_rd, 12 * N, torch.float32).view(N, 3)
+        for k in e.kinds:
+            D, H, W = e.dims[k]
+            V = D * H * W
+            if e.modes[k] == 2:
+                out.append(_native_grad_view(_blob_view(gradb, Lay.g_nat[k], 128 * V, torch.float32), e.dims[k]))
+            elif e.modes[k] == 3:
+                out.append(_blob_view(gradb, Lay.g_dense[k], 128 * V, torch.float32).view(1, 32, D, H, W))
+            else:
+                out.append(None)
+        if e.like:
+            views = torch._C._nn.unflatten_dense_tensors(_blob_view(gradb, Lay.g_params, 4 * P.pgrad_floats, torch.float32), e.like)
+            vo = 0
+            for k in e.kinds:
+                if e.par_grad[k]:
+                    out += list(views[vo:vo + _N_PARAMS])
+                    vo += _N_PARAMS
+                else:
+                    out += [None] * _N_PARAMS
+        else:
+            out += [None] * (_N_PARAMS * len(e.kinds))
+        return tuple(out)
+
+
+try:
+    _plan_apply = torch._C._FunctionBase.__dict__['apply'].__get__(None, _PlanFn)
+except Exception:           # pragma: no cover
+    _plan_apply = None
+
+
+def _plan_render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params_flat):
+    """-> outputs of _PlanFn, or None when the call is not one a step plan serves."""
+    if (not STEP_PLANS or _capture['active'] or plan.z_given is not None or t_rand is not None or gt_depth is None or plan.vm
+            or plan.stage == 'coarse' or plan.state.profile or not rays_o.is_cuda or not torch.is_grad_enabled()):
+        return None
+    N = rays_o.shape[0]
+    S = plan.n_lin + plan.n_surf
+    if N <= 0 or S % 16 != 0 or S > 64 or len(params_flat) != _N_PARAMS * len(plan.kinds):
+        return None
+    loss_key, gc = (0, 0, 0.0), None
+    if plan.loss is not None:
+        if len(plan.loss) != 3:
+            return None
+        lgd, gc, lw = plan.loss
+        if lgd.shape[0] != N:
+            return None
+        loss_key = (1, int(gc is not None), float(lw))
+    if not any(t.requires_grad for t in grids) and not any(t.requires_grad for t in params_flat) and \
+            not (rays_o.requires_grad or rays_d.requires_grad):
+        return None                                 # (forward-only calls: nothing to save; _RenderFn's route is as cheap)
+    e = _plan_lookup(plan, N, rays_o, rays_d, grids, params_flat, loss_key)
+    if e is None:
+        return None
+    if _plan_apply is not None and not torch._C._are_functorch_transforms_active():
+        return _plan_apply(e, plan, rays_o, rays_d, gt_depth, gc, *grids, *params_flat)
+    return _PlanFn.apply(e, plan, rays_o, rays_d, gt_depth, gc, *grids, *params_flat)
+
+
 def render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params_flat):
+    out = _plan_render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params_flat)
+    if out is not None:
+        return out
     if _render_apply is not None and not torch._C._are_functorch_transforms_active():
         return _render_apply(plan, rays_o, rays_d, gt_depth, t_rand, *grids, *params_flat)
     return _RenderFn.apply(plan, rays_o, rays_d, gt_depth, t_rand, *grids, *params_flat)

@@ -494,6 +494,64 @@ int enslam_ray_points(int32_t n_rays, int32_t n_samples, const float *rays_o, co
  * p @ B in float32) on n float32 arguments; either output may be NULL. */
 int enslam_fourier_sincos(int64_t n, const float *x, float *sin_out, float *cos_out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Step plans: one differentiable render call (Renderer.render_batch_ray, or render_batch_ray_rgbd_loss, and its backward)
+ * as TWO calls of this library instead of the six to eight entry points above, with every buffer of the call a fixed
+ * offset inside three caller-allocated blobs.  A Python host pays ~200 us per direction for marshalling ~180 pointers,
+ * allocating ~25 tensors and laying out accumulators; with a plan it checks a cache key, allocates three blobs and makes one
+ * call.  Replaces nothing in the reference (host glue); the launches are exactly those of the entry points above.
+ *
+ * enslam_step_plan describes what does not change between the steps of a loop (filled by the host once per combination of
+ * stage / batch size / grid set / gradient pattern); enslam_step_layout is derived from it (enslam_plan_layout).
+ *   grid_mode[k]  0: kind k unused by the stage
+ *                 1: values given voxel-major ([V][32]: a channels_last_3d tensor or a cached copy), no gradient
+ *                 2: values voxel-major, gradient wanted: added into the gradient blob's [V][32] region of kind k (zero-filled
+ *                    by the forward), which the host hands to autograd as a channels_last_3d tensor
+ *                 3: values channel-major ([32][V], the reference's strides), gradient wanted: touched 64-voxel blocks
+ *                    converted per step (scratch blob), gradient transposed back into a dense [32][V] region of the gradient blob
+ *   par_grad[k]   decoder k's parameters get gradients (all or none); they appear in the gradient blob's parameter region at the
+ *                 float offsets pgrad_off[k][..] in the order W0,b0,..,W4,b4,Wc0,bc0,..,Wc4,bc4,Wo,bo,B
+ *   loss_kind     0: outputs depth / var / rgb, backward from their gradients; 1: the mapper's RGB-D loss fused into the
+ *                 compositing launches (enslam_render_loss_fwd), backward from d(total)/d(loss)
+ * Blobs (device memory, 256-byte aligned, sizes from the layout): scratch (lives from forward to backward), grad (lives as long
+ * as any gradient the host made from it), out (depth | var | rgb | loss).  Nothing needs clearing by the caller. */
+typedef struct enslam_step_plan {
+    int32_t stage, n_rays, n_lin, n_surf, lindisp, act_light, need_rays, use_work_list, loss_kind, use_color;
+    float w_color;
+    int32_t grid_mode[4], par_grad[4];
+    int32_t grid_D[4], grid_H[4], grid_W[4];
+    double bound[6], coarse_bound[6];
+    enslam_mlp_params params[4];       /* the callers' parameter tensors (sources of the per-step packing) */
+    int64_t pgrad_off[4][23];          /* float offsets inside the gradient blob's parameter region */
+    int64_t pgrad_floats;              /* size of that region */
+    const float *t_lin;                /* device: [n_lin] */
+    const double *t_surf;              /* device: [n_surf] */
+} enslam_step_plan;
+
+typedef struct enslam_step_layout {    /* byte offsets (-1: absent) and sizes */
+    int64_t scratch_bytes, grad_bytes, out_bytes;
+    int64_t s_zero_bytes;              /* scratch [0, s_zero_bytes) is cleared by the forward: block flags, packed decoders */
+    int64_t s_flags[4], s_packed[4], s_z, s_dmax, s_raw, s_act, s_work, s_draw, s_dgw, s_vm[4], s_gacc[4];
+    int64_t g_flat, g_flat_floats;     /* grad blob: range the forward's prepare roles clear */
+    int64_t g_packed[4], g_ro, g_rd, g_counter, g_nat[4], g_params, g_dense[4];
+    int64_t o_depth, o_var, o_rgb, o_loss;
+    int32_t n_samples, finish_needed, inline_rays, merged;
+} enslam_step_layout;
+
+int64_t enslam_plan_struct_bytes(int32_t which);       /* sizeof(enslam_step_plan) (0) / sizeof(enslam_step_layout) (1): binding self-check */
+int enslam_plan_layout(const enslam_step_plan *plan, enslam_step_layout *layout);
+/* grid_values[k]: the grid's values (voxel-major for modes 1 / 2, channel-major for mode 3).  gt_color: loss_kind 1 with colour term.
+ * depth_max: device float32 [2] {max, max * 1.2f} of the whole batch or NULL (taken over this call's rays). */
+int enslam_plan_forward(const enslam_step_plan *plan, const enslam_step_layout *layout, void *scratch, void *grad, void *out,
+                        const float *rays_o, const float *rays_d, const float *gt_depth, const float *gt_color,
+                        const float *depth_max, const float *const *grid_values, void *stream);
+/* g_depth / g_var (float64 [N]) / g_rgb (float32 [N,3]): gradients of the outputs, any may be NULL (loss_kind 0);
+ * g_loss: device float64 [1] (loss_kind 1). */
+int enslam_plan_backward(const enslam_step_plan *plan, const enslam_step_layout *layout, void *scratch, void *grad, void *out,
+                         const float *rays_o, const float *rays_d, const float *gt_depth, const float *gt_color,
+                         const float *const *grid_values, const double *g_depth, const double *g_var, const float *g_rgb,
+                         const double *g_loss, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

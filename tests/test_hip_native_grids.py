@@ -259,3 +259,69 @@ def test_reference_mapper_formulation_on_native_grids():
         a, b = res['contiguous'][k], res['channels_last_3d'][k]
         assert float((a - grids[k]).abs().max()) > 1e-3                      # (something was optimised)
         assert float((a - b).abs().max()) <= 1e-5 + 2e-4 * 0.01 * 2, k
+
+
+def test_step_plans_serve_the_plain_calls_and_follow_changes(monkeypatch):
+    """functional._PlanFn (one library call per direction from a cached enslam_step_plan) against _RenderFn (ENSLAM_STEP_PLANS=0) on
+    the same call: identical outputs, gradients within float-atomic ordering; the cache follows what a loop changes -- gradient flags
+    of the decoders (a tracker freezes them), a replaced grid tensor, a parameter's storage, the batch size, the layout."""
+    import evennicer_slam_amd as E
+    import evennicer_slam_amd.functional as EF
+    from tests.hip_util import DEV, as_layout, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+
+    def run(cg, n=64, params_grad=True):
+        for p in model.parameters():
+            p.grad = None
+            p.requires_grad_(params_grad)
+        ro, rd = rays['rays_o'][:n].clone().requires_grad_(True), rays['rays_d'][:n].clone().requires_grad_(True)
+        for g in cg.values():
+            g.grad = None
+        d, v, c = renderer.render_batch_ray(cg, model, rd, ro, DEV, 'color', gt_depth=rays['gt_depth'][:n])
+        (d.sum() + 0.3 * c.sum().double() + 0.1 * v.sum()).backward()
+        return ([d.detach(), v.detach(), c.detach()],
+                [ro.grad, rd.grad] + [cg[k].grad for k in KEYS] + [p.grad for p in model.color_decoder.parameters() if p.grad is not None])
+
+    try:
+        for layout in ('contiguous', 'channels_last_3d'):
+            cg = {k: as_layout(v, layout).requires_grad_(True) for k, v in grids.items()}
+            monkeypatch.setattr(EF, 'STEP_PLANS', False)
+            o0, g0 = run(cg)
+            monkeypatch.setattr(EF, 'STEP_PLANS', True)
+            before = dict(EF.plan_stats)
+            o1, g1 = run(cg)
+            assert EF.plan_stats['built'] + EF.plan_stats['hits'] == before['built'] + before['hits'] + 1      # the plan route ran
+            for a, b in zip(o0, o1):
+                assert torch.equal(a, b)
+            assert len(g0) == len(g1) > 20
+            for a, b in zip(g0, g1):
+                assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-30)
+            if layout == 'channels_last_3d':
+                assert all(cg[k].grad.is_contiguous(memory_format=torch.channels_last_3d) for k in KEYS)
+            b0 = EF.plan_stats['built']
+            run(cg)
+            assert EF.plan_stats['built'] == b0                                  # same loop step again: found, not rebuilt
+            o2, g2 = run(cg, params_grad=False)                                  # decoders frozen: another plan (light workspace)
+            assert EF.plan_stats['built'] == b0 + 1 and torch.equal(o2[0], o1[0])
+            assert float((g2[1] - g1[1]).abs().max()) <= 2e-5 * float(g1[1].abs().max())
+            run(cg, n=48)                                                        # another batch size
+            assert EF.plan_stats['built'] == b0 + 2
+            cg2 = dict(cg)
+            cg2['grid_fine'] = (cg['grid_fine'].detach() * 1.5).contiguous(memory_format=torch.channels_last_3d if layout != 'contiguous'
+                                                                          else torch.contiguous_format).requires_grad_(True)
+            o3, g3 = run(cg2)                                                    # a replaced grid tensor
+            assert EF.plan_stats['built'] == b0 + 3 and not torch.equal(o3[0], o1[0])
+            w = model.color_decoder.pts_linears[1].weight
+            with torch.no_grad():
+                w.data = (w.data * 0.5).clone()                                  # same parameter object, new storage
+            o4, g4 = run(cg)
+            assert EF.plan_stats['built'] == b0 + 4 and not torch.equal(o4[2], o1[2])
+            monkeypatch.setattr(EF, 'STEP_PLANS', False)
+            o5, g5 = run(cg)
+            monkeypatch.setattr(EF, 'STEP_PLANS', True)
+            assert torch.equal(o4[0], o5[0]) and torch.equal(o4[2], o5[2])
+            with torch.no_grad():
+                w.data = (w.data * 2.0).clone()
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(True)

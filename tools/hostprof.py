@@ -8,7 +8,8 @@ dev = torch.device('cuda', 0)
 sc = bench.build_scene_cpu('room0', 0)
 rays = bench.make_rays(sc, 1000, 1000)
 model = sc['model'].to(dev); bench.attach_bounds(model, sc['bound'])
-grids = {k: v.to(dev).requires_grad_(True) for k, v in sc['grids'].items()}
+mf = torch.channels_last_3d if os.environ.get('LAYOUT', 'contiguous') == 'channels_last_3d' else torch.contiguous_format
+grids = {k: v.to(dev).contiguous(memory_format=mf).requires_grad_(True) for k, v in sc['grids'].items()}
 ro, rd, gd, gc = [t.to(dev) for t in rays]
 ro.requires_grad_(True); rd.requires_grad_(True)
 renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **bench.CAM))
@@ -28,6 +29,7 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"host-only per step {1e3*(t1-t0)/200:.3f} ms ; with final sync {1e3*(t2-t0)/200:.3f} ms")
 torch.autograd.set_multithreading_enabled(False)      # the engine then calls the Python backward on this thread: cProfile sees it
+if os.environ.get('NO_CPROFILE') == '1': sys.exit(0)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(200): step()
 pr.disable(); torch.cuda.synchronize()
