@@ -325,3 +325,52 @@ def test_step_plans_serve_the_plain_calls_and_follow_changes(monkeypatch):
     finally:
         for p in model.parameters():
             p.requires_grad_(True)
+
+
+@pytest.mark.parametrize("stage", ['middle', 'fine', 'color'])
+@pytest.mark.parametrize("pattern", ['rays', 'grids', 'params', 'grids+params', 'all', 'fused-loss'])
+def test_step_plan_route_equals_the_function_route(monkeypatch, stage, pattern):
+    """every gradient pattern a caller can ask for (pose only: the tracker; grids only: mapper stages with fixed decoders; decoders
+    only; everything), each stage, plain outputs or the fused mapper loss: the step-plan route against _RenderFn"""
+    import evennicer_slam_amd.functional as EF
+    from tests.hip_util import DEV, as_layout, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    want_rays = pattern in ('rays', 'all', 'fused-loss')
+    want_grids = pattern in ('grids', 'grids+params', 'all', 'fused-loss')
+    want_params = pattern in ('params', 'grids+params', 'all', 'fused-loss')
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+            p.requires_grad_(want_params)
+        cg = {k: as_layout(v, 'channels_last_3d' if k != 'grid_color' else 'contiguous').requires_grad_(want_grids) for k, v in grids.items()}
+        ro, rd = rays['rays_o'].clone().requires_grad_(want_rays), rays['rays_d'].clone().requires_grad_(want_rays)
+        if pattern == 'fused-loss':
+            loss, d, v, c = renderer.render_batch_ray_rgbd_loss(cg, model, rd, ro, DEV, stage, rays['gt_depth'], rays['gt_color'], 0.2)
+        else:
+            d, v, c = renderer.render_batch_ray(cg, model, rd, ro, DEV, stage, gt_depth=rays['gt_depth'])
+            loss = d.sum() + 0.1 * v.sum() + (0.3 * c.sum().double() if stage == 'color' else 0.0)
+        loss.backward()
+        gs = [ro.grad, rd.grad] + [cg[k].grad for k in KEYS] + [p.grad for p in model.parameters()]
+        return [d.detach(), v.detach(), c.detach(), loss.detach()], gs
+
+    try:
+        monkeypatch.setattr(EF, 'STEP_PLANS', False)
+        o0, g0 = run()
+        monkeypatch.setattr(EF, 'STEP_PLANS', True)
+        n0 = EF.plan_stats['built'] + EF.plan_stats['hits']
+        o1, g1 = run()
+        assert EF.plan_stats['built'] + EF.plan_stats['hits'] == n0 + 1
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(True)
+    for a, b in zip(o0[:3], o1[:3]):
+        assert torch.equal(a, b)
+    assert abs(float(o0[3]) - float(o1[3])) <= 1e-12 * max(abs(float(o0[3])), 1.0)
+    got = 0
+    for a, b in zip(g0, g1):
+        assert (a is None) == (b is None)
+        if a is not None:
+            got += 1
+            assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-30)
+    assert got > 0
