@@ -838,6 +838,134 @@ def run_tracker_iter(dev, n_rays=200, steps=200):
     return out
 
 
+def run_slam_fps(dev, frames=10):
+    """BASELINE's second metric ("Replica room0 tracking+mapping FPS") on SYNTHETIC data with random-weight networks -- datasets and
+    pretrained weights are not in the image, so this times the schedule's compute, not accuracy: room0 grids, Replica camera, the
+    shipped schedule (configs/Replica/replica.yaml + configs/nice_slam.yaml): per frame 10 camera iterations (event term every frame,
+    the RGB-D term on every 5th), every 5th frame 60 mapper iterations of 1000 rays (colour stage, frustum-masked grids + colour
+    decoder).  One process, one GPU: the reference's tracker and mapper processes alternate here.  Tracker:
+    tracker.GraphedCameraIteration; mapper: MaskedGridOptimizer + FusedAdam, one hipGraph per iteration."""
+    import copy
+    import evennicer_slam_amd as E
+    import evennicer_slam_amd.functional as EF
+    from evennicer_slam_amd.graph import GraphedStep
+    from evennicer_slam_amd.mapper import FusedAdam, MaskedGridOptimizer
+    KEYS = ('grid_middle', 'grid_fine', 'grid_color')
+    sc = build_scene_cpu('room0', 0)
+    H, W = CAM['H'], CAM['W']
+    g = torch.Generator().manual_seed(1)
+    fr = []
+    for _ in range(4):
+        ev = torch.randint(0, 4, (H, W, 2), generator=g).float()
+        fr.append(dict(depth=(torch.rand(H, W, generator=g) * 3.0 + 0.5).to(dev), color=torch.rand(H, W, 3, generator=g).to(dev),
+                       event=ev.to(dev), mask=(ev.sum(-1) > 2).long().to(dev)))
+    model = copy.deepcopy(sc['model']).to(dev)
+    attach_bounds(model, sc['bound'])
+    for name in ('coarse_decoder', 'middle_decoder', 'fine_decoder'):
+        for q in getattr(model, name).parameters():
+            q.requires_grad_(False)
+    grids = {k: v.to(dev).contiguous(memory_format=torch.channels_last_3d) for k, v in sc['grids'].items()}
+    masks = {}
+    for k in KEYS:
+        D, Hh, Ww = grids[k].shape[2:]
+        m = torch.zeros(D, Hh, Ww, dtype=torch.bool)
+        m[:, :, Ww // 4: 3 * Ww // 4] = True
+        masks[k] = m.to(dev)
+    renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **CAM))
+    opt = MaskedGridOptimizer(grids, masks, keys=KEYS)
+    dec_opt = FusedAdam(list(model.color_decoder.parameters()), lr=0.005)
+    opt.set_lr({k: 0.005 for k in KEYS})
+    c_map = opt.render_grids()
+    m_ro, m_rd, m_gd, m_gc = [t.to(dev) for t in make_rays(sc, 1000, 1000)]
+    one = {}
+
+    def map_it():
+        dec_opt.zero_grad()
+        loss, _d, _v, _c = renderer.render_batch_ray_rgbd_loss(c_map, model, m_rd, m_ro, dev, 'color', m_gd, m_gc, 0.2)
+        if 'one' not in one:
+            one['one'] = torch.ones_like(loss)
+        loss.backward(gradient=one['one'])
+        dec_opt.step()
+        opt.step()
+        return loss
+
+    for _ in range(3):
+        map_it()
+    dec_opt.zero_grad()
+    _gcmod.collect()
+    g_map = GraphedStep(map_it)
+    t_model = copy.deepcopy(model)
+    for q in t_model.parameters():
+        q.requires_grad_(False)
+    attach_bounds(t_model, sc['bound'])
+    t_grids = {k: v.detach().clone() for k, v in grids.items()}
+    cfg = dict(sc['cfg'])
+    cfg['tracking'] = {'device': dev, 'w_color_loss': 0.5, 'ignore_edge_W': 100, 'ignore_edge_H': 100, 'handle_dynamic': True,
+                       'use_color_in_tracking': True, 'iters': 10}
+    cfg['event'] = {'activate_events': True, 'blur': True, 'kernel_sizes': [9], 'kernel_weights': [1], 'unblurred_weight': 0,
+                    'balancer': 0.025}
+    torch.manual_seed(0)
+    net = E.event.UNet_2heads(6, 2, 2)
+    for q in net.parameters():
+        q.requires_grad_(False)
+    net = net.to(dev).eval()
+    slam = types.SimpleNamespace(nice=True, bound=sc['bound'], event_net=net, low_gpu_mem=False, **CAM)
+    slam.renderer = E.Renderer(sc['cfg'], None, slam)
+    trk = E.tracker.TrackerIteration(cfg, None, slam)
+    trk.c, trk.decoders = t_grids, t_model
+    ct = torch.tensor([1.0, 0.0, 0.0, 0.0, 3.0, 1.0, 0.0], device=dev, requires_grad=True)
+    cam_opt = FusedAdam([ct], lr=1e-3)
+    f0 = fr[0]
+    kw = dict(batch_size=200, scale_factor=0.15)
+    git_full = E.tracker.GraphedCameraIteration(trk, ct, cam_opt, f0['color'], f0['depth'], f0['event'], f0['mask'], f0['color'], rgbd=True,
+                                                event=True, **kw)
+    git_ev = E.tracker.GraphedCameraIteration(trk, ct, cam_opt, f0['color'], f0['depth'], f0['event'], f0['mask'], f0['color'], rgbd=False,
+                                              event=True, **kw)
+
+    def update_para_from_mapping():                     # Tracker.py:247-260, in place
+        opt.write_back()
+        with torch.no_grad():
+            for k in KEYS:
+                t_grids[k].copy_(grids[k])
+            for pt, pm in zip(t_model.parameters(), model.parameters()):
+                pt.copy_(pm)
+        git_full.refresh_map()
+
+    for _ in range(60):                                 # (a first mapping round outside the timed frames)
+        g_map.replay()
+    update_para_from_mapping()
+    torch.cuda.synchronize()
+    t_track = t_map = 0.0
+    t_all = time.perf_counter()
+    for i in range(1, frames + 1):
+        f, prev = fr[i % 4], fr[(i - 1) % 4]
+        a = time.perf_counter()
+        git = git_full if i % 5 == 0 else git_ev
+        git.set_frame(f['color'], f['depth'], f['event'], f['mask'], prev['color'])
+        for _ in range(10):
+            git.step()
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        t_track += b - a
+        if i % 5 == 0:                                  # mapping.every_frame 5
+            for _ in range(60):
+                g_map.replay()
+            update_para_from_mapping()
+            torch.cuda.synchronize()
+            t_map += time.perf_counter() - b
+    t_all = time.perf_counter() - t_all
+    out = {"workload": "synthetic Replica-schedule run, room0, 1 GPU, one process: per frame 10 camera iterations (event term: 18360-ray "
+                       "render + UNet_2heads with random weights + blurred-L2; RGB-D term every 5th frame), every 5th frame 60 mapper "
+                       "iterations of 1000 rays (colour stage) + the tracker's map update; synthetic images, no dataset",
+           "frames": frames, "frames_per_s": frames / t_all, "tracking_ms_per_frame": t_track / frames * 1e3,
+           "mapping_ms_per_round": t_map / max(frames // 5, 1) * 1e3}
+    del g_map, git_full, git_ev, trk, opt, dec_opt, grids, t_grids, model, t_model, net
+    EF.clear_caches()
+    _gcmod.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -912,6 +1040,7 @@ def main():
             guarded("config2_surfaces", surfaces)
             guarded("config3", lambda: run_config3(env.dev, steps=max(10, min(30, args.steps // 10))))
             guarded("tracker_iter_200", lambda: run_tracker_iter(env.dev, 200, steps=max(50, args.steps)))
+            guarded("slam_fps_synthetic", lambda: run_slam_fps(env.dev, frames=10))
     if env.rank == 0:
         print(json.dumps(primary), flush=True)
     env.close()
