@@ -81,3 +81,54 @@ def test_binding_raises_enslam_error_with_the_entry_name():
     assert E._lib.check(0, "ok") is None
     with pytest.raises(E.EnslamError):                         # CPU tensors never reach the kernels
         E.functional._require_hip(torch.zeros(3), "x")
+
+
+def test_step_plan_entries_refuse_inconsistent_plans():
+    """enslam_plan_layout / _forward / _backward: malformed plans and missing blobs return ENSLAM_EINVAL (nothing is launched)"""
+    import evennicer_slam_amd as E
+    L = E._lib
+    lib = L.lib()
+    dev = torch.device('cuda', 0)
+    t_lin = torch.linspace(0, 1, 32, device=dev)
+    t_surf = torch.linspace(0, 1, 16, dtype=torch.float64, device=dev)
+
+    def plan(**kw):
+        P = L.StepPlan()
+        P.stage, P.n_rays, P.n_lin, P.n_surf = 3, 64, 32, 16
+        P.act_light = 1
+        for k in (1, 2, 3):
+            P.grid_mode[k] = 1
+            P.grid_D[k], P.grid_H[k], P.grid_W[k] = 4, 5, 6
+        P.t_lin, P.t_surf = t_lin.data_ptr(), t_surf.data_ptr()
+        for name, v in kw.items():
+            if isinstance(v, dict):
+                for i, x in v.items():
+                    getattr(P, name)[i] = x
+            else:
+                setattr(P, name, v)
+        return P
+
+    Lay = L.StepLayout()
+    assert lib.enslam_plan_layout(ctypes.byref(plan()), ctypes.byref(Lay)) == 0
+    assert Lay.n_samples == 48 and Lay.inline_rays == 1 and Lay.merged == 1 and Lay.scratch_bytes > 0 and Lay.out_bytes > 0
+    assert lib.enslam_plan_layout(ctypes.byref(plan(grid_mode={2: 3}, need_rays=1)), ctypes.byref(Lay)) == 0
+    assert Lay.merged == 0 and Lay.finish_needed == 1 and Lay.s_vm[2] >= 0 and Lay.g_dense[2] >= 0 and Lay.s_dgw >= 0
+    for bad in (plan(stage=0), plan(n_rays=0), plan(n_surf=8), plan(grid_mode={3: 0}), plan(grid_mode={0: 1}), plan(par_grad={2: 1}),
+                plan(act_light=0), plan(loss_kind=2), plan(grid_D={1: 0}), plan(t_lin=None), plan(stage=2)):
+        assert lib.enslam_plan_layout(ctypes.byref(bad), ctypes.byref(Lay)) == EINVAL
+    assert lib.enslam_plan_layout(ctypes.byref(plan(stage=2, grid_mode={3: 0})), ctypes.byref(Lay)) == 0        # fine stage: two grids
+    P = plan()
+    assert lib.enslam_plan_layout(ctypes.byref(P), ctypes.byref(Lay)) == 0
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gv = (ctypes.c_void_p * 4)()
+    ro = torch.zeros(64, 3, device=dev)
+    gd = torch.ones(64, device=dev)
+    blob = torch.zeros(max(Lay.scratch_bytes, Lay.grad_bytes, Lay.out_bytes), dtype=torch.uint8, device=dev)
+    b = blob.data_ptr()
+    # a used grid without values; missing blobs; missing rays
+    assert lib.enslam_plan_forward(ctypes.byref(P), ctypes.byref(Lay), b, b, b, ro.data_ptr(), ro.data_ptr(), gd.data_ptr(), None, None, gv, st) == EINVAL
+    assert lib.enslam_plan_forward(ctypes.byref(P), ctypes.byref(Lay), None, b, b, ro.data_ptr(), ro.data_ptr(), gd.data_ptr(), None, None, gv, st) == EINVAL
+    assert lib.enslam_plan_forward(ctypes.byref(P), ctypes.byref(Lay), b, b, b, None, ro.data_ptr(), gd.data_ptr(), None, None, gv, st) == EINVAL
+    assert lib.enslam_plan_backward(ctypes.byref(P), ctypes.byref(Lay), b, None, b, ro.data_ptr(), ro.data_ptr(), gd.data_ptr(), None, gv, None,
+                                    None, None, None, st) == EINVAL
+    torch.cuda.synchronize()
