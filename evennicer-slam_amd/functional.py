@@ -448,7 +448,8 @@ def is_native_grid(g):
     channels_last_3d memory format (`grid.contiguous(memory_format=torch.channels_last_3d)` -- same shape, same values, same
     indexing as the reference's grids; only the strides differ).  Such a grid is gathered from where it lies, nothing is
     converted per step, and its gradient comes back in the same memory format without a transposed copy."""
-    return g.dim() == 5 and g.shape[1] == 32 and g.is_contiguous(memory_format=_CL3D) and not g.is_contiguous()
+    return (g.dim() == 5 and g.shape[1] == 32 and g.is_contiguous(memory_format=_CL3D) and not g.is_contiguous()
+            and g.data_ptr() % 16 == 0)           # (the gathers load 16 bytes at a time: an odd view offset takes the copying route)
 
 
 def _native_vm(g):
