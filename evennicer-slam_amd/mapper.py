@@ -184,6 +184,14 @@ class FusedAdam:
         for p in self.params:
             p.grad = None
 
+    def reset(self):
+        """Back to the state of a freshly constructed optimiser (moments and step count zero; the learning rate stays): what
+        the reference gets by building a new torch.optim.Adam per frame (Tracker.py:303-306) -- without new device buffers, so a
+        captured iteration that reads them keeps working."""
+        self._m.zero_()
+        self._v.zero_()
+        self.step_t.zero_()
+
     def step(self, lr=None):
         if lr is not None:
             self.set_lr(lr)

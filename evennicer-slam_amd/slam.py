@@ -126,9 +126,11 @@ class SLAM:
             est = delta @ pre
         else:
             est = pre
+        use_event = self.event_net is not None and self.cfg['event'].get('activate_events', False)
+        if t.get('graphed', False) and int(t['iters']) > 0:
+            return self._track_graphed(idx, est, gt_color, gt_depth, gt_event, gt_mask, pre_gt_color, t, use_event)
         camera_tensor = get_tensor_from_camera(est.detach()).to(self.device).requires_grad_(True)
         opt = FusedAdam([camera_tensor], lr=t['lr'])
-        use_event = self.event_net is not None and self.cfg['event'].get('activate_events', False)
         best, best_loss, first_loss = camera_tensor.detach().clone(), None, None
         for it in range(t['iters']):
             out = self.tracker.optimize_cam_in_batch(camera_tensor, est, gt_color, gt_depth, gt_event, gt_mask, t['pixels'], opt,
@@ -144,6 +146,48 @@ class SLAM:
         if self.verbose:
             gt = self.gt_c2w_list[idx][:3, 3].to(self.device)
             print(f'frame {idx}: tracking loss {first_loss} -> {best_loss}; translation error init '
+                  f'{float((est[:3, 3] - gt).norm()):.4f} -> {float((c2w[:3, 3] - gt).norm()):.4f} m', flush=True)
+        return c2w
+
+    def _track_graphed(self, idx, est, gt_color, gt_depth, gt_event, gt_mask, pre_gt_color, t, use_event):
+        """`track` with the camera iterations as replays of ONE hipGraph (tracker.GraphedCameraIteration, captured at the first tracked
+        frame and kept): per frame the initial pose goes into the captured camera tensor, the optimiser is reset, the images are
+        copied in (set_frame draws the frame's pixels ahead) and the map the mapper has just published is copied into the captured
+        tensors (refresh_map); the losses stay on the device and the least-loss candidate (Tracker.py:321-330) is picked by one
+        argmin behind the last iteration -- no host round trip per iteration."""
+        from .tracker import GraphedCameraIteration
+        iters, n = int(t['iters']), int(t['pixels'])
+        sf = self.cfg['event'].get('scale_factor', 0.1)
+        g = getattr(self, '_gtrack', None)
+        init = get_tensor_from_camera(est.detach()).to(self.device).float()
+        if g is None or g['key'] != (iters, n, use_event):
+            ct = init.clone().requires_grad_(True)
+            opt = FusedAdam([ct], lr=t['lr'])
+            git = GraphedCameraIteration(self.tracker, ct, opt, gt_color, gt_depth, gt_event if use_event else None,
+                                         gt_mask if use_event else None, pre_gt_color if use_event else None, batch_size=n, rgbd=True,
+                                         event=use_event, scale_factor=sf, n_draws=iters)
+            g = self._gtrack = dict(key=(iters, n, use_event), ct=ct, opt=opt, git=git,
+                                    cams=torch.empty((iters, 7), dtype=torch.float32, device=self.device),
+                                    losses=torch.empty(iters, dtype=torch.float64, device=self.device))
+        ct, opt, git = g['ct'], g['opt'], g['git']
+        with torch.no_grad():
+            ct.copy_(init.reshape(ct.shape))
+        opt.reset()
+        opt.set_lr(t['lr'])
+        git.refresh_map()                                   # (update_para_from_mapping replaced the tracker's map objects)
+        git.set_frame(gt_color, gt_depth, gt_event if use_event else None, gt_mask if use_event else None,
+                      pre_gt_color if use_event else None)
+        for it in range(iters):
+            l_rgbd, l_event, _l_mask = git.step()
+            g['losses'][it].copy_(l_rgbd + l_event if use_event else l_rgbd)
+            g['cams'][it].copy_(ct.detach().reshape(-1))         # the candidate of this loss: the pose AFTER the step (Tracker.py:321-330)
+        k = torch.argmin(g['losses'])
+        best = g['cams'][k]
+        c2w = torch.eye(4, device=self.device)
+        c2w[:3] = get_camera_from_tensor(best)
+        if self.verbose:
+            gt = self.gt_c2w_list[idx][:3, 3].to(self.device)
+            print(f'frame {idx}: tracking loss {float(g["losses"][0])} -> {float(g["losses"][k])} (graphed); translation error init '
                   f'{float((est[:3, 3] - gt).norm()):.4f} -> {float((c2w[:3, 3] - gt).norm()):.4f} m', flush=True)
         return c2w
 

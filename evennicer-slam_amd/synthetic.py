@@ -124,7 +124,8 @@ def demo_config(inp, evf, cam, device='cuda:0', env=None):
                     'mapping_window_size': 5, 'frustum_feature_selection': True, 'stage': stage},
         'tracking': {'device': device, 'w_color_loss': 0.5, 'ignore_edge_W': 4, 'ignore_edge_H': 4, 'handle_dynamic': True,
                      'use_color_in_tracking': True, 'lr': float(env.get('TRACK_LR', 0.002)), 'pixels': int(env.get('TRACK_PIXELS', 1000)),
-                     'iters': int(env.get('TRACK_ITERS', 40)), 'const_speed_assumption': True, 'gt_camera': False},
+                     'iters': int(env.get('TRACK_ITERS', 40)), 'const_speed_assumption': True, 'gt_camera': False,
+                     'graphed': bool(int(env.get('TRACK_GRAPHED', 0)))},
         'event': {'activate_events': False, 'blur': True, 'kernel_sizes': [9], 'kernel_weights': [1], 'unblurred_weight': 0,
                   'balancer': 0.025, 'scale_factor': 0.5},
     }

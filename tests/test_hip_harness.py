@@ -94,7 +94,8 @@ def test_run_harness_on_a_synthetic_sequence(tmp_path):
     assert slam2.evaluate(res2['ckpt'])['absolute_translational_error.rmse'] < 1e-6
 
 
-def test_tracking_converges_on_a_view_consistent_sequence(tmp_path):
+@pytest.mark.parametrize("graphed", [False, True])
+def test_tracking_converges_on_a_view_consistent_sequence(tmp_path, graphed):
     """SURVEY f3 / VERDICT r2 item 5: a sequence on which tracking MUST converge.  30 frames of an analytic room
     (synthetic.BoxRoom: every frame is a rendering of the same geometry and colours) along a known trajectory, read back
     through the Replica_event reader; decoders pre-fitted on five ground-truth-posed frames in place of the pretrained
@@ -110,7 +111,9 @@ def test_tracking_converges_on_a_view_consistent_sequence(tmp_path):
     n = 30
     cam = dict(H=60, W=80, fx=70.0, fy=70.0, cx=39.5, cy=29.5)
     (inp, evf), poses = write_demo_sequence(str(tmp_path / 'data'), n, cam)
-    cfg = demo_config(inp, evf, cam, device=DEV)
+    # graphed: the camera iterations of every frame as replays of one hipGraph (SLAM._track_graphed: GraphedCameraIteration with
+    # refresh_map / set_frame per frame, least-loss candidate by one argmin on the device) instead of Python-driven iterations
+    cfg = demo_config(inp, evf, cam, device=DEV, env={'TRACK_GRAPHED': int(graphed)})
     ds = D.get_dataset(cfg, types.SimpleNamespace(input_folder=None, event_folder=None), 1, device=DEV)
     assert len(ds) == n
     ate = {}
