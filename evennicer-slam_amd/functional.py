@@ -1300,6 +1300,9 @@ class _PlanEntry:
 
 
 plan_stats = {'built': 0, 'hits': 0, 'declined': 0}      # (diagnostic counters; tests read them)
+# > 0 while graph.GraphedStep runs the eager warm-up iterations of a step it is about to capture: those must leave the caches the
+# capture will read (packed decoders of fixed decoders, converted grids) warm, which only _RenderFn's route fills
+plans_suspended = [0]
 _plan_entries = {}              # (stage, N, n_lin, n_surf, lindisp, loss key, work list, t_lin ptr, t_surf ptr, bound key) -> [entries]
 
 
@@ -1534,7 +1537,7 @@ except Exception:           # pragma: no cover
 
 def _plan_render(plan, rays_o, rays_d, gt_depth, t_rand, grids, params_flat):
     """-> outputs of _PlanFn, or None when the call is not one a step plan serves."""
-    if (not STEP_PLANS or _capture['active'] or plan.z_given is not None or t_rand is not None or gt_depth is None or plan.vm
+    if (not STEP_PLANS or _capture['active'] or plans_suspended[0] or plan.z_given is not None or t_rand is not None or gt_depth is None or plan.vm
             or plan.stage == 'coarse' or plan.state.profile or not rays_o.is_cuda or not torch.is_grad_enabled()):
         return None
     N = rays_o.shape[0]

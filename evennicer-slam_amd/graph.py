@@ -18,16 +18,20 @@ import torch
 class GraphedStep:
     def __init__(self, step_fn, warmup=3):
         self.step_fn = step_fn
+        from . import functional as EF
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):             # first-use work (module loading, attribute calls) stays outside
-                out = step_fn()
-                del out
+        EF.plans_suspended[0] += 1              # the warm-up goes the route the capture will go: its caches are the ones the graph reads
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(warmup):         # first-use work (module loading, attribute calls) stays outside
+                    out = step_fn()
+                    del out
+        finally:
+            EF.plans_suspended[0] -= 1
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         gc.collect()                            # reference cycles holding tensors of the warm-up steps (see below)
-        from . import functional as EF
         self.graph = torch.cuda.CUDAGraph()
         EF.begin_capture()
         ok = False
