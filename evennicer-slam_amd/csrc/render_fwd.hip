@@ -366,7 +366,9 @@ constexpr int fwd_ring_lds_bytes(int stage) { return (2 * fwd_ring_floats(stage)
 
 // decoder `kind` through the ring; its layer i is global chunk C0+i (buffer (C0+i)&1).  pk_next: packed decoder whose
 // layer 0 follows in the ring (nullptr: none).  NEXT_CD: its fc_c width.
-template <int CT, int C0, int RB, int NEXT_CD>
+// RES >= 0: the decoder's whole forward section ([B^T | chunk 0 .. chunk 4 | Wo | bo], the packed layout verbatim) is RESIDENT in
+// LDS at byte offset RES -- no ring traffic and no barrier anywhere in the call (render_fwd_res_kernel: waves run independently).
+template <int CT, int C0, int RB, int NEXT_CD, int RES = -1>
 ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict__ pk_next, float* ring, float pc,
                           const f32x4 (&c)[CT], f32x4& o, float* ws, bool wl, float* stage, unsigned wt, unsigned wq, int wave, int lane, int p, int q,
                           StampCtx& sx) {
@@ -375,7 +377,7 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
     f32x4 emb[6];
     // B^T [96][4] sits right in front of layer 0's chunk in the packed decoder and rides in with it (ring slot of chunk C0:
     // [B^T | W0 | b0 | Wc0 | bc0]): six LDS reads instead of six global loads in front of the embedding MFMAs
-    constexpr int RO0 = (C0 & 1) ? RB * 4 : 0;
+    constexpr int RO0 = RES >= 0 ? RES : ((C0 & 1) ? RB * 4 : 0);
     const unsigned bt = wq - (unsigned)q * 16u + RO0 + (unsigned)(p * 4 + q) * 4u;
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
@@ -399,16 +401,19 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
     unsigned mb0 = 0u, mb1 = 0u;
     auto layer = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        constexpr int RO = (((C0 + i) & 1) ? RB * 4 : 0) + (i == 0 ? 384 * 4 : 0);      // (layer 0: behind B^T)
+        constexpr int RO = RES >= 0 ? RES + 4 * L.oW(i)
+                                    : (((C0 + i) & 1) ? RB * 4 : 0) + (i == 0 ? 384 * 4 : 0);      // (layer 0: behind B^T)
         constexpr int K = L.K(i);
         constexpr int OB = RO + 32 * K * 4, OC = OB + 32 * 4, OBC = OC + 32 * CD * 4;
-        float* nxt = ring + (((C0 + i + 1) & 1) ? RB : 0);
-        if constexpr (i < 4) {
-            // (layer 4's chunk brings the output layer along: Wo [16][32] | bo [16] follow it in the packed decoder)
-            ring_load(nxt, pk + L.oW(i + 1), (L.oW(i + 2) - L.oW(i + 1) + (i == 3 ? 528 : 0)) / 4, wave, lane);
-        } else if constexpr (NEXT_CD > 0) {
-            constexpr XyzLay LN{NEXT_CD};
-            ring_load(nxt, pk_next, LN.oW(1) / 4, wave, lane);                       // B^T | chunk 0 of the next decoder
+        if constexpr (RES < 0) {
+            float* nxt = ring + (((C0 + i + 1) & 1) ? RB : 0);
+            if constexpr (i < 4) {
+                // (layer 4's chunk brings the output layer along: Wo [16][32] | bo [16] follow it in the packed decoder)
+                ring_load(nxt, pk + L.oW(i + 1), (L.oW(i + 2) - L.oW(i + 1) + (i == 3 ? 528 : 0)) / 4, wave, lane);
+            } else if constexpr (NEXT_CD > 0) {
+                constexpr XyzLay LN{NEXT_CD};
+                ring_load(nxt, pk_next, LN.oW(1) / 4, wave, lane);                   // B^T | chunk 0 of the next decoder
+            }
         }
         f32x4 acc[2];
         acc[0] = lds4(wq + OB);
@@ -454,6 +459,7 @@ ENS_DEV void mlp_xyz_ring(const float* __restrict__ pk, const float* __restrict_
             }
         }
         FST(sx, 4)  // workspace stores of h
+        if constexpr (RES >= 0) return;             // resident weights: nothing to wait for, nobody to wait for
 #ifndef ENS_FULL_VMCNT
         // The layer barrier waits for the ring chunk only, not for the workspace stores issued behind it: vmcnt counts
         // loads, stores and LDS-DMA together in issue order (MI355X_MICROARCH.md), so leaving the N youngest operations --
@@ -622,6 +628,105 @@ __global__ __launch_bounds__(256, 3) void render_fwd_ring_kernel(int64_t n_tiles
     }
     FST(sx, 8)
     FST_FLUSH(sx, blockIdx.x, wave, lane)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight-stationary forward for LARGE forward-only batches (render_img, eval_points / Mesher lattices, the event term's
+// rescaled image): one workgroup of 12 waves per CU keeps the forward sections of its decoders RESIDENT in LDS -- workgroups of
+// role 0 the two occupancy decoders (middle 66 KB + fine 87 KB), role 1 the colour decoder (66 KB) -- and every wave walks its
+// own tiles (static stride) through mlp_xyz_ring<.., RES>: no weight ring (the ring kernel streams 210 KB per 4 tiles through
+// LDS), no per-layer workgroup barrier, waves of one SIMD drift apart so that one wave's gathers / sines run under another's
+// MFMAs.  The two roles write disjoint components of raw (occupancy | colour).  Colour stage, no activation workspace.
+// ------------------------------------------------------------------------------------------------
+constexpr int fwd_res_lds_bytes() { return (XyzLay{32}.fwd_floats() + XyzLay{64}.fwd_floats()) * 4; }
+constexpr int FWD_RES_WAVES = 12;
+constexpr int64_t FWD_RES_MIN_TILES = 16384;        // (5 tiles per wave and more: below that the ring kernel's residency rounds win)
+
+ENS_DEV void res_load(float* dst_lds, const float* __restrict__ src, int n4, int wave, int lane) {      // all 12 waves, 1 KB per wave instruction
+    for (int j = 0; j * (64 * FWD_RES_WAVES) < n4; ++j) {
+        const int e = j * (64 * FWD_RES_WAVES) + wave * 64 + lane;
+        if (e < n4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * e),
+                                             (__attribute__((address_space(3))) void*)(dst_lds + 4 * (j * (64 * FWD_RES_WAVES) + wave * 64)),
+                                             16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(64 * FWD_RES_WAVES, 1) void render_fwd_res_kernel(int64_t n_tiles, int tiles_per_ray,
+                                                                               const float* __restrict__ rays_o,
+                                                                               const float* __restrict__ rays_d,
+                                                                               const double* __restrict__ z_vals, DevScene sc,
+                                                                               float* __restrict__ raw_out,
+                                                                               const double* __restrict__ points, int64_t n_points,
+                                                                               int apply_mask, int n_wg_occ) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    constexpr int MID_BYTES = XyzLay{32}.fwd_floats() * 4;
+    const int role = (int)blockIdx.x < n_wg_occ ? 0 : 1;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
+    if (role == 0) {
+        res_load(fsm, sc.packed[1], XyzLay{32}.fwd_floats() / 4, wave, lane);
+        res_load(fsm + XyzLay{32}.fwd_floats(), sc.packed[2], XyzLay{64}.fwd_floats() / 4, wave, lane);
+    } else {
+        res_load(fsm, sc.packed[3], XyzLay{32}.fwd_floats() / 4, wave, lane);
+    }
+    __syncthreads();                                                  // (vmcnt(0): the resident images have landed)
+    StampCtx sx;
+    FST_INIT(sx)
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)fsm;
+    unsigned wt = lds0 + frag_off(p, q) * 4, wq = lds0 + q * 16;
+    opaque(wt); opaque(wq);
+    const int n_wg = role == 0 ? n_wg_occ : (int)gridDim.x - n_wg_occ;
+    const int wg = role == 0 ? (int)blockIdx.x : (int)blockIdx.x - n_wg_occ;
+    const int64_t stride = (int64_t)n_wg * FWD_RES_WAVES;
+    for (int64_t tile = (int64_t)wave * n_wg + wg; tile < n_tiles; tile += stride) {      // (neighbouring tiles to neighbouring CUs)
+        const int64_t ray = tile / tiles_per_ray;
+        const int64_t sidx = tile * 16 + p;
+        double pw[3];
+        if (points != nullptr) {
+            const int64_t pi = sidx < n_points ? sidx : n_points - 1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pw[a] = points[pi * 3 + a];
+        } else {
+            const double z = z_vals[sidx];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pw[a] = (double)rays_o[ray * 3 + a] + (double)rays_d[ray * 3 + a] * z;
+        }
+        bool inb = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) inb = inb && (pw[a] < sc.hi[a]) && (pw[a] > sc.lo[a]);
+        const float pc = q == 0 ? (float)pw[0] : (q == 1 ? (float)pw[1] : (q == 2 ? (float)pw[2] : 0.f));
+        const VoxNorm vn = vox_norm(pw, sc.lo, sc.hi, sc.gs);
+        const bool live = points == nullptr || sidx < n_points;
+        if (role == 0) {
+            f32x4 cm[2], occ = splat4(0.f);
+            {
+                const Vox v = make_vox_n(vn, sc.grid[1]);
+                gather8(v, sc.grid[1], q, cm[0], cm[1]);
+            }
+            mlp_xyz_ring<2, 0, 0, 0, 0>(nullptr, nullptr, nullptr, pc, cm, occ, nullptr, false, nullptr, wt, wq, wave, lane, p, q, sx);
+            f32x4 cf[4], of;
+            {
+                const Vox v = make_vox_n(vn, sc.grid[2]);
+                gather8(v, sc.grid[2], q, cf[0], cf[1]);
+            }
+            cf[2] = cm[0];
+            cf[3] = cm[1];
+            mlp_xyz_ring<4, 0, 0, 0, MID_BYTES>(nullptr, nullptr, nullptr, pc, cf, of, nullptr, false, nullptr, wt, wq, wave, lane, p, q, sx);
+            if (q == 0 && live) raw_out[sidx * 4 + 3] = (inb || (points != nullptr && !apply_mask)) ? of[0] + occ[0] : 100.f;   // Renderer.py:58
+        } else {
+            f32x4 cc[2], col = splat4(0.f);
+            {
+                const Vox v = make_vox_n(vn, sc.grid[3]);
+                gather8(v, sc.grid[3], q, cc[0], cc[1]);
+            }
+            mlp_xyz_ring<2, 0, 0, 0, 0>(nullptr, nullptr, nullptr, pc, cc, col, nullptr, false, nullptr, wt, wq, wave, lane, p, q, sx);
+            if (q == 0 && live) {
+                raw_out[sidx * 4 + 0] = col[0];
+                raw_out[sidx * 4 + 1] = col[1];
+                raw_out[sidx * 4 + 2] = col[2];
+            }
+        }
+    }
 }
 
 #ifdef ENS_STAMPS
@@ -1007,6 +1112,35 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
                 hipFuncSetAttribute(reinterpret_cast<const void*>(render_fwd_ring_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, fwd_ring_lds_bytes(3)) != hipSuccess)
                 return -2;
             attr_set = true;
+        }
+        // large forward-only colour-stage batches: the weight-stationary kernel (ENSLAM_FWD_RES=0 / 1 forces the ring / resident form)
+        static const int res_env = [] { const char* e = getenv("ENSLAM_FWD_RES"); return e ? atoi(e) : -1; }();
+        if (stage == 3 && act_ws == nullptr && raw != nullptr && (res_env >= 0 ? res_env != 0 : n_units >= FWD_RES_MIN_TILES)) {
+            static bool res_attr = false;
+            if (!res_attr) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_fwd_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        fwd_res_lds_bytes()) != hipSuccess)
+                    return -2;
+                res_attr = true;
+            }
+            static const int cus_r = [] {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+                return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            }();
+            // occupancy decoders : colour decoder = 588 : 254 MFMAs per tile (70 : 30), but the colour role also carries a grid gather,
+            // an embedding and the output stores per tile: two thirds of the workgroups for role 0 measured best (eval_points, 16 M
+            // points: 160 / 170 / 179 / 188 / 196 of 256 -> 887 / 946 / 935 / 834 / 740 M points/s)
+            static const int occ_env = [] { const char* e = getenv("ENSLAM_FWD_RES_OCC"); return e ? atoi(e) : 0; }();      // A/B aid
+            const int n_occ = (occ_env > 0 && occ_env < cus_r) ? occ_env : (cus_r * 2 + 1) / 3;
+            render_fwd_res_kernel<<<dim3(cus_r), dim3(64 * FWD_RES_WAVES), fwd_res_lds_bytes(), st>>>(n_units, tpr, ro, rd, z, sc, raw, pts,
+                                                                                                     n_points, apply_mask, n_occ);
+            if (hipGetLastError() != hipSuccess) return -2;
+            if (pts_ring) return 0;
+            if (ts != nullptr && ls != nullptr)
+                return ens_launch_tracker_tail((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, *ls, *ts, wl, st);
+            return ens_launch_composite_fwd((int)(n_units / tpr), 16 * tpr, raw, z, depth, var, rgb, nullptr, st, ls, wl);
         }
         const int64_t groups = (n_units + 3) / 4;
         // colour stage: two roles per group of 4 tiles, interleaved in runs of 8 blocks (render_fwd_ring_kernel)
