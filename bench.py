@@ -441,7 +441,8 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
             loss, depth, var, color = renderer.render_batch_ray_rgbd_loss(grids, model, rd, ro, dev, stage, gd, gc, 0.2)
         if 'one' not in seed_grad:              # d(loss)/d(loss) = 1, allocated once (backward() would fill one per step)
             seed_grad['one'] = torch.ones_like(loss)
-        loss.backward(gradient=seed_grad['one'])
+        with EF.engine_on_calling_thread():       # scoped (the library's loops do the same); see `autograd_engine`
+            loss.backward(gradient=seed_grad['one'])
         return loss
 
     def post():         # one bucketed RCCL all-reduce of the leaf gradients
@@ -516,9 +517,21 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
         for _ in range(5):
             api_step()
         n_api = min(steps, 100)
+        # (i) nothing changed at all: PyTorch's default autograd threading (the engine's worker thread runs our backward)
         api_el, _l = env.timed(api_step, n_api)
         del _l
         api = (n_local * n_api / api_el, api_el / n_api * 1e3)
+        # (ii) the caller wraps its backward in `with EF.engine_on_calling_thread():` (one line)
+        from evennicer_slam_amd import functional as _EF
+
+        def api_step_ct():
+            with _EF.engine_on_calling_thread():
+                return api_step()
+        for _ in range(3):
+            api_step_ct()
+        api_el2, _l = env.timed(api_step_ct, n_api)
+        del _l
+        api = api + (n_local * n_api / api_el2, api_el2 / n_api * 1e3)
 
     mode = 'eager'
     gstep = None
@@ -623,10 +636,16 @@ def run_workload(env, args, scene, rays, scaling, steps, warmup, want_events, wa
         "loss": float(loss.item()), "mode": mode, "loss_impl": "torch" if args.torch_loss else ("fused HIP (losses.rgbd_loss)" if args.separate_loss or stage == 'coarse'
                                                                   else "fused into the compositing launches (render_batch_ray_rgbd_loss)"),
         "eager_rays_per_s": total_rays * eager_steps / eager_elapsed,
+        "autograd_engine": ("headline (hipGraph replay): no autograd at replay time; eager_rays_per_s and the capture: backward inside "
+                            "`with functional.engine_on_calling_thread()` (scoped, restored on exit); api_rays_per_s: PyTorch's "
+                            "default threading; api_calling_thread_rays_per_s: the scoped form"),
     }
     if api is not None:
-        out["api_rays_per_s"], out["api_ms_per_step"] = api
-        out["api_step"] = "render_batch_ray + torch L1 losses + loss.backward(), Python-driven (no hipGraph, no fused-loss entry)"
+        out["api_rays_per_s"], out["api_ms_per_step"] = api[0], api[1]
+        out["api_step"] = ("render_batch_ray + torch L1 losses + loss.backward(), Python-driven (no hipGraph, no fused-loss entry), "
+                           "PyTorch's default autograd threading")
+        out["api_calling_thread_rays_per_s"], out["api_calling_thread_ms_per_step"] = api[2], api[3]
+        out["api_calling_thread_step"] = "the same with `with functional.engine_on_calling_thread(): loss.backward()`"
     if fit is not None:
         out["fit"] = fit
     if comm_on:

@@ -804,7 +804,8 @@ size_t enslam_grid_handoff_floats(int32_t stage, int32_t n_rays, int32_t n_sampl
 
 size_t enslam_activation_floats(int32_t stage, int32_t n_rays, int32_t n_samples, int32_t act_light) {
     if (stage == ENSLAM_STAGE_COARSE || n_rays <= 0 || n_samples <= 0) return 0;
-    return (size_t)n_rays * (size_t)(n_samples / 16) * ACT_SLOTS * (act_light ? ACTL_STRIDE : ACT_STRIDE);
+    // full workspace: the activation blocks, then the dh region of the two-kernel backward (render_bwd2.hip)
+    return (size_t)n_rays * (size_t)(n_samples / 16) * ACT_SLOTS * (act_light ? ACTL_STRIDE : ACT_STRIDE + DH_STRIDE);
 }
 
 int enslam_eval_points(int32_t stage, int64_t n_points, const double* points, const enslam_scene* scene,

@@ -97,6 +97,11 @@ constexpr int ACT_SLOTS = 3;                                // decoder slots per
 // lane-linear) and the embedding's position gradient (one float4 per lane, meaningful on q == 0 lanes).
 constexpr int DG_DPE = 2 * 256;
 constexpr int DG_STRIDE = 3 * 256;
+// Two-kernel backward (render_bwd2.hip): dh_i of the five layers, chain kernel -> weight-gradient kernel, per (tile, decoder
+// slot): 10 tiles in register layout (lane-linear), layer i's row tile rt at (2 i + rt) * 256, then dC as [sample][32]
+// (2 tiles) for the scatter.  The region follows the activation blocks in the full workspace (enslam_activation_floats
+// counts it).
+constexpr int DH_STRIDE = 12 * 256;
 
 // ----------------------------------------------------------------------------------------------
 // Scene description passed by value to kernels

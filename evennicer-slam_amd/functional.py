@@ -21,6 +21,39 @@ def _require_hip(t, what):
                             f"fallback")
 
 
+def engine_on_calling_thread():
+    """Context manager: run the backward passes started inside it on the calling thread instead of the autograd engine's
+    per-device worker thread.  For a Python-implemented autograd.Function the worker thread costs two thread switches and a
+    GIL hand-over per call (0.25-0.3 ms of a 0.9 ms Python-driven step, tools/hostprof.py); results are identical.  The
+    switch is scoped: PyTorch's setting is restored on exit and nothing outside the block changes (round 3 flipped it
+    process-wide in Renderer.__init__).  `ENSLAM_KEEP_AUTOGRAD_THREADS=1` makes this a no-op.
+
+        with EF.engine_on_calling_thread():
+            loss.backward()
+    """
+    if os.environ.get('ENSLAM_KEEP_AUTOGRAD_THREADS') == '1':
+        import contextlib
+        return contextlib.nullcontext()
+    return torch.autograd.set_multithreading_enabled(False)
+
+
+def _live_grid_guard(grids):
+    """[(grid, version)] of the channels_last_3d grids a render call reads IN PLACE: its backward reads the same storage again
+    (corner re-gather of the ray gradients, the recompute route), through a detached alias autograd does not version-check."""
+    return [(g, g._version) for g in grids if is_native_grid(g)]
+
+
+def _check_live_grids(guard):
+    """Plain torch raises when a tensor saved for backward has been modified in place; the in-place read of a native grid gets
+    the same protection: an optimiser step / MaskedGridOptimizer.step / any in-place write to the map between a render call
+    and its backward would silently give ray and grid gradients of a different map."""
+    for g, v in guard:
+        if g._version != v:
+            raise L.EnslamError("a feature grid read in place by this render call (channels_last_3d layout) was modified in place "
+                                f"between the call and its backward (version {v} -> {g._version}): backpropagate before updating "
+                                "the map, or render from a clone")
+
+
 def _f32c(t):
     """detached contiguous float32 form of t (no copies, no dispatcher calls beyond detach() when it already is one)."""
     t = t.detach()
@@ -56,8 +89,15 @@ _capture = {'epoch': 0, 'active': 0, 'raw_writes': None, 'init_zero': None, 'per
 # the 64-voxel blocks that hold non-zeros (`prev` of enslam_step_finish_rays_prev).  The finish launch of the next replay
 # rewrites exactly the blocks flagged here or touched by its own rays, so EVERY other writer of such a buffer has to add the
 # blocks it fills to these flags: parallel.allreduce_gradients (the sums of the other ranks' blocks) does through
-# note_foreign_blocks().  Entries live as long as the GraphedStep that captured them (graph.GraphedStep.__del__).
+# note_foreign_blocks().  Entries live as long as the GraphedStep that captured them (graph.GraphedStep.close / __del__).
+# An address alone does not identify a buffer (the allocator hands a freed address out again): an entry is
+# data_ptr -> (weak reference to the buffer tensor, flags), a look-up also compares the storage, and a graph that goes away
+# removes only the entries that are still its own (_persist_register / forget_persistent).
 _persist_prev = {}
+
+
+def _persist_register(g, pv):
+    _persist_prev[g.data_ptr()] = (weakref.ref(g), pv)
 
 
 def _capturing():
@@ -101,8 +141,7 @@ def end_capture(ok=True):
     # from all-zero memory; filled here, eagerly, once -- a fill inside the capture would run at every replay
     init, _capture['init_zero'] = _capture['init_zero'] or [], None
     if not ok:
-        for ptr, _pv in (_capture['persist'] or {}).values():
-            _persist_prev.pop(ptr, None)
+        forget_persistent(list((_capture['persist'] or {}).values()))
         _capture['persist'] = None
         _capture['persist_need'] = {}
         end_capture.persist_keys = []
@@ -116,22 +155,33 @@ def end_capture(ok=True):
             out.append(t)
     persist, _capture['persist'] = _capture['persist'] or {}, None
     _capture['persist_need'] = {}
-    end_capture.persist_keys = [ptr for ptr, _pv in persist.values()]      # (read by graph.GraphedStep)
+    end_capture.persist_keys = list(persist.values())                      # (ptr, flags) pairs, read by graph.GraphedStep
     return out
 
 
 def forget_persistent(keys):
-    """The graph that owned these persistent gradient buffers is gone (graph.GraphedStep.__del__)."""
-    for k in keys:
-        _persist_prev.pop(k, None)
+    """The graph that owned these persistent gradient buffers is gone (graph.GraphedStep.close): keys = its (data_ptr, flags)
+    pairs.  Only entries that still carry THESE flags are removed -- a newer graph may have been given the same address."""
+    for ptr, pv in keys:
+        e = _persist_prev.get(ptr)
+        if e is not None and e[1] is pv:
+            del _persist_prev[ptr]
 
 
 def note_foreign_blocks(grad, flags):
     """`grad` (a dense feature-grid gradient) has just been written in the 64-voxel blocks flagged in `flags` (uint8, one per
     block) by something other than the render backward -- the unpack of a gradient all-reduce.  If it is the persistent
     gradient buffer of a captured step, those blocks join the flags of the blocks its next replay must rewrite."""
-    pv = _persist_prev.get(grad.data_ptr())
-    if pv is not None and pv.numel() == flags.numel():
+    e = _persist_prev.get(grad.data_ptr())
+    if e is None:
+        return False
+    g0, pv = e[0](), e[1]
+    if g0 is None:                              # the buffer this entry described is gone: the address now belongs to something else
+        del _persist_prev[grad.data_ptr()]
+        return False
+    if g0.untyped_storage()._cdata != grad.untyped_storage()._cdata:
+        return False
+    if pv.numel() == flags.numel():
         torch.maximum(pv, flags.reshape(pv.shape).to(pv.dtype), out=pv)
         return True
     return False
@@ -793,7 +843,7 @@ class _Accumulators:
                 g = torch.empty(n, dtype=torch.float32, device=dev)
                 _capture['init_zero'].append(g.untyped_storage())
                 _capture['persist'][grid_ids[i]] = (g.data_ptr(), pv)
-                _persist_prev[g.data_ptr()] = pv
+                _persist_register(g, pv)
                 self.nat_persist[k] = (g, pv)
 
     def native_grad(self, plan, k):
@@ -1021,6 +1071,7 @@ class _RenderFn(torch.autograd.Function):
                     if need_first is not None:
                         torch.maximum(need_first, flags[i], out=need_first)
         ctx.keep = (ro, rd, z, raw, depth, grids_vm, packed, act, flags)
+        ctx.live_guard = _live_grid_guard(grids) if any(ctx.needs_input_grad) and not _cap_tag() else []
         ctx.rgb = rgb if plan.loss is not None else None
         ctx.d_raw_unit = d_raw_unit if plan.loss is not None else None
         ctx.work, ctx.wcount = work, wcount
@@ -1044,6 +1095,7 @@ class _RenderFn(torch.autograd.Function):
         else:
             g_depth, g_var, g_rgb = gouts
         ro, rd, z, raw, depth, grids_vm, packed, act, flags = ctx.keep
+        _check_live_grids(ctx.live_guard)
         N, dev, st = ro.shape[0], ro.device, _stream()
         nk = len(plan.kinds)
         needs = ctx.needs_input_grad            # (plan, ro, rd, gd, t_rand, grids..., params...)
@@ -1205,7 +1257,7 @@ class _RenderFn(torch.autograd.Function):
                 plan.state.flags[ctx.grid_ids[i]] = pv      # the launch moves the flags there (last_block_flags)
                 _capture['init_zero'] += [g.untyped_storage(), pv.untyped_storage()]
                 _capture['persist'][ctx.grid_ids[i]] = (g.data_ptr(), pv)
-                _persist_prev[g.data_ptr()] = pv
+                _persist_register(g, pv)
         for k in plan.kinds:
             out.append(grid_out.get(k))
         kinds_p = [k for k in plan.kinds if need_par[k]]
@@ -1442,6 +1494,7 @@ class _PlanFn(torch.autograd.Function):
         state.work = (_blob_view(gradb, Lay.g_counter, 4, torch.int32), e.ntiles) if P.use_work_list else (None, 0)
         ctx.e, ctx.rplan = e, rplan
         ctx.keep = (ro, rd, gd, gc, scratch, gradb, outb, gv, hold)
+        ctx.live_guard = _live_grid_guard(tensors[:len(e.kinds)]) if any(ctx.needs_input_grad) else []
         ctx.calls = 0
         if P.loss_kind == 1:
             loss = _blob_view(outb, Lay.o_loss, 8, torch.float64)
@@ -1455,6 +1508,7 @@ class _PlanFn(torch.autograd.Function):
         e = ctx.e
         P, Lay = e.plan, e.layout
         ro, rd, gd, gc, scratch, gradb, outb, gv, hold = ctx.keep
+        _check_live_grids(ctx.live_guard)
         N, dev = P.n_rays, ro.device
         n_in = e.n_in + 2
         if P.loss_kind == 1:

@@ -45,14 +45,25 @@ class GraphedStep:
             self.raw_writes = EF.end_capture(ok)
             self._persist_keys = list(getattr(EF.end_capture, 'persist_keys', []))
 
+    def close(self):
+        """Release the graph and withdraw its persistent gradient buffers from the library's registry.  Call it when the step
+        is no longer replayed (the destructor does the same, but a GraphedStep caught in a reference cycle is collected late)."""
+        keys, self._persist_keys = getattr(self, '_persist_keys', []), []
+        if keys:
+            from . import functional as EF
+            EF.forget_persistent(keys)
+        self.graph = None
+        self.out = None
+
     def __del__(self):
         try:
-            from . import functional as EF
-            EF.forget_persistent(getattr(self, '_persist_keys', []))
+            self.close()
         except Exception:
             pass
 
     def replay(self):
+        if self.graph is None:
+            raise RuntimeError("this GraphedStep has been closed")
         self.graph.replay()
         if self.raw_writes:
             torch._C._increment_version(self.raw_writes)        # one call for the list (a bare tensor would be iterated row by row)

@@ -16,7 +16,8 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .functional import VoxelMajorGrid, _native_vm, _ptr, _require_hip, _stream, is_native_grid, note_raw_write
+from .functional import (VoxelMajorGrid, _native_vm, _ptr, _require_hip, _stream, engine_on_calling_thread, is_native_grid,
+                         note_raw_write)
 
 GRID_KEYS = ('grid_coarse', 'grid_middle', 'grid_fine', 'grid_color')
 
@@ -345,7 +346,8 @@ class MapperIteration:
             loss = rgbd_loss(depth, color if use_color else None, gd_l, gc_l, self.w_color_loss)
         if self._one is None:
             self._one = torch.ones_like(loss)
-        loss.backward(gradient=self._one)                                   # :573
+        with engine_on_calling_thread():
+            loss.backward(gradient=self._one)                               # :573
         if self.dec_opt is not None:
             self.dec_opt.step()                                             # :575 (one optimizer.step() in the reference)
         if self.cam_opt is not None:

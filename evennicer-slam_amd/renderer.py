@@ -27,13 +27,8 @@ class Renderer(object):
             raise NotImplementedError("the HIP path implements the NICE / occupancy configuration "
                                       "(configs/nice_slam.yaml: occupancy True); iMAP mode is out of scope")
         self._tvals = {}
-        # The autograd engine hands every backward to a per-device worker thread; for a Python-implemented Function that is two
-        # thread switches and a GIL hand-over per call -- 0.25-0.3 ms of a 0.9 ms Python-driven step here (tools/hostprof.py).
-        # A process that renders through this class drives ONE device, so the engine is told to run backward passes on the
-        # calling thread (results are identical).  ENSLAM_KEEP_AUTOGRAD_THREADS=1 leaves PyTorch's default in place.
-        import os
-        if os.environ.get('ENSLAM_KEEP_AUTOGRAD_THREADS') != '1' and torch.autograd.is_multithreading_enabled():
-            torch.autograd.set_multithreading_enabled(False)
+        # (PyTorch's autograd threading is left alone here: the loops of this package scope the single-thread engine around
+        # their own backward calls -- functional.engine_on_calling_thread -- and a caller can do the same.)
         # ray-sharded callers (parallel.ShardedRenderer) set this to functional.batch_depth_max(whole batch)
         self.depth_max_override = None
         # what render calls leave behind for this renderer's caller (touched-block flags, work-list size, profiling hooks)

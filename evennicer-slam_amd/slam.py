@@ -272,7 +272,8 @@ class SLAM:
             opt.zero_grad(set_to_none=True)
             depth, _u, color = self.renderer.render_batch_ray(grids, dec, rd, ro, dev, 'color', gt_depth=gd)
             loss = rgbd_loss(depth, color, gd, gc, self.cfg['mapping']['w_color_loss'])
-            loss.backward()
+            with EF.engine_on_calling_thread():
+                loss.backward()
             opt.step()
         for q in params:
             q.grad = None

@@ -15,6 +15,7 @@ import os
 import torch
 
 from . import _lib as L
+from . import functional as EF
 from .functional import _ptr, _require_hip, _stream
 
 
@@ -327,7 +328,8 @@ class TrackerIteration(object):
             gt_event, gt_mask = frame[0], frame[1]
         o = self.iteration_losses(camera_tensor, gt_color, gt_depth, frame, batch_size, rgbd, event, scale_factor)
         if o['total'] is not None and o['total'].requires_grad:
-            o['total'].backward()                                                                   # :197-199,231-232
+            with EF.engine_on_calling_thread():
+                o['total'].backward()                                                               # :197-199,231-232
         optimizer.step()
         optimizer.zero_grad()
         item = lambda x: None if x is None else float(x.item())
@@ -366,7 +368,8 @@ class GraphedCameraIteration(object):
                                      scale_factor, static_shapes=True)
             if 'one' not in self.__dict__:
                 self.one = torch.ones_like(o['total'])
-            o['total'].backward(gradient=self.one)
+            with EF.engine_on_calling_thread():
+                o['total'].backward(gradient=self.one)
             optimizer.step()
             if self._zero is None:
                 self._zero = o['total'].new_zeros(())

@@ -34,8 +34,8 @@ def run(grid_grad, par_grad, ray_grad, stage='color', steps=30):
     tf = np.array([x.elapsed_time(y) for x, y in fwd[5:]]) * 1e3
     print(f"stage {stage:6s} grid_grad={int(grid_grad)} par_grad={int(par_grad)} ray_grad={int(ray_grad)}: decoder_bwd median {np.median(t):8.1f} us  min {t.min():8.1f}   fwd(all launches) median {np.median(tf):7.1f} us", flush=True)
 
-combos = [(1,1,1)] if os.environ.get("QUICK") else [(0,0,1),(1,1,1)] if os.environ.get("TRACK") else [(1,1,1),(0,1,1),(1,0,1),(1,1,0),(0,0,1),(0,1,0),(1,0,0)]
+combos = [tuple(int(x) for x in os.environ["COMBO"].split(","))] if os.environ.get("COMBO") else [(1,1,1)] if os.environ.get("QUICK") else [(0,0,1),(1,1,1)] if os.environ.get("TRACK") else [(1,1,1),(0,1,1),(1,0,1),(1,1,0),(0,0,1),(0,1,0),(1,0,0)]
 for combo in combos:
     run(*combo)
-for st in (() if (os.environ.get("QUICK") or os.environ.get("TRACK")) else ("middle","fine","coarse")):
+for st in (() if (os.environ.get("QUICK") or os.environ.get("TRACK") or os.environ.get("COMBO")) else ("middle","fine","coarse")):
     run(1,1,1,stage=st)

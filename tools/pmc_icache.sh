@@ -16,7 +16,7 @@ if not fs:
     print("no counters in", sys.argv[1]); sys.exit(0)
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
 for r in csv.DictReader(open(fs[0])):
-    m = re.search(r"(render_fwd_ring_kernel|decoder_bwd_split_kernel|step_kernel|sample_kernel|composite_fwd_kernel)", r["Kernel_Name"])
+    m = re.search(r"(render_fwd_ring_kernel|decoder_bwd_split_kernel|decoder_chain_kernel|decoder_dw_kernel|step_kernel|sample_kernel|composite_fwd_kernel)", r["Kernel_Name"])
     if not m: continue
     acc[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"]); n[m.group(1)][r["Counter_Name"]] += 1
 for k in acc:

@@ -18,12 +18,12 @@ import csv, sys, glob, collections, re, json
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
 for f in glob.glob(sys.argv[1] + '/p*/**/p_counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(render_fwd_ring_kernel|decoder_bwd_split_kernel|step_kernel|sample_kernel|composite_fwd_kernel)", r["Kernel_Name"])
+        m = re.search(r"(render_fwd_ring_kernel|decoder_bwd_split_kernel|decoder_chain_kernel|decoder_dw_kernel|step_kernel|sample_kernel|composite_fwd_kernel)", r["Kernel_Name"])
         if not m: continue
         acc[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"]); n[m.group(1)][r["Counter_Name"]] += 1
 out = {k: {c: round(v / n[k][c]) for c, v in sorted(acc[k].items())} for k in acc}
 json.dump(out, open(sys.argv[1] + '/sweep.json', 'w'), indent=1)
-for k in ('render_fwd_ring_kernel', 'decoder_bwd_split_kernel'):
+for k in ('render_fwd_ring_kernel', 'decoder_bwd_split_kernel', 'decoder_chain_kernel', 'decoder_dw_kernel'):
     print(k)
     for c, v in out.get(k, {}).items(): print(f"   {c:34s} {v:>14,d}")
 PY
