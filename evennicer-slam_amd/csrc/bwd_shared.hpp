@@ -338,16 +338,7 @@ ENS_DEV void dep_tile(const unsigned (&dep)[4], const f32x4& x) {
     for (int r = 0; r < 4; ++r) lds_st1(dep[r] + T * 1024, x[r]);
 }
 
-int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return cus;
-}
+int device_cus() { return ens_device_cus(); }
 
 
 }  // namespace

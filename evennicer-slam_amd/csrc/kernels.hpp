@@ -5,6 +5,24 @@
 #include "common.hpp"
 #include "raygrad.hpp"
 
+// Function attributes (dynamic LDS limits) and CU counts belong to a DEVICE, and the reference lets one process render on two
+// (cfg['tracking']['device'] != cfg['mapping']['device']): the launchers keep their one-time flags and cached counts per device
+// ordinal, not per process.
+constexpr int ENS_MAX_DEVICES = 16;
+inline int ens_device_ordinal() {
+    int d = 0;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < ENS_MAX_DEVICES) ? d : 0;
+}
+inline int ens_device_cus() {
+    static int cus[ENS_MAX_DEVICES] = {};
+    const int d = ens_device_ordinal();
+    if (cus[d] == 0) {
+        hipDeviceProp_t prop;
+        cus[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus[d];
+}
+
 // Mapper RGB-D loss (Mapper.py:553-562) fused into the compositing launches: gd != null switches it on
 struct LossSpec {
     const float* gd;             // gt depth [N] (term only where > 0)

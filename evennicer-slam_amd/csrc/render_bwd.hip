@@ -1629,7 +1629,8 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
     }
     if (n2 == 0) return 0;
     const int64_t n_tiles = (int64_t)n_rays * ntl;
-    static bool attr_set = false;
+    static bool attr_done[ENS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[ens_device_ordinal()];
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_xyz(4)) != hipSuccess ||

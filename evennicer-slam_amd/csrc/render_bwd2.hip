@@ -30,6 +30,22 @@
 
 #define IC(n) std::integral_constant<int, n>{}
 
+// Diagnostic build only (-DENS_STAMPS, tools/stamps_bwd2.py): per-wave s_memtime totals per code segment, written to a buffer of
+// their own ([workgroup][16 waves][S2_NSEG], last slot = s_memrealtime span); never compiled into the shipped library.
+#ifdef ENS_STAMPS
+#define S2_NSEG 12
+static __device__ unsigned long long* g_stamp_buf2 = nullptr;
+#define S2_DECL unsigned long long s2_acc[S2_NSEG] = {}; unsigned long long s2_prev = 0, s2_rt0 = 0;
+#define S2_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s2_rt0)::"memory"); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s2_prev)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#define S2(k) { unsigned long long n_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n_)::"memory"); __builtin_amdgcn_sched_barrier(0); s2_acc[k] += n_ - s2_prev; s2_prev = n_; }
+#define S2_FLUSH(sel_, wave_, lane_) { unsigned long long r1_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1_)::"memory"); s2_acc[S2_NSEG - 1] = r1_ - s2_rt0; if (g_stamp_buf2 && (lane_) == 0) { for (int k_ = 0; k_ < S2_NSEG; ++k_) g_stamp_buf2[(((size_t)(sel_) * 256 + blockIdx.x) * 16 + (wave_)) * S2_NSEG + k_] = s2_acc[k_]; } }
+#else
+#define S2_DECL
+#define S2_START
+#define S2(k)
+#define S2_FLUSH(sel_, wave_, lane_)
+#endif
+
 namespace {
 
 // cooperative async copy global -> LDS of n4 float4 by NWAVES waves (1 KB per wave instruction)
@@ -86,7 +102,18 @@ constexpr int c2_off(int i) { return i == 4 ? 0 : (i == 3 ? 2048 : (i == 2 ? 716
 constexpr int C2_BP = 15360, C2_BT = 16896, C2_WFLOATS = 17280;
 constexpr int C2_IMG = 384;                         // gradient image of a workgroup: dB^T [96][4]
 constexpr int C2_WAVES = 12;                        // three per SIMD (<= 168 registers)
-constexpr int C2_WAVE_FLOATS = 6 * 256;             // per-wave scratch: 6 tiles d_arg deposit
+constexpr int C2_WAVE_FLOATS = 6 * 256;             // per-wave scratch: 6 tiles d_arg deposit (tiles 0, 1 double as dC staging)
+// Where the feature-gradient scatter runs (A/B aid):
+//   2 = in a launch of its own between the two kernels (decoder_scatter_kernel: one wave per tile and decoder, values in
+//       registers, fire-and-forget atomics);
+//   1 = in the chain kernel, the previous tile's scatter in four pieces in front of the backward layers 4..1 of the wave's next tile;
+//   0 = in the weight-gradient kernel, two samples per wave and step.
+// Measured (room0, 1000 rays, same box): 1 -> chain 47 -> 103 us (the scatter is ~1800 instructions per tile, as many as the
+// chain itself, and every wait for a load behind it waits for its atomics); 0 -> weight-gradient kernel 59 -> 102 us (its
+// barrier per item waits for the slowest wave's atomics).
+#ifndef ENS_SCATTER_WHERE
+#define ENS_SCATTER_WHERE 2
+#endif
 constexpr int lds_bytes_chain2() { return (C2_WFLOATS + C2_IMG + C2_WAVES * C2_WAVE_FLOATS) * 4; }
 
 // What the chain kernel leaves per (tile, decoder slot) for the weight-gradient kernel (DH_STRIDE floats): dh_i of the five
@@ -146,15 +173,21 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
     auto item_tile = [&](int64_t i) { return work_tile_u(A, i < n_items ? i : n_items - 1); };
 
     // loads of a tile are issued one tile ahead
-    f32x4 draw_n = splat4(0.f);
+    f32x4 draw_n = splat4(0.f), rec_n = splat4(0.f), bq_n = splat4(0.f);
     uint2 mw_n = make_uint2(0u, 0u);
     float pc_n = 0.f;
+    constexpr bool SCAT = ENS_SCATTER_WHERE == 1;
     auto fetch = [&](int tile) {
         const float* __restrict__ w = A.act_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * ACT_STRIDE;
         draw_n = ld4(A.d_raw + ((int64_t)tile * 16 + p) * 4);
         mw_n = *reinterpret_cast<const uint2*>(w + ACT_MASK + lane * 2);
         if (q < 3) pc_n = w[WSQ + (p >> 2) * 64 + (q ^ (p >> 2)) * 4 + (p & 3)];      // coordinate q of sample p (swizzled tile)
+        bq_n = ld4(w + WSQ + (lane ^ (lane >> 4)) * 4);             // the coordinates' fragment (dB^T operand), un-swizzled by address
+        if (SCAT && want_g) rec_n = ld4(w + ACT_VOX + p * 4);
     };
+    float* const stg = smem + C2_WFLOATS + C2_IMG + wave * C2_WAVE_FLOATS;       // dC as [sample][32]: scratch tiles 0, 1
+    f32x4 rec_prev = splat4(0.f);
+    bool pend = false;
     int64_t it = (int64_t)wg * NW + wave;
     int tile_cur = 0, tile_nxt = 0;                                 // work-list entries run two tiles ahead of their use
     if (it < n_items) {
@@ -162,15 +195,39 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         tile_nxt = item_tile(it + stride);
         fetch(tile_cur);
     }
+    S2_DECL
+    S2_START
     for (; it < n_items; it += stride) {
         const int tile = tile_cur;
         tile_cur = tile_nxt;
         tile_nxt = item_tile(it + 2 * stride);
-        const f32x4 draw = draw_n * dscale;
-        const uint2 mw = mw_n;
-        const float pc = pc_n;
+        f32x4 draw = draw_n * dscale, rec = rec_n, bq = bq_n;
+        uint2 mw = mw_n;
+        float pc = pc_n;
+        // The prefetched values are taken into their own registers HERE, in front of this tile's atomics (left to the compiler
+        // the copies sink behind them, and the wait for the loads becomes a wait for float atomics issued a moment ago)
+        asm volatile("" : "+v"(draw), "+v"(mw.x), "+v"(mw.y), "+v"(rec), "+v"(pc), "+v"(bq) :: "memory");
+        S2(0)       // prefetched loads have arrived
         if (it + stride < n_items) fetch(tile_cur);
-        const float* __restrict__ wsb = A.act_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * ACT_STRIDE;
+        ScatterSt sst;
+        sst.acc[0] = sst.acc[1] = sst.acc[2] = sst.acc[3] = 0.f; sst.cur = 0u; sst.open = false;
+        const float rp0 = rec_prev[0], rp1 = rec_prev[1], rp2 = rec_prev[2], rp3 = rec_prev[3];
+        const int sri = __builtin_bit_cast(int, rp0), srx = __builtin_bit_cast(int, rp1), sry = __builtin_bit_cast(int, rp2),
+                  srz = __builtin_bit_cast(int, rp3);
+        // one 4-sample piece of the PREVIOUS tile's scatter (values from the staging tiles): in front of layers 4, 3, 2, 1, so that
+        // the last atomics are issued two layers and the tail before the tile ends
+        auto piece = [&](auto ic) {
+            constexpr int P0 = decltype(ic)::value;
+            if constexpr (SCAT) {
+                if (pend) {
+                    scatter_piece_lds<P0>(sst, stg, sri, srx, sry, srz, A.ggrid[kind], lane);
+                    if constexpr (P0 == 12) {
+                        if (sst.open) scatter_flush(sst, A.ggrid[kind], lane, 15, 0);
+                        wave_lds_fence();
+                    }
+                }
+            }
+        };
         float* const dhw = A.dh_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * DH_STRIDE;
         float* const dgw = handoff ? A.dgrid_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * DG_STRIDE : nullptr;
         const unsigned mbits[5] = {mw.x & 255u, (mw.x >> 8) & 255u, (mw.x >> 16) & 255u, (mw.x >> 24) & 255u, mw.y & 255u};
@@ -208,10 +265,14 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
                 lin_lds_swz<2, 2, 32, 0>(dh, wb, swd, dpre);
             }
         };
-        bwd_layer(IC(4)); bwd_layer(IC(3)); bwd_layer(IC(2)); bwd_layer(IC(1)); bwd_layer(IC(0));
+        S2(1)       // next tile's loads issued, output layer
+        piece(IC(0)); S2(2) bwd_layer(IC(4)); S2(3) piece(IC(4)); S2(2) bwd_layer(IC(3)); S2(3) piece(IC(8)); S2(2) bwd_layer(IC(2)); S2(3)
+        piece(IC(12)); S2(2)
+        bwd_layer(IC(1)); bwd_layer(IC(0));
+        S2(3)       // (2: scatter pieces, 3: backward layers)
+        pend = false;
 
         // ---- embedding: d_arg = d_emb * cos(arg);  dB^T += d_arg (x) p;  dp += B d_arg
-        const f32x4 bq = ld4(wsb + WSQ + (lane ^ (lane >> 4)) * 4);  // the coordinates' fragment straight from the swizzled workspace tile
 #pragma unroll
         for (int t = 0; t < 6; ++t) {                               // cos(arg) recomputed: cheaper than carrying it
             const float a = *reinterpret_cast<const lds_float*>(static_cast<uintptr_t>(wbt + 16 * t * 16));
@@ -221,6 +282,7 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         }
         f32x4 dpe[1] = {splat4(0.f)};
         if (want_r) lin_lds_swz<1, 6, 96, 0>(dpe, wbp, swd, demb);  // rows 0..2: dp (q == 0 lanes)
+        S2(4)       // cos, d_arg, dp
         {
             // dB^T of this tile: d_arg through this wave's own LDS tiles (sample index into the MFMA K slot), six 16 x 16
             // products against the coordinates, summed into the workgroup's image by LDS float atomics (12 lanes of each carry a
@@ -248,14 +310,24 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
                 }
             }
         }
+        S2(5)       // dB^T
         if (handoff) {                  // hand-off to the ray-gradient role: dC (register layout) + embedding's position gradient
             st4(dgw + lane * 4, dc[0]);
             st4(dgw + 256 + lane * 4, dc[1]);
             st4(dgw + DG_DPE + lane * 4, dpe[0]);
         }
-        if (want_g) {                   // dC as [sample][32] for the scatter in the weight-gradient kernel
-            st4(dhw + DH_DC + p * 32 + 4 * q, dc[0]);
-            st4(dhw + DH_DC + p * 32 + 16 + 4 * q, dc[1]);
+        if (want_g) {
+            if constexpr (SCAT) {       // dC as [sample][32] in this wave's staging tiles (the dB^T fragments above have been read)
+                wave_lds_fence();
+                st4(stg + p * 32 + 4 * q, dc[0]);
+                st4(stg + p * 32 + 16 + 4 * q, dc[1]);
+                wave_lds_fence();
+                rec_prev = rec;
+                pend = true;
+            } else {                    // ... or in the workspace, for the scatter in the weight-gradient kernel
+                st4(dhw + DH_DC + p * 32 + 4 * q, dc[0]);
+                st4(dhw + DH_DC + p * 32 + 16 + 4 * q, dc[1]);
+            }
         }
         if (want_r && !handoff) {                                   // ray_grad_unit (raygrad.hpp) on this tile, in place
             const TileGeo G = tile_geo((int64_t)tile, A.ntl, 16 * A.ntl, A.ro, A.rd, A.z, p);
@@ -269,7 +341,12 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
             if (q != 0) { dpx = dpy = dpz = 0.f; }
             add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
         }
+        S2(6)       // hand-off, staging
     }
+
+    if (SCAT && pend) scatter_tile_rec(stg, rec_prev, A.ggrid[kind], lane);
+    S2(7)           // last tile's scatter
+    S2_FLUSH(0, wave, lane)
 
     // ---- dB^T: one flush of the workgroup's image
     wg_barrier_lds();
@@ -408,7 +485,7 @@ ENS_DEV void dw2_body(const BwdArgs& A, int kind, int wg, int n_wg, float* smem,
     for (int k = 0; k < NP; ++k) acc[k] = splat4(0.f);
 
     const DevGrid ggrid = A.ggrid[kind];
-    const bool want_g = ggrid.data != nullptr;
+    const bool want_g = ENS_SCATTER_WHERE == 0 && ggrid.data != nullptr;
     const float dscale = draw_scale_of(A);
     const int64_t n_items = work_count_u(A);
     const int64_t my_n = n_items > wg ? (n_items - wg + n_wg - 1) / n_wg : 0;      // items wg, wg + n_wg, ...
@@ -562,22 +639,30 @@ ENS_DEV void dw2_body(const BwdArgs& A, int kind, int wg, int n_wg, float* smem,
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::NFILL) : "memory");
         turn(0, IC(0));
         int t_cur = t0, t_nx1 = t1;                                 // tiles of items n and n + 1
+        S2_DECL
+        S2_START
         auto step = [&](int64_t n, auto par) {                      // par = n & 1: register set of item n + 1 is par ^ 1, of n + 2 par
             constexpr int PAR = decltype(par)::value;
             wg_barrier_lds();                                       // item n complete in LDS; everybody is done with item n - 1's stage
+            S2(0)   // barrier
             const int tile = t_next;
             t_next = item_tile(n + 3);
             const bool take = want_g && (int)(n & 7) == wave;
             if (want_g) scatter_loads(take, t_cur);
             fill(n + 2, tile, IC(PAR));
+            S2(1)   // fill issue
             compute(n);
             __builtin_amdgcn_sched_barrier(0);
+            S2(2)   // fragment reads + products
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::NFILL) : "memory");
+            S2(3)   // wait for the fill of item n + 1
             turn(n + 1, IC(PAR ^ 1));
+            S2(4)   // deposit tiles
             if (want_g) {
                 scatter_step();
                 if (take) scatter_take(t_cur);
             }
+            S2(5)   // scatter
             t_cur = t_nx1; t_nx1 = tile;
         };
         int64_t n = 0;
@@ -590,6 +675,8 @@ ENS_DEV void dw2_body(const BwdArgs& A, int kind, int wg, int n_wg, float* smem,
         if (want_g) {                                               // the tiles still in hand
             for (int k = 0; k < 8; ++k) { scatter_loads(false, 0); scatter_step(); }
         }
+        S2(6)       // drain
+        S2_FLUSH(1, wave, lane)
     }
 
     // ---- flush: owned tiles -> packed-layout LDS image (aliases the ring) -> float atomics / partial rows
@@ -645,6 +732,36 @@ __global__ __launch_bounds__(512, 1) void decoder_dw_kernel(BwdArgs A) {
     }
 }
 
+// The feature-gradient scatter as a launch of its own: one wave per (active tile, decoder).  The wave takes the tile's dC
+// ([sample][32], left by the chain kernel) and cell records into registers FIRST, then runs the scatter state machine
+// (scatter_piece, bwd_shared.hpp) and ends: nothing ever waits for an atomic, and the launch is as wide as the work list.
+__global__ __launch_bounds__(256) void decoder_scatter_kernel(BwdArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t item = unit / A.n_roles;
+    const int r = (int)(unit - item * A.n_roles);
+    if (item >= work_count_u(A)) return;
+    const int kind = A.role_kind[r];
+    const DevGrid gg = A.ggrid[kind];
+    if (gg.data == nullptr) return;
+    const int tile = work_tile_u(A, item);
+    const int64_t blk = (int64_t)tile * ACT_SLOTS + (kind - 1);
+    const f32x4 rec = ld4(A.act_ws + blk * ACT_STRIDE + ACT_VOX + (lane & 15) * 4);
+    const float* __restrict__ dcw = A.dh_ws + blk * DH_STRIDE + DH_DC + (lane & 31);
+    float val[16];
+#pragma unroll
+    for (int pt = 0; pt < 16; ++pt) val[pt] = dcw[pt * 32];
+    const float c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
+    const int ri = __builtin_bit_cast(int, c0), rx = __builtin_bit_cast(int, c1), ry = __builtin_bit_cast(int, c2), rz = __builtin_bit_cast(int, c3);
+    ScatterSt st;
+    st.acc[0] = st.acc[1] = st.acc[2] = st.acc[3] = 0.f; st.cur = 0u; st.open = false;
+    scatter_piece<0>(st, val, ri, rx, ry, rz, gg, lane);
+    scatter_piece<4>(st, val, ri, rx, ry, rz, gg, lane);
+    scatter_piece<8>(st, val, ri, rx, ry, rz, gg, lane);
+    scatter_piece<12>(st, val, ri, rx, ry, rz, gg, lane);
+    if (st.open) scatter_flush(st, gg, lane, 15, 0);
+}
+
 // workgroups of a launch over its roles: a workgroup takes `per` tiles per pass, so a role with m workgroups needs
 // ceil(groups / m) passes of relative cost c -- the split whose slowest role finishes first (as in render_bwd.hip)
 void split_roles(int total, int groups, const float* cs, int n, int* split) {
@@ -670,11 +787,19 @@ void split_roles(int total, int groups, const float* cs, int n, int* split) {
 
 }  // namespace
 
+#ifdef ENS_STAMPS
+extern "C" int enslam_debug_set_stamp_buffer2(void* p) {
+    unsigned long long* v = (unsigned long long*)p;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf2), &v, sizeof(v)) == hipSuccess ? 0 : -2;
+}
+#endif
+
 int ens_launch_decoder_bwd2(const BwdArgs& A0, const int* kinds, const float* costs, int n, int stage, int64_t n_tiles,
                             hipStream_t st) {
     if (n <= 0) return 0;
     if (A0.act_ws == nullptr || A0.act_light || A0.dh_ws == nullptr) return -1;
-    static bool attr_set = false;
+    static bool attr_done[ENS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[ens_device_ordinal()];
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds_bytes_chain2()) != hipSuccess ||
@@ -714,5 +839,18 @@ int ens_launch_decoder_bwd2(const BwdArgs& A0, const int* kinds, const float* co
     };
     const int r = launch(true);
     if (r != 0) return r;
+    if (ENS_SCATTER_WHERE == 2) {
+        bool any = false;
+        for (int i = 0; i < n; ++i) any = any || A0.ggrid[kinds[i]].data != nullptr;
+        if (any) {
+            BwdArgs B = A0;
+            B.n_roles = n;
+            for (int i = 0; i < n; ++i) B.role_kind[i] = kinds[i];
+            for (int i = n; i < 4; ++i) B.role_kind[i] = -1;
+            const int64_t units = n_tiles * n;
+            decoder_scatter_kernel<<<dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st>>>(B);
+            if (hipGetLastError() != hipSuccess) return -2;
+        }
+    }
     return launch(false);
 }

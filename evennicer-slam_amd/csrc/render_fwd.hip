@@ -1105,7 +1105,8 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
     if (ls != nullptr && tpr == 0) return -1;                 // the fused loss rides in the separate compositing launch
     int rc;
     if (tpr > 0 && stage >= 1 && stage <= 3) {
-        static bool attr_set = false;
+        static bool attr_done[ENS_MAX_DEVICES] = {};
+        bool& attr_set = attr_done[ens_device_ordinal()];
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_fwd_ring_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, fwd_ring_lds_bytes(1)) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(render_fwd_ring_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, fwd_ring_lds_bytes(2)) != hipSuccess ||
@@ -1116,24 +1117,22 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
         // large forward-only colour-stage batches: the weight-stationary kernel (ENSLAM_FWD_RES=0 / 1 forces the ring / resident form)
         static const int res_env = [] { const char* e = getenv("ENSLAM_FWD_RES"); return e ? atoi(e) : -1; }();
         if (stage == 3 && act_ws == nullptr && raw != nullptr && (res_env >= 0 ? res_env != 0 : n_units >= FWD_RES_MIN_TILES)) {
-            static bool res_attr = false;
+            static bool res_done[ENS_MAX_DEVICES] = {};
+            bool& res_attr = res_done[ens_device_ordinal()];
             if (!res_attr) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_fwd_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         fwd_res_lds_bytes()) != hipSuccess)
                     return -2;
                 res_attr = true;
             }
-            static const int cus_r = [] {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-                return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            }();
+            const int cus_r = ens_device_cus();
+            if (cus_r < 2) return -1;                                // (the two roles need a workgroup each)
             // occupancy decoders : colour decoder = 588 : 254 MFMAs per tile (70 : 30), but the colour role also carries a grid gather,
             // an embedding and the output stores per tile: two thirds of the workgroups for role 0 measured best (eval_points, 16 M
             // points: 160 / 170 / 179 / 188 / 196 of 256 -> 887 / 946 / 935 / 834 / 740 M points/s)
             static const int occ_env = [] { const char* e = getenv("ENSLAM_FWD_RES_OCC"); return e ? atoi(e) : 0; }();      // A/B aid
-            const int n_occ = (occ_env > 0 && occ_env < cus_r) ? occ_env : (cus_r * 2 + 1) / 3;
+            int n_occ = (occ_env > 0 && occ_env < cus_r) ? occ_env : (cus_r * 2 + 1) / 3;
+            n_occ = n_occ < 1 ? 1 : (n_occ > cus_r - 1 ? cus_r - 1 : n_occ);       // both roles get at least one workgroup
             render_fwd_res_kernel<<<dim3(cus_r), dim3(64 * FWD_RES_WAVES), fwd_res_lds_bytes(), st>>>(n_units, tpr, ro, rd, z, sc, raw, pts,
                                                                                                      n_points, apply_mask, n_occ);
             if (hipGetLastError() != hipSuccess) return -2;
@@ -1145,12 +1144,7 @@ int ens_launch_render_fwd(int stage, int ntl, int64_t n_units, const float* ro, 
         const int64_t groups = (n_units + 3) / 4;
         // colour stage: two roles per group of 4 tiles, interleaved in runs of 8 blocks (render_fwd_ring_kernel)
         const dim3 grid((unsigned)(fwd_split_roles(stage) ? ((groups + 7) / 8) * 16 : groups)), block(256);
-        static const int cus = [] {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-            return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }();
+        const int cus = ens_device_cus();
         const int stag = (ENS_FWD_STAGGER > 0 && !fwd_split_roles(stage) && grid.x <= (unsigned)(3 * cus)) ? cus : 0;
         if (stage == 1) render_fwd_ring_kernel<1><<<grid, block, fwd_ring_lds_bytes(1), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag, pts, n_points, apply_mask);
         else if (stage == 2) render_fwd_ring_kernel<2><<<grid, block, fwd_ring_lds_bytes(2), st>>>(n_units, tpr, ro, rd, z, sc, raw, act_ws, act_light, stag, pts, n_points, apply_mask);

@@ -382,6 +382,7 @@ class GraphedCameraIteration(object):
             trk.draws = None
         if self._draws is not None:
             self._draws[1].zero_()                       # (the warm-up iterations consumed rows)
+        self._steps_since_draw = 0
         # The captured iteration reads the device-side forms (voxel-major copies, packed decoders) of exactly these
         # objects: the graph owns them from here on (refresh_map copies a replaced map INTO them).
         self._map_c = {k: trk.c[k] for k in ('grid_middle', 'grid_fine', 'grid_color')}
@@ -392,6 +393,7 @@ class GraphedCameraIteration(object):
         self.gt_depth.copy_(gt_depth)
         if self._draws is not None:
             self.trk.draw_ahead(self.n_draws, self._draws[0].shape[1], out=self._draws)      # fresh pixels for the new frame
+        self._steps_since_draw = 0
         if self.event:
             for dst, src in zip(self.frame, self.trk.prepare_event_frame(gt_event, gt_mask, pre_gt_color, self.scale_factor)):
                 dst.copy_(src)
@@ -438,4 +440,11 @@ class GraphedCameraIteration(object):
         return refresh_in_place(trk.c, trk.decoders, 'color')
 
     def step(self):
+        # The captured iteration takes row `counter % n_draws` of the pixel indices drawn ahead: once every row has been used
+        # (more step() calls since set_frame() than n_draws) fresh rows are drawn -- one eager randint -- instead of silently
+        # reusing the same pixel batches.
+        if self._draws is not None and self._steps_since_draw >= self.n_draws:
+            self.trk.draw_ahead(self.n_draws, self._draws[0].shape[1], out=self._draws)
+            self._steps_since_draw = 0
+        self._steps_since_draw += 1
         return self.graph.replay()
