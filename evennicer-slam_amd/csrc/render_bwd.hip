@@ -1649,8 +1649,10 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
     const int groups = (int)((n_tiles + 3) / 4);
     // chain waves + dW waves (decoder_bwd_split_kernel) unless ENS_SPLIT=0 selects the 4-wave kernel (A/B aid)
     static const bool use_split = [] { const char* e = getenv("ENS_SPLIT"); return e == nullptr || e[0] != '0'; }();
-    // two-kernel form (render_bwd2.hip: dX-chain kernel + split-K weight-gradient kernel) unless ENS_BWD2=0 (A/B aid)
-    static const bool use_bwd2 = [] { const char* e = getenv("ENS_BWD2"); return e == nullptr || e[0] != '0'; }();
+    // ENS_BWD2=1: the two-kernel form (render_bwd2.hip: dX-chain kernel + split-K weight-gradient kernel).  Built and parity-
+    // tested in round 4, slower than the persistent kernel (the feature-gradient scatter's atomics need a
+    // kernel that lasts as long as they take to drain), so it stays an A/B aid.
+    static const bool use_bwd2 = [] { const char* e = getenv("ENS_BWD2"); return e != nullptr && e[0] == '1'; }();
     auto launch_subset = [&](const int* ks, const float* cs, int n, bool light) -> int {
         if (n == 0) return 0;
         int total = device_cus() * (light ? 2 : 1);

@@ -103,28 +103,146 @@ constexpr int C2_BP = 15360, C2_BT = 16896, C2_WFLOATS = 17280;
 constexpr int C2_IMG = 384;                         // gradient image of a workgroup: dB^T [96][4]
 constexpr int C2_WAVES = 12;                        // three per SIMD (<= 168 registers)
 constexpr int C2_WAVE_FLOATS = 6 * 256;             // per-wave scratch: 6 tiles d_arg deposit (tiles 0, 1 double as dC staging)
+// mode 3 (below): 8 chain waves + 4 scatter waves; per chain wave two hand-off buffers [dC 512 | cell records 64] behind its scratch
+constexpr int C2_CHAIN_WAVES_3 = 8;
+constexpr int C2_HAND = 512 + 64;
+constexpr int C2_WAVE_FLOATS_3 = 6 * 256 + C2_HAND;
+// ... and a WINDOW of the grid gradient in LDS: the 4 x 4 x 4 voxels around the origin of the workgroup's first ray.  Every ray of
+// a camera starts in the same cell, so the first samples of ALL rays add into the same few voxel rows: measured with the scatter
+// as a launch of its own, the tile next to the camera costs 62 of its 82 us (atomics on one address are served one after the
+// other at the memory side) and all other tiles together 14.5.  Adds into the 3 x 3 x 3 cells of the window go to LDS
+// (ds_add_f32) and leave the workgroup once, at its end: a hot row then receives one add per workgroup instead of one per ray.
+constexpr int C2_WIN = 64 * 32;
 // Where the feature-gradient scatter runs (A/B aid):
 //   2 = in a launch of its own between the two kernels (decoder_scatter_kernel: one wave per tile and decoder, values in
 //       registers, fire-and-forget atomics);
+//   3 = in the chain kernel by DEDICATED scatter waves: 8 chain waves + 4 scatter waves per workgroup; a chain wave hands a
+//       tile's dC and cell records over in LDS (two buffers, counters), a scatter wave serves two chain waves, reads only LDS
+//       and issues atomics -- it never has a load to wait for, so no atomic is ever waited for either;
 //   1 = in the chain kernel, the previous tile's scatter in four pieces in front of the backward layers 4..1 of the wave's next tile;
 //   0 = in the weight-gradient kernel, two samples per wave and step.
 // Measured (room0, 1000 rays, same box): 1 -> chain 47 -> 103 us (the scatter is ~1800 instructions per tile, as many as the
 // chain itself, and every wait for a load behind it waits for its atomics); 0 -> weight-gradient kernel 59 -> 102 us (its
 // barrier per item waits for the slowest wave's atomics).
 #ifndef ENS_SCATTER_WHERE
-#define ENS_SCATTER_WHERE 2
+#define ENS_SCATTER_WHERE 3
 #endif
-constexpr int lds_bytes_chain2() { return (C2_WFLOATS + C2_IMG + C2_WAVES * C2_WAVE_FLOATS) * 4; }
+constexpr int C2_SYNC = 32;                         // hand-off counters (ints): ready[8] | done[8]
+constexpr int lds_bytes_chain2() {
+    return ENS_SCATTER_WHERE == 3 ? (C2_WFLOATS + C2_IMG + C2_SYNC + C2_WIN + C2_CHAIN_WAVES_3 * C2_WAVE_FLOATS_3) * 4
+                                  : (C2_WFLOATS + C2_IMG + C2_WAVES * C2_WAVE_FLOATS) * 4;
+}
+ENS_DEV int lds_poll(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 
 // What the chain kernel leaves per (tile, decoder slot) for the weight-gradient kernel (DH_STRIDE floats): dh_i of the five
 // layers in register layout (tile 2 i + rt) and dC as [sample][32 channels] (tiles 10, 11), which that kernel scatters
 // into the grid gradient.
 constexpr int DH_DC = 10 * 256;
 
+// ---- the scatter state machine of bwd_shared.hpp with the LDS window
+struct GradWin { float* win; int lin0, W, HW; };          // window in LDS (null: none), linear index of its voxel (0,0,0), grid strides
+struct ScatterStW { float acc[4]; unsigned cur; bool open; int woff; };
+ENS_DEV int win_offset(unsigned cur, const GradWin& w) {  // float offset of cell `cur`'s corner voxel in the window, or -1 (all scalar)
+    if (w.win == nullptr) return -1;
+    const int d = (int)(cur & 0x1fffffffu) - w.lin0;
+    if (d < 0 || d >= 3 * w.HW) return -1;
+    const int dz = d >= 2 * w.HW ? 2 : (d >= w.HW ? 1 : 0);
+    const int r = d - dz * w.HW;
+    if (r >= 3 * w.W) return -1;
+    const int dy = r >= 2 * w.W ? 2 : (r >= w.W ? 1 : 0);
+    const int dx = r - dy * w.W;
+    if (dx >= 3) return -1;
+    return ((dz * 4 + dy) * 4 + dx) * 32;
+}
+ENS_DEV void scatter_flush_w(ScatterStW& st, const DevGrid& gg, const GradWin& w, int lane, int kmask, int half) {
+    const int ch = lane & 31, dxb = lane >> 5;
+    const int rowy = gg.W * 32, rowz = gg.H * gg.W * 32;
+    const unsigned cur = st.cur;
+    const bool okx = !dxb || (cur >> 29 & 1u), oky = cur >> 30 & 1u, okz = cur >> 31;
+    const bool mine = half == 0 || (half == 1) == (dxb == 0);
+    if (st.woff >= 0) {                                   // (wave-uniform) the whole cell lies in the window: LDS float atomics
+        float* base = w.win + st.woff + dxb * 32 + ch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!((kmask >> k) & 1)) continue;
+            if (mine && st.acc[k] != 0.f) lds_add(base + ((k >> 1) * 16 + (k & 1) * 4) * 32, st.acc[k]);
+            if (mine) st.acc[k] = 0.f;
+        }
+        return;
+    }
+    float* base = gg.data + (int64_t)(cur & 0x1fffffffu) * 32 + dxb * 32 + ch;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!((kmask >> k) & 1)) continue;
+        const bool ok = mine && okx && (!(k & 1) || oky) && (!(k >> 1) || okz);
+        if (ok && st.acc[k] != 0.f) atomicAdd(base + (k & 1) * rowy + (k >> 1) * rowz, st.acc[k]);
+        if (mine) st.acc[k] = 0.f;
+    }
+}
+template <int P0>
+ENS_DEV void scatter_piece_w(ScatterStW& st, const float (&val)[16], int ri, int rx, int ry, int rz, const DevGrid& gg,
+                             const GradWin& w, int lane) {
+    const int dxb = lane >> 5;
+    const int stepy = gg.W, stepz = gg.H * gg.W;
+#pragma unroll
+    for (int pt = P0; pt < P0 + 4; ++pt) {
+        const float v = val[pt];
+        if (!__any(v != 0.f)) continue;
+        const unsigned lin = (unsigned)__builtin_amdgcn_readlane(ri, pt);
+        const float fx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rx, pt));
+        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ry, pt));
+        const float fz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rz, pt));
+        if (!st.open) {
+            st.cur = lin; st.open = true; st.woff = win_offset(lin, w);
+        } else if (lin != st.cur) {                        // new cell: keep the partial sums of shared corner voxels (see scatter_tile_rec)
+            const unsigned cur = st.cur;
+            const int d = (int)(lin & 0x1fffffffu) - (int)(cur & 0x1fffffffu);
+            const int nwoff = win_offset(lin, w);
+            // (partial sums are carried over only between two cells on the same side of the window's edge)
+            const bool carry = (nwoff >= 0) == (st.woff >= 0);
+            if (carry && d == 1 && (cur >> 29 & 1u)) {
+                scatter_flush_w(st, gg, w, lane, 15, 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float o = __shfl_xor(st.acc[k], 32); st.acc[k] = dxb ? 0.f : o; }
+            } else if (carry && d == -1 && (lin >> 29 & 1u)) {
+                scatter_flush_w(st, gg, w, lane, 15, 2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float o = __shfl_xor(st.acc[k], 32); st.acc[k] = dxb ? o : 0.f; }
+            } else if (carry && d == stepy && (cur >> 30 & 1u)) {
+                scatter_flush_w(st, gg, w, lane, 5, 0);
+                st.acc[0] = st.acc[1]; st.acc[2] = st.acc[3]; st.acc[1] = 0.f; st.acc[3] = 0.f;
+            } else if (carry && d == -stepy && (lin >> 30 & 1u)) {
+                scatter_flush_w(st, gg, w, lane, 10, 0);
+                st.acc[1] = st.acc[0]; st.acc[3] = st.acc[2]; st.acc[0] = 0.f; st.acc[2] = 0.f;
+            } else if (carry && d == stepz && (cur >> 31)) {
+                scatter_flush_w(st, gg, w, lane, 3, 0);
+                st.acc[0] = st.acc[2]; st.acc[1] = st.acc[3]; st.acc[2] = 0.f; st.acc[3] = 0.f;
+            } else if (carry && d == -stepz && (lin >> 31)) {
+                scatter_flush_w(st, gg, w, lane, 12, 0);
+                st.acc[2] = st.acc[0]; st.acc[3] = st.acc[1]; st.acc[0] = 0.f; st.acc[1] = 0.f;
+            } else {
+                scatter_flush_w(st, gg, w, lane, 15, 0);
+            }
+            st.cur = lin;
+            st.woff = nwoff;
+        }
+        const float wx = dxb ? fx : (1.f - fx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float wt = (wx * ((k & 1) ? fy : (1.f - fy))) * ((k >> 1) ? fz : (1.f - fz));
+            st.acc[k] = fmaf(wt, v, st.acc[k]);
+        }
+    }
+}
+
 template <int CT, int NOUT>
 ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* smem) {
     constexpr XyzLay L{CT * 16};
-    constexpr int NW = C2_WAVES;
+    constexpr int NW = C2_WAVES;                                    // waves of the workgroup
+    constexpr bool HANDS = ENS_SCATTER_WHERE == 3;
+    constexpr int NCW = HANDS ? C2_CHAIN_WAVES_3 : C2_WAVES;        // ... of which run the chain
+    constexpr int WF = HANDS ? C2_WAVE_FLOATS_3 : C2_WAVE_FLOATS;
+    constexpr int SCR0 = C2_WFLOATS + C2_IMG + (HANDS ? C2_SYNC + C2_WIN : 0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = lane & 15, q = lane >> 4;
     const float* __restrict__ pk = A.sc.packed[kind];
     float* gpk = A.gpacked[kind];
@@ -146,15 +264,97 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         lds_fill<NW>(smem + C2_BP, pk + oBp, 16 * 96 / 4, wave, lane);
         lds_fill<NW>(smem + C2_BT, pk + oBT, 96, wave, lane);
     }
-    for (int e = threadIdx.x; e < C2_IMG; e += NW * 64) img[e] = 0.f;
+    for (int e = threadIdx.x; e < C2_IMG + (HANDS ? C2_SYNC + C2_WIN : 0); e += NW * 64) img[e] = 0.f;      // (counters and window follow the image)
+    int* const sync = reinterpret_cast<int*>(smem + C2_WFLOATS + C2_IMG);
     float woT[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) { constexpr int oWoT = L.oWoT(); woT[rt] = pk[oWoT + (16 * rt + p) * 4 + q]; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    const int64_t n_items = work_count_u(A);
+    // mode 3: a workgroup takes a CONTIGUOUS chunk of the work list (rays of one camera, mostly: the window sits at their origin),
+    // its chain wave w the items c0 + w, c0 + w + 8, ...; the other modes deal the items round-robin over all waves
+    const int64_t chunk = HANDS ? (n_items + n_wg - 1) / n_wg : 0;
+    const int64_t c0 = HANDS ? (int64_t)wg * chunk : (int64_t)wg * NCW;
+    const int64_t c1 = HANDS ? (c0 + chunk < n_items ? c0 + chunk : n_items) : n_items;
+    const int64_t stride = HANDS ? NCW : (int64_t)n_wg * NCW;
+    GradWin gw{nullptr, 0, A.ggrid[kind].W, A.ggrid[kind].H * A.ggrid[kind].W};
+    if constexpr (HANDS) {
+        if (want_g && c0 < c1) {                                    // the window: around the origin of the chunk's first ray
+            const int ray = work_tile_u(A, c0) / A.ntl;
+            const double o[3] = {(double)A.ro[ray * 3], (double)A.ro[ray * 3 + 1], (double)A.ro[ray * 3 + 2]};
+            const DevGrid g = A.sc.grid[kind];
+            const Vox v = make_vox(o, A.sc.lo, A.sc.hi, g);
+            const int wx0 = min(max(__builtin_amdgcn_readfirstlane(v.ix) - 1, 0), g.W - 4);
+            const int wy0 = min(max(__builtin_amdgcn_readfirstlane(v.iy) - 1, 0), g.H - 4);
+            const int wz0 = min(max(__builtin_amdgcn_readfirstlane(v.iz) - 1, 0), g.D - 4);
+            gw.win = smem + C2_WFLOATS + C2_IMG + C2_SYNC;
+            gw.lin0 = (wz0 * g.H + wy0) * g.W + wx0;
+        }
+    }
+    auto finish_wg = [&]() {                                        // every wave of the workgroup: dB^T image and the window leave
+        wg_barrier_lds();
+        for (int e = threadIdx.x; e < C2_IMG; e += NW * 64) {
+            const float v = img[e];
+            constexpr int oBT = L.oBT();
+            if (v != 0.f) atomicAdd(gpk + oBT + e, v);
+        }
+        if (HANDS && gw.win != nullptr) {
+            for (int e = threadIdx.x; e < C2_WIN; e += NW * 64) {
+                const float v = gw.win[e];
+                const int vox = e >> 5, dx = vox & 3, dy = (vox >> 2) & 3, dz = vox >> 4;
+                if (v != 0.f) atomicAdd(A.ggrid[kind].data + (int64_t)(gw.lin0 + dz * gw.HW + dy * gw.W + dx) * 32 + (e & 31), v);
+            }
+        }
+    };
+    if constexpr (HANDS) {
+        if (wave >= NCW) {
+            // ---- scatter wave: serves chain waves 2 s and 2 s + 1, tile by tile in their order; everything it reads comes from LDS
+            if (want_g) {
+                const int s0 = 2 * (wave - NCW);
+                const int ch = lane & 31;
+                int64_t cnt[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int64_t it0 = c0 + s0 + j;
+                    cnt[j] = it0 < c1 ? (c1 - it0 + stride - 1) / stride : 0;
+                }
+                const int64_t kmax = cnt[0] > cnt[1] ? cnt[0] : cnt[1];
+                for (int64_t k = 0; k < kmax; ++k) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (k >= cnt[j]) continue;
+                        const int w = s0 + j;
+                        for (int spin = 0; spin < (1 << 22) && lds_poll(sync + w) < (int)k + 1; ++spin) __builtin_amdgcn_s_sleep(4);
+                        asm volatile("" ::: "memory");
+                        const float* hb = smem + SCR0 + w * WF + 6 * 256;
+                        float val[16];
+#pragma unroll
+                        for (int pt = 0; pt < 16; ++pt) val[pt] = hb[pt * 32 + ch];
+                        const f32x4 rec = *reinterpret_cast<const f32x4*>(hb + 512 + p * 4);
+                        const float c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
+                        const int ri = __builtin_bit_cast(int, c0), rx = __builtin_bit_cast(int, c1), ry = __builtin_bit_cast(int, c2),
+                                  rz = __builtin_bit_cast(int, c3);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(sync + 8 + w, (int)k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // buffer free
+                        ScatterStW st;
+                        st.acc[0] = st.acc[1] = st.acc[2] = st.acc[3] = 0.f; st.cur = 0u; st.open = false; st.woff = -1;
+                        scatter_piece_w<0>(st, val, ri, rx, ry, rz, A.ggrid[kind], gw, lane);
+                        scatter_piece_w<4>(st, val, ri, rx, ry, rz, A.ggrid[kind], gw, lane);
+                        scatter_piece_w<8>(st, val, ri, rx, ry, rz, A.ggrid[kind], gw, lane);
+                        scatter_piece_w<12>(st, val, ri, rx, ry, rz, A.ggrid[kind], gw, lane);
+                        if (st.open) scatter_flush_w(st, A.ggrid[kind], gw, lane, 15, 0);
+                    }
+                }
+            }
+            finish_wg();
+            return;
+        }
+    }
+
     // ---- per-wave LDS bases
-    const unsigned scr = lds0 + (C2_WFLOATS + C2_IMG + wave * C2_WAVE_FLOATS) * 4;
+    const unsigned scr = lds0 + (SCR0 + wave * WF) * 4;
     unsigned dep[4];
     dep_bases(dep, scr, p, q);
     unsigned fbs = scr + frag_lane_off(lane);
@@ -165,8 +365,6 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
     unsigned wbt = lds0 + (C2_BT + p * 4 + q) * 4;
     opaque(wsw); opaque(wbp); opaque(wbt);
 
-    const int64_t n_items = work_count_u(A);
-    const int64_t stride = (int64_t)n_wg * NW;
     constexpr int WSQ = (14 + CT) * 256;
     const float dscale = draw_scale_of(A);
     const bool handoff = want_r && A.dgrid_ws != nullptr;
@@ -183,21 +381,23 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         mw_n = *reinterpret_cast<const uint2*>(w + ACT_MASK + lane * 2);
         if (q < 3) pc_n = w[WSQ + (p >> 2) * 64 + (q ^ (p >> 2)) * 4 + (p & 3)];      // coordinate q of sample p (swizzled tile)
         bq_n = ld4(w + WSQ + (lane ^ (lane >> 4)) * 4);             // the coordinates' fragment (dB^T operand), un-swizzled by address
-        if (SCAT && want_g) rec_n = ld4(w + ACT_VOX + p * 4);
+        if ((SCAT || HANDS) && want_g) rec_n = ld4(w + ACT_VOX + p * 4);
     };
-    float* const stg = smem + C2_WFLOATS + C2_IMG + wave * C2_WAVE_FLOATS;       // dC as [sample][32]: scratch tiles 0, 1
+    float* const stg = smem + SCR0 + wave * WF;                     // dC as [sample][32]: scratch tiles 0, 1
+    float* const hand = smem + SCR0 + wave * WF + 6 * 256;          // mode 3: the two hand-off buffers of this wave
+    int n_done = 0;                                                 // tiles of this wave so far
     f32x4 rec_prev = splat4(0.f);
     bool pend = false;
-    int64_t it = (int64_t)wg * NW + wave;
+    int64_t it = c0 + wave;
     int tile_cur = 0, tile_nxt = 0;                                 // work-list entries run two tiles ahead of their use
-    if (it < n_items) {
+    if (it < c1) {
         tile_cur = item_tile(it);
         tile_nxt = item_tile(it + stride);
         fetch(tile_cur);
     }
     S2_DECL
     S2_START
-    for (; it < n_items; it += stride) {
+    for (; it < c1; it += stride) {
         const int tile = tile_cur;
         tile_cur = tile_nxt;
         tile_nxt = item_tile(it + 2 * stride);
@@ -208,7 +408,7 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
         // the copies sink behind them, and the wait for the loads becomes a wait for float atomics issued a moment ago)
         asm volatile("" : "+v"(draw), "+v"(mw.x), "+v"(mw.y), "+v"(rec), "+v"(pc), "+v"(bq) :: "memory");
         S2(0)       // prefetched loads have arrived
-        if (it + stride < n_items) fetch(tile_cur);
+        if (it + stride < c1) fetch(tile_cur);
         ScatterSt sst;
         sst.acc[0] = sst.acc[1] = sst.acc[2] = sst.acc[3] = 0.f; sst.cur = 0u; sst.open = false;
         const float rp0 = rec_prev[0], rp1 = rec_prev[1], rp2 = rec_prev[2], rp3 = rec_prev[3];
@@ -317,7 +517,17 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
             st4(dgw + DG_DPE + lane * 4, dpe[0]);
         }
         if (want_g) {
-            if constexpr (SCAT) {       // dC as [sample][32] in this wave's staging tiles (the dB^T fragments above have been read)
+            if constexpr (HANDS) {      // dC as [sample][32] and the cell records into the hand-off buffer of this tile's parity
+                float* hb = hand;
+                // (its previous content, the tile before, has been taken)
+                for (int spin = 0; spin < (1 << 22) && lds_poll(sync + 8 + wave) < n_done; ++spin) __builtin_amdgcn_s_sleep(2);
+                asm volatile("" ::: "memory");
+                st4(hb + p * 32 + 4 * q, dc[0]);
+                st4(hb + p * 32 + 16 + 4 * q, dc[1]);
+                if (q == 0) st4(hb + 512 + p * 4, rec);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(sync + wave, n_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if constexpr (SCAT) {       // dC as [sample][32] in this wave's staging tiles (the dB^T fragments above have been read)
                 wave_lds_fence();
                 st4(stg + p * 32 + 4 * q, dc[0]);
                 st4(stg + p * 32 + 16 + 4 * q, dc[1]);
@@ -342,24 +552,23 @@ ENS_DEV void chain2_role(const BwdArgs& A, int kind, int wg, int n_wg, float* sm
             add_ray_grad(dpx, dpy, dpz, G.zf, G.ray, A.g_ro, A.g_rd, lane);
         }
         S2(6)       // hand-off, staging
+        ++n_done;
     }
 
     if (SCAT && pend) scatter_tile_rec(stg, rec_prev, A.ggrid[kind], lane);
     S2(7)           // last tile's scatter
     S2_FLUSH(0, wave, lane)
 
-    // ---- dB^T: one flush of the workgroup's image
-    wg_barrier_lds();
-    for (int e = threadIdx.x; e < C2_IMG; e += NW * 64) {
-        const float v = img[e];
-        constexpr int oBT = L.oBT();
-        if (v != 0.f) atomicAdd(gpk + oBT + e, v);
-    }
+    // ---- dB^T: one flush of the workgroup's image (and of the gradient window)
+    finish_wg();
 }
 
 extern __shared__ __attribute__((aligned(16))) float ens_smem2[];
 
 __global__ __launch_bounds__(C2_WAVES * 64, 1) void decoder_chain_kernel(BwdArgs A) {
+#if ENS_SCATTER_WHERE == 3
+    if (threadIdx.x < C2_CHAIN_WAVES_3 * 64) __builtin_amdgcn_s_setprio(1);     // chain waves first, scatter waves in their gaps
+#endif
     int role = 0;
 #pragma unroll
     for (int r = 1; r < 4; ++r) role = (r < A.n_roles && (int)blockIdx.x >= A.role_begin[r]) ? r : role;
@@ -745,6 +954,12 @@ __global__ __launch_bounds__(256) void decoder_scatter_kernel(BwdArgs A) {
     const DevGrid gg = A.ggrid[kind];
     if (gg.data == nullptr) return;
     const int tile = work_tile_u(A, item);
+#ifdef ENS_EXP_SKIP_NEAR            // timing experiment (wrong results): no scatter for the tile next to the camera
+    if (tile % A.ntl == 0) return;
+#endif
+#ifdef ENS_EXP_ONLY_NEAR            // timing experiment (wrong results): ONLY the tile next to the camera
+    if (tile % A.ntl != 0) return;
+#endif
     const int64_t blk = (int64_t)tile * ACT_SLOTS + (kind - 1);
     const f32x4 rec = ld4(A.act_ws + blk * ACT_STRIDE + ACT_VOX + (lane & 15) * 4);
     const float* __restrict__ dcw = A.dh_ws + blk * DH_STRIDE + DH_DC + (lane & 31);
@@ -819,7 +1034,7 @@ int ens_launch_decoder_bwd2(const BwdArgs& A0, const int* kinds, const float* co
     }
     (void)costs; (void)stage;
     auto launch = [&](bool chain) -> int {
-        const int per = chain ? C2_WAVES : 1;
+        const int per = chain ? (ENS_SCATTER_WHERE == 3 ? C2_CHAIN_WAVES_3 : C2_WAVES) : 1;
         const int groups = (int)((n_tiles + per - 1) / per);
         int total = cus;
         const int64_t max_useful = (int64_t)groups * n;

@@ -91,13 +91,16 @@ _capture = {'epoch': 0, 'active': 0, 'raw_writes': None, 'init_zero': None, 'per
 # blocks it fills to these flags: parallel.allreduce_gradients (the sums of the other ranks' blocks) does through
 # note_foreign_blocks().  Entries live as long as the GraphedStep that captured them (graph.GraphedStep.close / __del__).
 # An address alone does not identify a buffer (the allocator hands a freed address out again): an entry is
-# data_ptr -> (weak reference to the buffer tensor, flags), a look-up also compares the storage, and a graph that goes away
-# removes only the entries that are still its own (_persist_register / forget_persistent).
+# data_ptr -> (the buffer's STORAGE, flags).  The entry holds the storage (so its address cannot be handed out again while the
+# entry lives) but not the tensor: a second reference to the tensor would make AccumulateGrad clone the gradient instead of
+# adopting it, and the `.grad` that callers pass back in is a detached alias (another tensor object on the same storage)
+# anyway.  A look-up compares the storage; a graph that goes away removes only the entries that are still its own
+# (_persist_register / forget_persistent).
 _persist_prev = {}
 
 
 def _persist_register(g, pv):
-    _persist_prev[g.data_ptr()] = (weakref.ref(g), pv)
+    _persist_prev[g.data_ptr()] = (g.untyped_storage(), pv)
 
 
 def _capturing():
@@ -175,11 +178,8 @@ def note_foreign_blocks(grad, flags):
     e = _persist_prev.get(grad.data_ptr())
     if e is None:
         return False
-    g0, pv = e[0](), e[1]
-    if g0 is None:                              # the buffer this entry described is gone: the address now belongs to something else
-        del _persist_prev[grad.data_ptr()]
-        return False
-    if g0.untyped_storage()._cdata != grad.untyped_storage()._cdata:
+    st0, pv = e
+    if st0._cdata != grad.untyped_storage()._cdata:     # another buffer at the same address
         return False
     if pv.numel() == flags.numel():
         torch.maximum(pv, flags.reshape(pv.shape).to(pv.dtype), out=pv)

@@ -354,11 +354,19 @@ def make_room0():
     ro, rd, gd, gc = ref_common.get_samples(0, cam['H'], 0, cam['W'], 1000, cam['H'], cam['W'], cam['fx'],
                                             cam['fy'], cam['cx'], cam['cy'], c2w, depth_img, color_img, 'cpu')
     ro, rd, gd, gc = ro.float().contiguous(), rd.float().contiguous(), gd.float(), gc.float()
-    out, _ = run_stage(renderer, model, c, bound, ro, rd, gd, 'color', None, mapper_loss_gt=(gd, gc))
+    out, pts = run_stage(renderer, model, c, bound, ro, rd, gd, 'color', None, mapper_loss_gt=(gd, gc))
     keep = {k: out[k] for k in ('depth', 'var', 'color', 'z_vals', 'loss', 'g_rays_o', 'g_rays_d')}
     for k, v in out.items():
         if k.startswith('gp_'):
             keep[k] = v
+    # (round 4) point-level parity at the headline scene's size as well, as make_golden_scenes.py keeps it for office0 / recording4:
+    # decoder outputs and bound mask of the first 256 rays, their samples' voxel indices / fractions in the three grids
+    keep['raw_256'] = out['raw'].reshape(1000, -1, 4)[:256].copy()
+    keep['mask_256'] = out['mask'].reshape(1000, -1)[:256].copy()
+    p256 = pts[:256 * out['z_vals'].shape[1]]
+    for key in ('grid_middle', 'grid_fine', 'grid_color'):
+        for kk, vv in voxel_index(p256, bound, c[key].shape[2:]).items():
+            keep[f'vox_{key}_{kk}'] = vv
     rng = np.random.RandomState(0)
     for key in ('grid_middle', 'grid_fine', 'grid_color'):
         gg = out['g_' + key].reshape(-1)
@@ -371,7 +379,7 @@ def make_room0():
         keep[f'gidx_{key}'] = pick.astype(np.int64)
         keep[f'gval_{key}'] = gg[pick]
     keep.update(rays_o=ro.numpy(), rays_d=rd.numpy(), gt_depth=gd.numpy(), gt_color=gc.numpy(), **meta)
-    np.savez(os.path.join(HERE, 'room0_color1000.npz'), **keep)
+    np.savez_compressed(os.path.join(HERE, 'room0_color1000.npz'), **keep)
     print('room0 color1000 loss', out['loss'],
           'nonzero frac', [keep[f'gstat_{k}'][2] / keep[f'gstat_{k}'][3] for k in ('grid_middle', 'grid_fine', 'grid_color')])
 
@@ -433,6 +441,9 @@ def make_bounds():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'room0':       # only the two room0 fixtures (self-seeded: torch.manual_seed(0) inside)
+        make_room0()
+        sys.exit(0)
     make_bounds()
     make_ray_fixtures()
     make_tiny()
