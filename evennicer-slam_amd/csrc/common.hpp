@@ -348,21 +348,11 @@ ENS_DEV void ens_sincosf(float x, float& s, float& c) {
     c = ((n + 1) & 2) ? -cc : cc;
 }
 // sin alone: the same reduction and the same two polynomials, but only the one the quadrant selects is evaluated
-// (coefficients chosen by n & 1) -- bit-identical to the s of ens_sincosf.
-#ifdef ENS_HW_SINCOS
-// A/B aid (round 3): the hardware's v_sin_f32 / v_cos_f32 (argument in revolutions) behind a Cody-Waite reduction by 2*pi
-// (6.28125 has 8 significant bits: k * 6.28125 is exact for |k| < 2^16).  7 vector instructions instead of ~20, but 3.9e-7 / 3.5e-7
-// maximum absolute error for |x| <= 4000 against 9e-8 of the polynomial form (build/exp/vsin_test.hip, measured on gfx950).
-ENS_DEV float ens_red_rev(float x) {
-    const float k = rintf(x * 0.15915494309189535f);
-    float r = fmaf(-k, 6.28125f, x);
-    r = fmaf(-k, 1.9350051879882812e-3f, r);
-    r = fmaf(-k, 3.0199159819567529e-7f, r);
-    return r * 0.15915494309189535f;
-}
-ENS_DEV float ens_sinf(float x) { return __builtin_amdgcn_sinf(ens_red_rev(x)); }
-ENS_DEV float ens_cosf(float x) { return __builtin_amdgcn_cosf(ens_red_rev(x)); }
-#else
+// (coefficients chosen by n & 1) -- bit-identical to the s of ens_sincosf.  The FORWARD's sine stays this polynomial form
+// (9e-8 of float64): its values decide the ReLU masks of layer 0 and 3, and an implementation that strays 4x further from the
+// reference's torch.sin flips more pre-activations that sit within rounding of zero -- the outputs do not notice, but the
+// gradient of that sample jumps (measured in round 4 with the hardware sine in the forward: recording4 fixture, ONE ray of
+// 1000 with a ray-gradient error of 1.9e-2 of the maximum, every rendered output still within 2.5e-6).
 ENS_DEV float ens_sinf(float x) {
     int n;
     const float r = ens_reduce_pio2(x, n);
@@ -375,7 +365,22 @@ ENS_DEV float ens_sinf(float x) {
     const float v = fmaf(t, odd ? z : r, odd ? fmaf(-0.5f, z, 1.f) : r);
     return (n & 2) ? -v : v;
 }
-// cos alone, same scheme (the backward's d sin(x)/dx)
+#ifndef ENS_POLY_SINCOS
+// cos alone (the BACKWARD's d sin(x)/dx), default since round 4: the hardware's v_cos_f32 (argument in revolutions) behind a
+// Cody-Waite reduction by 2*pi (6.28125 has 8 significant bits: k * 6.28125 is exact for |k| < 2^16).  7 vector instructions
+// instead of ~20; 3.5e-7 maximum absolute error for |x| <= 4000 against 9e-8 of the polynomial form (measured on gfx950).  The
+// factor enters d_arg = d_emb * cos(arg) smoothly (no mask depends on it): gradients move by ~3e-7 relative.
+// -DENS_POLY_SINCOS restores the polynomial (A/B aid; profiles/r04_sincos_errors.txt holds both).
+ENS_DEV float ens_red_rev(float x) {
+    const float k = rintf(x * 0.15915494309189535f);
+    float r = fmaf(-k, 6.28125f, x);
+    r = fmaf(-k, 1.9350051879882812e-3f, r);
+    r = fmaf(-k, 3.0199159819567529e-7f, r);
+    return r * 0.15915494309189535f;
+}
+ENS_DEV float ens_cosf(float x) { return __builtin_amdgcn_cosf(ens_red_rev(x)); }
+#else
+// cos alone, same scheme as ens_sinf
 ENS_DEV float ens_cosf(float x) {
     int n;
     const float r = ens_reduce_pio2(x, n);

@@ -205,6 +205,64 @@ def test_large_batch_forward_kernel_feeds_the_same_backward():
     assert 'WORST' in r.stdout
 
 
+def test_two_kernel_backward_matches_the_reference_fixtures():
+    """ENS_BWD2=1: the two-kernel form of the saved-activation backward (csrc/render_bwd2.hip: dX-chain kernel with dedicated
+    scatter waves + split-K weight-gradient kernel) against the reference-generated fixtures -- the tiny colour scene (all
+    gradients) and room0 at 1000 x 48 (outputs, ray gradients, every decoder parameter, sampled grid-gradient entries), the
+    latter also through the graphed bench step.  The switch is read once per process: a child process."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, types, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench, evennicer_slam_amd as E\n"
+        "from tests.util import load, rel_err, GRID_KEYS\n"
+        "from tests.hip_util import tiny_on_gpu\n"
+        "s, bound, model, grids, rays, renderer = tiny_on_gpu()\n"
+        "g = load('tiny_color_mapperloss')\n"
+        "cg = {k: v.clone().requires_grad_(True) for k, v in grids.items()}\n"
+        "ro = rays['rays_o'].clone().requires_grad_(True); rd = rays['rays_d'].clone().requires_grad_(True)\n"
+        "d, v, c = renderer.render_batch_ray(cg, model, rd, ro, 'cuda:0', 'color', gt_depth=rays['gt_depth'])\n"
+        "m = rays['gt_depth'] > 0\n"
+        "(torch.abs(rays['gt_depth'][m] - d[m]).sum() + 0.2 * torch.abs(rays['gt_color'] - c).sum()).backward()\n"
+        "w = max(rel_err(cg[k].grad.cpu().numpy(), g['g_' + k]) for k in GRID_KEYS if 'g_' + k in g)\n"
+        "w = max(w, rel_err(rd.grad.cpu().numpy(), g['g_rays_d']), rel_err(ro.grad.cpu().numpy(), g['g_rays_o']))\n"
+        "w = max([w] + [rel_err(p.grad.cpu().numpy(), g['gp_' + n]) for n, p in model.named_parameters()\n"
+        "               if 'gp_' + n in g and np.abs(g['gp_' + n]).max() > 0])\n"
+        "print('WORST tiny', w)\n"
+        "assert w <= 1e-3\n"
+        "dev = torch.device('cuda', 0)\n"
+        "sc = bench.build_scene_cpu('room0', 0)\n"
+        "g = load('room0_color1000')\n"
+        "model = sc['model'].to(dev); bench.attach_bounds(model, sc['bound'])\n"
+        "renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **bench.CAM))\n"
+        "t = lambda k: torch.from_numpy(g[k]).to(dev)\n"
+        "for layout in ('contiguous', 'channels_last_3d'):\n"
+        "    cg = {k: (v.to(dev).contiguous(memory_format=torch.channels_last_3d) if layout != 'contiguous' else v.to(dev)).requires_grad_(True)\n"
+        "          for k, v in sc['grids'].items()}\n"
+        "    for p in model.parameters(): p.grad = None\n"
+        "    ro = t('rays_o').requires_grad_(True); rd = t('rays_d').requires_grad_(True)\n"
+        "    gd, gc = t('gt_depth'), t('gt_color')\n"
+        "    d, v, c = renderer.render_batch_ray(cg, model, rd, ro, dev, 'color', gt_depth=gd)\n"
+        "    bench.mapper_loss(d, c, gd, gc, 'color').backward()\n"
+        "    w = max(rel_err(rd.grad.cpu().numpy(), g['g_rays_d']), rel_err(ro.grad.cpu().numpy(), g['g_rays_o']))\n"
+        "    w = max([w] + [rel_err(p.grad.cpu().numpy(), g['gp_' + n]) for n, p in model.named_parameters()\n"
+        "                   if 'gp_' + n in g and np.abs(g['gp_' + n]).max() > 0])\n"
+        "    for key in ('grid_middle', 'grid_fine', 'grid_color'):\n"
+        "        gg = cg[key].grad.contiguous().reshape(-1).cpu().numpy()\n"
+        "        ref = g['gval_' + key]\n"
+        "        w = max(w, float(np.abs(gg[g['gidx_' + key]] - ref).max() / np.abs(ref).max()))\n"
+        "        st = g['gstat_' + key]\n"
+        "        assert abs(gg.astype(np.float64).sum() - st[0]) <= 1e-3 * st[1] and int(np.count_nonzero(gg)) <= st[2] * 1.001 + 8\n"
+        "    print('WORST room0', layout, w)\n"
+        "    assert w <= 1e-3\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ENS_BWD2='1')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert 'WORST room0 channels_last_3d' in r.stdout
+
+
 def test_weight_gradients_as_partial_images_match_the_atomic_path():
     """enslam_decoder_bwd_partials + enslam_step_finish_partials (per-workgroup partial images summed by the finish launch)
     against the default float-atomic accumulation, every decoder parameter of the colour stage."""

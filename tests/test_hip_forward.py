@@ -128,10 +128,12 @@ def test_room0_coarse200_config0():
 
 
 def test_fourier_embedding_large_arguments():
-    """The embedding's own sin / cos (float32 Cody-Waite reduction + minimax polynomials, csrc/common.hpp) against
-    float64 libm on the argument range of p @ B (B ~ 25 * randn, |p| up to ~10: a few thousand), at quadrant
-    boundaries and on huge / tiny / special arguments.  Bar: 2e-7 absolute (the outputs' 1e-4 budget is spent on the
-    float32 rounding of the argument itself, 1.2e-4 at |x| = 2000)."""
+    """The embedding's own sin (forward: float32 Cody-Waite reduction + minimax polynomials) and cos (backward: Cody-Waite
+    reduction by 2 pi + the hardware's v_cos_f32), csrc/common.hpp, against float64 libm on the argument range of p @ B
+    (B ~ 25 * randn, |p| up to ~10: a few thousand), at quadrant boundaries and on huge / tiny / special arguments.  Bars: sin
+    2e-7 absolute (measured 9e-8: its values decide ReLU masks, it stays as close to the reference's torch.sin as float32
+    allows), cos 1e-6 (measured 3.5e-7; it only scales d_arg).  The outputs' 1e-4 budget is spent on the float32 rounding of the
+    argument itself, 1.2e-4 at |x| = 2000."""
     import evennicer_slam_amd.functional as EF
     g = torch.Generator().manual_seed(3)
     x = torch.cat([
@@ -146,7 +148,7 @@ def test_fourier_embedding_large_arguments():
     es = (s.double().cpu() - torch.sin(xd)).abs()
     ec = (c.double().cpu() - torch.cos(xd)).abs()
     assert float(es.max()) < 2e-7, float(es.max())
-    assert float(ec.max()) < 2e-7, float(ec.max())
+    assert float(ec.max()) < 1e-6, float(ec.max())
     assert float(s[x == 0].abs().max()) == 0.0 and float((c[x == 0] - 1).abs().max()) == 0.0
     # the pair is consistent: sin^2 + cos^2 = 1 to float32 rounding
-    assert float((s.double() ** 2 + c.double() ** 2 - 1).abs().max()) < 5e-7
+    assert float((s.double() ** 2 + c.double() ** 2 - 1).abs().max()) < 2e-6
