@@ -177,8 +177,14 @@ ENS_DEV void scatter_tile_rec(const float* dep, const f32x4& rec, const DevGrid&
 
 ENS_DEV float draw_scale_of(const BwdArgs& A) { return A.draw_scale != nullptr ? (float)A.draw_scale[0] : 1.f; }
 // number of work items of the saved-activation roles and the tile behind item v (v < count)
-ENS_DEV int64_t work_count(const BwdArgs& A) { return A.work != nullptr ? (int64_t)A.n_work[0] : (int64_t)A.n_rays * A.ntl; }
-ENS_DEV int64_t work_tile(const BwdArgs& A, int64_t v) { return A.work != nullptr ? (int64_t)A.work[v] : v; }
+// Wave-uniform look-ups of the work list go through the scalar cache (a load from the constant address space: s_load_dword,
+// tracked by lgkmcnt).  As a vector load the look-up needs a vmcnt(0) before its value can steer the next loads -- which also
+// drains every LDS-DMA transfer, store and float atomic the wave has in flight.  The list is written by an earlier launch;
+// nothing in these kernels writes it.
+typedef __attribute__((address_space(4))) const int ens_cint;
+ENS_DEV int uload(const int* p) { return *reinterpret_cast<ens_cint*>(reinterpret_cast<uintptr_t>(p)); }
+ENS_DEV int64_t work_count(const BwdArgs& A) { return A.work != nullptr ? (int64_t)uload(A.n_work) : (int64_t)A.n_rays * A.ntl; }
+ENS_DEV int64_t work_tile(const BwdArgs& A, int64_t v) { return A.work != nullptr ? (int64_t)uload(A.work + v) : v; }
 
 
 // The same scatter as a resumable state machine: the dW waves of decoder_bwd_split_kernel run it in four 4-sample pieces

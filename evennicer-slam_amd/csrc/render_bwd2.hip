@@ -79,12 +79,6 @@ ENS_DEV void lin_lds_swz_rows(f32x4 (&acc)[NTOT], unsigned base_even, unsigned o
         }
     }
 }
-// Wave-uniform look-ups of the work list go through the scalar cache (a load from the constant address space: s_load_dword,
-// tracked by lgkmcnt).  As a vector load the look-up needs a vmcnt(0) before its value can steer the next loads -- which
-// also drains every LDS-DMA transfer, store and float atomic the wave has in flight.  The list is written by an earlier
-// launch; nothing in these kernels writes it.
-typedef __attribute__((address_space(4))) const int ens_cint;
-ENS_DEV int uload(const int* p) { return *reinterpret_cast<ens_cint*>(reinterpret_cast<uintptr_t>(p)); }
 ENS_DEV int64_t work_count_u(const BwdArgs& A) { return A.work != nullptr ? (int64_t)uload(A.n_work) : (int64_t)A.n_rays * A.ntl; }
 ENS_DEV int work_tile_u(const BwdArgs& A, int64_t v) { return A.work != nullptr ? uload(A.work + v) : (int)v; }
 
