@@ -37,6 +37,34 @@ def engine_on_calling_thread():
     return torch.autograd.set_multithreading_enabled(False)
 
 
+# ---- tensors another PROCESS writes ---------------------------------------------------------------------------------
+# The cached device-side forms (voxel-major copies of contiguous grids, packed decoders) are keyed on (tensor identity,
+# _version).  `_version` is a counter of THIS process's tensor object: an in-place update made by another process on the same
+# device memory (the reference shares its map and decoders between three processes over CUDA IPC: EvenNICER_SLAM.py:75-95,
+# 313-332) does not move it.  The reference's own flow never renders such memory directly -- the tracker clones the map and
+# deep-copies the decoders every frame (Tracker.py:248-260), the mappers render the tensors they themselves update
+# (Mapper.py:633-641) -- and is safe as it stands.  A caller that DOES render straight from memory another process writes
+# declares it: `external_writers(True)` (or ENSLAM_EXTERNAL_WRITERS=1) makes every version-keyed cache miss, so each call
+# re-converts the touched blocks and re-packs the decoders from what the memory holds now (channels_last_3d grids are read in
+# place and are current either way).  tests/test_hip_multiprocess.py exercises all of it across spawned processes.
+_external = [os.environ.get('ENSLAM_EXTERNAL_WRITERS') == '1', 0]
+
+
+def external_writers(on=True):
+    """Declare that tensors handed to the renderer may be modified in place by other processes (see above); returns the
+    previous setting."""
+    prev, _external[0] = _external[0], bool(on)
+    return prev
+
+
+def _ver(t):
+    """Version of tensor t for cache keys: its `_version`, or -- with external writers declared -- a value no cache has seen."""
+    if _external[0]:
+        _external[1] += 1
+        return -_external[1]
+    return t._version
+
+
 def _live_grid_guard(grids):
     """[(grid, version)] of the channels_last_3d grids a render call reads IN PLACE: its backward reads the same storage again
     (corner re-gather of the ray gradients, the recompute route), through a detached alias autograd does not version-check."""
@@ -397,11 +425,11 @@ def _params_key(cache, ps):
     if prev is not None and len(prev) == len(ps) and all(a is b for a, b in zip(prev, ps)):
         ptrs = tuple(p.data_ptr() for p in ps)
         if ptrs == cache.ptrs_seen:
-            return (cache.ids_seen, ptrs, tuple(p._version for p in ps))
+            return (cache.ids_seen, ptrs, tuple(_ver(p) for p in ps))
     cache.ps_seen = list(ps)
     cache.ids_seen = tuple(id(p) for p in ps)
     cache.ptrs_seen = tuple(p.data_ptr() for p in ps)
-    return (cache.ids_seen, cache.ptrs_seen, tuple(p._version for p in ps))
+    return (cache.ids_seen, cache.ptrs_seen, tuple(_ver(p) for p in ps))
 
 
 def packed_decoders(items, arena=None, defer=False):
@@ -525,7 +553,7 @@ class _GridCache:
 
     def _lookup(self, g, sparse):
         e = self.items.get(id(g))
-        if e is not None and e.ref() is g and e.version == g._version and (e.valid is not None) == sparse and _tag_visible(e.tag):
+        if e is not None and e.ref() is g and e.version == _ver(g) and (e.valid is not None) == sparse and _tag_visible(e.tag):
             return e
         return None
 
