@@ -287,3 +287,68 @@ def test_two_rank_graph_replay_with_allreduce_keeps_foreign_blocks_clean(layout)
             for a, b in zip(o['grads'][it], want):
                 assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30), (it, o['rank'])
                 assert np.array_equal(a == 0, b == 0) or np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30)
+
+
+def _pose_hip_step(sharded):
+    """A bundle-adjustment batch on the HIP path: rays of two frames from their camera tensors (tracker.get_samples_from_camera_tensor:
+    the fused pose -> ray launch), colour-stage render, mapper loss, backward to grids, colour decoder and BOTH camera tensors."""
+    import evennicer_slam_amd as E
+    from evennicer_slam_amd import parallel as PAR
+    from evennicer_slam_amd.tracker import get_samples_from_camera_tensor
+    from tests.hip_util import DEV, tiny_on_gpu
+    s, bound, model, grids, rays, renderer = tiny_on_gpu()
+    g = {k: v.detach().clone().requires_grad_(True) for k, v in grids.items()}
+    H, W, fx, fy, cx, cy = 48, 64, 50.0, 50.0, 31.5, 23.5
+    gen = torch.Generator().manual_seed(4)
+    depth_img = (torch.rand(H, W, generator=gen) * 0.8 + 0.4).to(DEV)
+    color_img = torch.rand(H, W, 3, generator=gen).to(DEV)
+    cams = [torch.tensor([1.0, 0.02, -0.03, 0.01, 0.1, -0.05, 0.2], device=DEV).requires_grad_(True),
+            torch.tensor([0.98, -0.05, 0.04, 0.02, 0.12, -0.02, 0.18], device=DEV).requires_grad_(True)]
+    torch.manual_seed(11)                                            # (every rank draws the same pixels: it holds the whole batch)
+    parts = [get_samples_from_camera_tensor(0, H, 0, W, 32, H, W, fx, fy, cx, cy, ct, depth_img, color_img, DEV) for ct in cams]
+    ro, rd, gd, gc = (torch.cat([p[i].float() for p in parts]) for i in range(4))
+    leaves = [g[k] for k in ('grid_middle', 'grid_fine', 'grid_color')] + list(model.color_decoder.parameters()) + cams
+    if sharded:
+        (depth, var, color), sl = PAR.ShardedRenderer(renderer).render_batch_ray(g, model, rd, ro, DEV, 'color', gt_depth=gd)
+        E.losses.rgbd_loss(depth, color, gd[sl], gc[sl], 0.2).backward()
+        PAR.allreduce_gradients(leaves)
+    else:
+        depth, var, color = renderer.render_batch_ray(g, model, rd, ro, DEV, 'color', gt_depth=gd)
+        E.losses.rgbd_loss(depth, color, gd, gc, 0.2).backward()
+    torch.cuda.synchronize()
+    return [t.grad.cpu().numpy() for t in leaves]
+
+
+def _pose_hip_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        q.put({'rank': rank, 'grads': _pose_hip_step(True)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_pose_gradients_on_hip_match_unsharded():
+    """north_star: "RCCL all-reduce of grid / MLP / pose gradients" -- the camera tensors of a BA batch in the bucket's small-tensor
+    section: rank 0 renders frame 0's rays, rank 1 frame 1's; after ONE bucketed all-reduce every rank holds the unsharded
+    gradient of both camera tensors (and of the grids and the colour decoder)."""
+    import torch.multiprocessing as mp
+    world, port = 2, 41500 + (os.getpid() % 2000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pose_hip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=600) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = _pose_hip_step(False)
+    assert np.abs(want[-1]).max() > 0 and np.abs(want[-2]).max() > 0
+    for o in outs:
+        for a, b in zip(o['grads'], want):
+            assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30)
+    for a, b in zip(outs[0]['grads'], outs[1]['grads']):
+        assert np.array_equal(a, b)                         # replicas hold identical sums

@@ -243,3 +243,70 @@ def test_sharded_step_with_ray_counts_not_divisible_by_the_world_size(world, n_r
         ref = params['color_decoder.pts_linears.0.weight'].grad.numpy()
         assert np.abs(o['g_w'] - ref).max() <= 1e-5 * np.abs(ref).max()
         assert np.array_equal(o['g_fine'], outs[0]['g_fine'])          # replicas hold identical sums
+
+
+def _pose_worker(rank, world, port, q):
+    """Rays of TWO frames from their camera tensors (a bundle-adjustment batch: Mapper.py:374-390, 502-535), every rank holding
+    the whole batch, rendering its shard; the camera tensors travel in the bucket's small-tensor section."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from evennicer_slam_amd.parallel import ShardedRenderer, allreduce_gradients
+        q.put(dict(rank=rank, **_pose_step(lambda r: ShardedRenderer(r), allreduce_gradients)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _pose_step(wrap, allreduce):
+    from oracle import render_oracle as R
+    from oracle import tracker_oracle as TO
+    params, grids, bound, s = tiny_scene()
+    params = {k: v.requires_grad_(True) for k, v in params.items()}
+    grids = {k: v.requires_grad_(True) for k, v in grids.items()}
+    H, W, fx, fy, cx, cy = 48, 64, 50.0, 50.0, 31.5, 23.5
+    g = torch.Generator().manual_seed(4)
+    depth_img = torch.rand(H, W, generator=g) * 0.8 + 0.4
+    color_img = torch.rand(H, W, 3, generator=g)
+    cams = [torch.tensor([1.0, 0.02, -0.03, 0.01, 0.1, -0.05, 0.2]).requires_grad_(True),
+            torch.tensor([0.98, -0.05, 0.04, 0.02, 0.12, -0.02, 0.18]).requires_grad_(True)]
+    ro, rd, gd, gc = [], [], [], []
+    for ct in cams:
+        idx = torch.randint(H * W, (20,), generator=g)
+        o, d, dep, col = R.sample_pixels(0, H, 0, W, 20, TO.camera_from_tensor(ct), depth_img, color_img, fx, fy, cx, cy, idx=idx)
+        ro.append(o); rd.append(d); gd.append(dep); gc.append(col)
+    ro, rd, gd, gc = torch.cat(ro), torch.cat(rd), torch.cat(gd), torch.cat(gc)
+    renderer = _OracleRenderer(params, bound)
+    leaves = [grids[k] for k in GRID_KEYS] + list(params.values()) + cams
+    if wrap is None:
+        depth, var, color = renderer.render_batch_ray(grids, None, rd, ro, 'cpu', 'color', gt_depth=gd)
+        R.mapper_loss(depth, color, gd, gc, 'color').backward()
+    else:
+        (depth, var, color), sl = wrap(renderer).render_batch_ray(grids, None, rd, ro, 'cpu', 'color', gt_depth=gd)
+        R.mapper_loss(depth, color, gd[sl], gc[sl], 'color').backward()
+        allreduce(leaves)
+    return dict(g_cam=[c.grad.numpy().copy() for c in cams], g_fine=grids['grid_fine'].grad.numpy().copy())
+
+
+def test_two_rank_sharded_pose_gradients_match_unsharded():
+    """north_star: "an RCCL all-reduce of grid / MLP / POSE gradients".  The camera tensors of a BA batch are leaves like any
+    other: each rank back-propagates its ray shard to them, the bucket sums them, every rank ends with the unsharded gradient."""
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pose_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _pose_step(None, None)
+    for o in outs:
+        for a, b in zip(o['g_cam'], ref['g_cam']):
+            assert np.abs(b).max() > 0
+            assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+        assert np.abs(o['g_fine'] - ref['g_fine']).max() <= 1e-5 * np.abs(ref['g_fine']).max()
+    # rank 0 renders frame 0's rays only, rank 1 frame 1's: before the all-reduce each rank held a gradient for ONE camera
+    assert all(np.array_equal(x, y) for x, y in zip(outs[0]['g_cam'], outs[1]['g_cam']))

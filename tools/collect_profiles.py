@@ -11,8 +11,8 @@ shutil.copy(os.path.join(O, 'timeline.txt'), os.path.join(P, f'{tag}_timeline_on
 pmc = json.load(open(os.path.join(O, 'pmc_summary.json')))
 json.dump(pmc, open(os.path.join(P, f'{tag}_pmc_summary.json'), 'w'), indent=1)
 out = {"_how": "tools/profile_round.sh on the GPU box: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum "
-               "(separate passes) -- python3 bench.py --steps 10 --warmup 3 --eager --no-secondary --no-cpu-baseline --no-kernel-events "
-               "(config 2 only); mean per dispatch; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads half of wide "
+               "(separate passes) -- python3 bench.py --steps 10 --warmup 3 --no-secondary --no-cpu-baseline --no-kernel-events --no-api "
+               "(config 2 only, the HEADLINE mode: hipGraph replays unless PMC_MODE=--eager was set); mean per dispatch; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads half of wide "
                f"coalesced fetches, MI355X_MICROARCH.md; WRITE_SIZE exact, float atomics included). Full counter set: {tag}_pmc_summary.json",
        "_commit": what}
 for k, v in pmc.items():
@@ -22,8 +22,11 @@ for k, v in pmc.items():
     out[name] = {"FETCH_SIZE_KB": v['FETCH_SIZE'], "WRITE_SIZE_KB": v['WRITE_SIZE'],
                  "bytes_per_launch": int((2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024),
                  "TCC_HIT_sum": v.get('TCC_HIT_sum'), "TCC_MISS_sum": v.get('TCC_MISS_sum'), "dispatches": v.get('dispatches')}
+mall = os.path.join(O, 'mall.txt')
+out["_infinity_cache"] = open(mall).read().strip() if os.path.exists(mall) else "not probed"
 json.dump(out, open(os.path.join(P, f'{tag}_traffic.json'), 'w'), indent=1)
 print(open(os.path.join(P, f'{tag}_timeline_one_replay.txt')).read())
 for k in out:
     if not k.startswith('_'):
         print(k, out[k]['bytes_per_launch'])
+print(out["_infinity_cache"])
