@@ -14,14 +14,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/eager -o e -- python3
 # Infinity-Cache (MALL) counters: whatever this rocprofv3 lists under that name gets a pass of its own; none listed = none exists.
 PMC_MODE=${PMC_MODE:-}
 rocprofv3 --list-avail > $O/avail.txt 2>&1 || true
-MALL=$(grep -o -i -E "[A-Z0-9_]*MALL[A-Z0-9_]*" $O/avail.txt | sort -u | head -4 | tr '\n' ' ')
-echo "MALL counters listed: ${MALL:-none}" > $O/mall.txt
+MALL=$(grep -o -E "\b[A-Z0-9_]*(MALL|INFINITY_CACHE|L3_HIT|L3_MISS)[A-Z0-9_]*\b" $O/avail.txt | sort -u | head -4 | tr '\n' ' ')
+echo "Infinity-Cache (MALL) counters in rocprofv3 --list-avail: ${MALL:-none (the TCC_EA0_RDREQ_DRAM / _GMI / _IO counters classify a request's DESTINATION, not its residency: a hit rate of the Infinity Cache cannot be read on this stack)}" > $O/mall.txt
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "$MALL"; do
   [ -z "$(echo $c | tr -d ' ')" ] && continue
   tag=$(echo $c | cut -d' ' -f1)
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o p -- python3 $R/bench.py --steps 10 --warmup 3 $PMC_MODE $ARGS > $O/pmc_$tag.log 2>&1 || echo "pass $tag failed" >> $O/mall.txt
 done
-python3 $R/tools/pmc_summary.py $O $O/pmc_summary.json > $O/pmc_summary.txt
+PMC_LAST=${PMC_LAST:-10} python3 $R/tools/pmc_summary.py $O $O/pmc_summary.json > $O/pmc_summary.txt
 python3 $R/tools/timeline.py $(find $O/graph -name 'g_kernel_trace.csv' | head -1) > $O/timeline.txt
 cat $O/timeline.txt
 cat $O/mall.txt
