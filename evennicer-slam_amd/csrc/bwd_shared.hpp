@@ -28,6 +28,8 @@ struct BwdArgs {
     int role_begin[5];       // workgroup ranges of the roles (decoder kinds) of this launch
     int role_kind[4];
     int n_roles;
+    int defer_mask;          // bit k: decoder kind k hands its feature gradient (dC) off through dgrid_ws instead of scattering it
+                             // (ens_launch_grid_scatter, grid_scatter.hip, follows the decoder launches)
 };
 // (render_bwd2.hip) the two-kernel form of the saved-activation backward for the roles of A (roles with parameter gradients)
 int ens_launch_decoder_bwd2(const BwdArgs& A, const int* kinds, const float* costs, int n, int stage, int64_t n_tiles, hipStream_t st);

@@ -1017,7 +1017,10 @@ int enslam_plan_layout(const enslam_step_plan* plan, enslam_step_layout* L) {
     if (plan->use_work_list) { L->s_work = o; o = plan_align(o + 4 * ntiles); }
     L->s_draw = o; o = plan_align(o + 16 * (int64_t)N * S);
     L->s_dgw = -1;
-    if (plan->need_rays && !L->inline_rays) { L->s_dgw = o; o = plan_align(o + 4 * (int64_t)enslam_grid_handoff_floats(plan->stage, N, S)); }
+    bool any_ggrid = false;                                                // ENSLAM_DEFER_SCATTER=1: the grid gradients' scatter reads the hand-off (grid_scatter.hip)
+    static const bool defer_on = [] { const char* e = getenv("ENSLAM_DEFER_SCATTER"); return e != nullptr && e[0] == '1'; }();
+    for (int k = 1; k < 4; ++k) any_ggrid = any_ggrid || (defer_on && plan->grid_mode[k] >= 2);
+    if ((plan->need_rays && !L->inline_rays) || any_ggrid) { L->s_dgw = o; o = plan_align(o + 4 * (int64_t)enslam_grid_handoff_floats(plan->stage, N, S)); }
     for (int k = 0; k < 4; ++k) {
         L->s_vm[k] = L->s_gacc[k] = -1;
         if (plan->grid_mode[k] == 3) {
@@ -1198,7 +1201,7 @@ int enslam_plan_backward(const enslam_step_plan* plan, const enslam_step_layout*
             g.Wo = pbase + off[j++]; g.bo = pbase + off[j++]; g.B = pbase + off[j++];
             ++npk;
         }
-    const bool ray_pending = dgw != nullptr;
+    const bool ray_pending = dgw != nullptr && plan->need_rays;
     if (nc == 0 && npk == 0 && !ray_pending) return ENSLAM_OK;
     return enslam_step_finish_native(nc, csrc, cdst, cvox, cneed, nullptr, npk, kinds, pk, parts, gs, plan->stage, ray_pending ? N : 0, S, rays_o,
                                      rays_d, z, &sc, ray_pending ? dgw : nullptr, p_ro, p_rd, work, wcount, nullptr, nullptr, 0, stream);

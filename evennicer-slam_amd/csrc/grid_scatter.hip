@@ -1,0 +1,391 @@
+// Feature-gradient scatter of the saved-activation backward as a launch of its own -- an EXPERIMENT of round 4, off by default
+// (ENSLAM_DEFER_SCATTER=1 selects it; DESIGN.md section 6.3 has the numbers and why it does not pay on gfx950).
+//
+// The decoder backward leaves d(loss)/d(interpolated feature) of every (tile, decoder) in the hand-off workspace the ray-gradient
+// role already reads (dgrid_ws: dC in register layout).  What is left is the transpose of the forward's trilinear gather
+// (Renderer.py:168-175 / common.py:342-357 through autograd: grid_sampler_3d_backward's scatter-add into the 8 corner voxels).
+// Inside the decoder kernels that is ~200 k float atomics of 256 B per 1000-ray step (50 MB at the chip-wide ~1.3 TB/s of
+// memory-side float atomics): 35 us of the persistent kernel's 135 (it runs in 100 us without them).
+//
+// Here the sums that share a destination are formed ON CHIP first:
+//   * the rays of a batch are ordered along a Morton curve (key: the cell, at 1/128 of the bound, of the point one tenth of
+//     the bound's extent along the ray), in chunks of 1024 -- every workgroup sorts the chunk of its group itself (bitonic:
+//     shuffles inside a wave, LDS across waves; no extra launch, no buffer, nothing for the host to provide);
+//   * one workgroup takes 16 consecutive rays of that order and ONE grid: neighbouring rays cross the same cells, so the
+//     ~6 000 corner contributions of the group fall on ~500 distinct voxel rows (tools/sim_scatter_merge.py) -- they are
+//     added into an LDS table of 576 rows x 32 channels (open addressing on the voxel index) and leave once per row:
+//     52 k row-adds (6.6 MB) per step instead of ~400 k (50 MB);
+//   * LDS float atomics are unusable for this (ds_add_f32: ~160 cycles per wave instruction on gfx950, measured; integer LDS
+//     atomics ~9): the table holds 64-bit FIXED-POINT sums (scale: a power of two from the group's largest |dC|; exact and
+//     order-independent above 2^-40 of that value, FLUSHED TO ZERO below it -- the one place where this path differs from
+//     float32 accumulation: gradient elements some 12 decades below the group's largest come out as exact zeros);
+//   * a row that finds no place in the table (8 probes) is added to the gradient directly, and a group that holds an inf / NaN
+//     adds everything directly -- correctness does not depend on the table's size or on the order of the rays.
+// Measured (1000 rays, room0): 57 us, of which 14.5 us launch + table clear + sort + flush scan, 10 us the units' loads,
+// geometry and probes, 32 us the adds -- the VALU work of 48 (tile, grid) units per CU (operand distribution, fixed-point
+// conversion, addresses: ~900 instructions each) on the 189 CUs the launch occupies.  The decoder kernel does the same
+// arithmetic in the issue slots its MFMA chains leave free.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "raygrad.hpp"
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GS_G = 16;                 // rays per workgroup
+constexpr int GS_CHUNK = 1024;           // rays ordered together
+constexpr int GS_ROWS = 576;             // table rows (the largest group of the bench scene needs 570)
+constexpr int GS_WAVES = 16;
+constexpr int GS_THREADS = GS_WAVES * 64;
+constexpr int GS_PROBES = 8;
+constexpr int GS_MAXU = 4;               // units per wave: GS_G * ntl / GS_WAVES, ntl <= 4
+constexpr unsigned GS_EMPTY = 0xFFFFFFFFu;
+static_assert(GS_CHUNK == GS_THREADS, "one key per thread");
+
+// LDS map (bytes)
+constexpr int GS_VALS = 0;                                   // [GS_ROWS + 1][32] int64 fixed point (row GS_ROWS: dummy, never read)
+constexpr int GS_KEYS = GS_VALS + (GS_ROWS + 1) * 256;       // [GS_ROWS] voxel row index or GS_EMPTY
+constexpr int GS_SORT = GS_KEYS + GS_ROWS * 4;               // sort keys [GS_CHUNK] u32
+constexpr int GS_RAYS = GS_SORT + GS_CHUNK * 4;              // [GS_G] ray of the group (-1: none)
+constexpr int GS_RED = GS_RAYS + 64;                         // [GS_WAVES] max |dC| per wave
+constexpr int GS_BYTES = GS_RED + 64;
+static_assert(GS_BYTES <= 160 * 1024, "LDS");
+static_assert(GS_ROWS % (2 * GS_WAVES) == 0 && GS_ROWS <= GS_THREADS, "flush / key init");
+
+struct ScatterArgs {
+    int n_rays, ntl, n_slots;
+    const float* ro;
+    const float* rd;
+    const double* z;
+    const float* dgrid_ws;       // [tile][ACT_SLOTS][DG_STRIDE]
+    const float* d_raw;          // [tile * 16][4]: tiles with all-zero d_raw were never handed off (work list); null: every tile was
+    double lo[3], hi[3];
+    float key_t;                 // ray parameter of the key point
+    DevGrid ggrid[3];            // gradient of slot 0..2 (voxel-major; data null: nothing to scatter)
+    int slot_of[3];              // slots with a gradient, in workgroup order
+    int n_active_slots;
+};
+
+ENS_DEV unsigned spread7(unsigned x) {           // 7 bits -> every third bit
+    x &= 0x7fu;
+    x = (x | (x << 8)) & 0x0000700fu;
+    x = (x | (x << 4)) & 0x000430c3u;
+    x = (x | (x << 2)) & 0x00049249u;
+    return x;
+}
+
+constexpr double GS_MAGIC = 6755399441055744.0;          // 1.5 * 2^52: (double)(x * S) + MAGIC has the integer in its low mantissa bits
+
+__global__ __launch_bounds__(GS_THREADS) void grid_scatter_kernel(ScatterArgs A) {
+    extern __shared__ __align__(16) unsigned char gs_lds[];
+    unsigned long long* vals = reinterpret_cast<unsigned long long*>(gs_lds + GS_VALS);
+    unsigned* keys = reinterpret_cast<unsigned*>(gs_lds + GS_KEYS);
+    int* rays = reinterpret_cast<int*>(gs_lds + GS_RAYS);
+    float* red = reinterpret_cast<float*>(gs_lds + GS_RED);
+    unsigned* skey = reinterpret_cast<unsigned*>(gs_lds + GS_SORT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_groups = (A.n_rays + GS_G - 1) / GS_G;
+    const int group = blockIdx.x % n_groups, slot = A.slot_of[blockIdx.x / n_groups];
+    const DevGrid gg = A.ggrid[slot];
+    const int chunk = group / (GS_CHUNK / GS_G);
+    const int r0 = chunk * GS_CHUNK;
+    const int n_chunk = min(GS_CHUNK, A.n_rays - r0);
+
+    // ---- A. empty table; Morton key of the chunk's ray `tid` (21 bits of cell, 10 bits of index); bitonic sort: element i's partner at
+    //         distance j is i ^ j -- lane ^ j inside a wave (shuffle), another wave's element through LDS for j >= 64
+#pragma unroll
+    for (int i = 0; i < (GS_ROWS + 1) * 256 / 16 / GS_THREADS; ++i)
+        reinterpret_cast<f32x4*>(gs_lds + GS_VALS)[i * GS_THREADS + tid] = splat4(0.f);
+    if (tid < ((GS_ROWS + 1) * 256 / 16) % GS_THREADS)
+        reinterpret_cast<f32x4*>(gs_lds + GS_VALS)[((GS_ROWS + 1) * 256 / 16 / GS_THREADS) * GS_THREADS + tid] = splat4(0.f);
+    if (tid < GS_ROWS) keys[tid] = GS_EMPTY;
+    unsigned e0 = 0xFFFFFFFFu;
+    if (tid < n_chunk) {
+        const int r = r0 + tid;
+        unsigned m = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float pa = A.ro[r * 3 + a] + A.rd[r * 3 + a] * A.key_t;
+            float u = (pa - (float)A.lo[a]) / (float)(A.hi[a] - A.lo[a]);
+            u = u >= 0.f ? u : 0.f;                                           // (NaN -> 0)
+            u = u <= 0.999f ? u : 0.999f;
+            m |= spread7((unsigned)(u * 128.f)) << a;
+        }
+        e0 = (m << 10) | (unsigned)tid;
+    }
+#ifndef ENS_EXP_GS_NOSORT
+    if (n_chunk > GS_G) {
+        for (int k = 2; k <= GS_CHUNK; k <<= 1) {
+            const bool up = (tid & k) == 0;
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                unsigned o;
+                if (j < 64) {
+                    o = __shfl_xor(e0, j);
+                } else {
+                    __syncthreads();                                          // (the previous LDS stage's readers are done)
+                    skey[tid] = e0;
+                    __syncthreads();
+                    o = skey[tid ^ j];
+                }
+                const bool low = (tid & j) == 0;                              // this thread holds the lower index of the pair
+                e0 = (low == up) ? min(e0, o) : max(e0, o);
+            }
+        }
+    }
+#endif
+    __syncthreads();
+    skey[tid] = e0;
+    __syncthreads();
+    if (tid < GS_G) {
+        const unsigned k = skey[(group % (GS_CHUNK / GS_G)) * GS_G + tid];
+        rays[tid] = k == 0xFFFFFFFFu ? -1 : r0 + (int)(k & 1023u);
+    }
+    __syncthreads();
+
+    // ---- B. this wave's units (ray of the group, tile index): everything they need from memory, all units at once
+    const int p = lane & 15, q = lane >> 4;
+    const int ch = lane & 31, dxb = lane >> 5;
+    const int n_units = GS_G * A.ntl;
+    int64_t tile[GS_MAXU];
+    bool act[GS_MAXU];
+    int cidx[GS_MAXU][2], ccell[GS_MAXU];
+    float cw[GS_MAXU][2];
+    float amax = 0.f;
+    {
+        typedef __attribute__((address_space(4))) const float cfloat;        // wave-uniform reads through the scalar cache
+        f32x4 dr[GS_MAXU];
+        int ray[GS_MAXU];
+#pragma unroll
+        for (int i = 0; i < GS_MAXU; ++i) {
+            const int u = wave + GS_WAVES * i;
+            ray[i] = __builtin_amdgcn_readfirstlane(u < n_units ? rays[u % GS_G] : -1);
+            act[i] = ray[i] >= 0;
+            tile[i] = act[i] ? (int64_t)ray[i] * A.ntl + u / GS_G : 0;
+            dr[i] = f32x4{1.f, 0.f, 0.f, 0.f};
+            if (act[i] && A.d_raw != nullptr) dr[i] = ld4(A.d_raw + (tile[i] * 16 + p) * 4);
+        }
+        f32x4 d0[GS_MAXU], d1[GS_MAXU];
+        double zz[GS_MAXU];
+        float o3[GS_MAXU][3], d3[GS_MAXU][3];
+#pragma unroll
+        for (int i = 0; i < GS_MAXU; ++i) {
+            act[i] = act[i] && __any(dr[i][0] != 0.f || dr[i][1] != 0.f || dr[i][2] != 0.f || dr[i][3] != 0.f);   // else: not in the work list, no hand-off
+            d0[i] = d1[i] = splat4(0.f);
+            zz[i] = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { o3[i][a] = 0.f; d3[i][a] = 0.f; }
+            if (act[i]) {
+                const float* dgw = A.dgrid_ws + (tile[i] * ACT_SLOTS + slot) * DG_STRIDE;
+                d0[i] = ld4(dgw + lane * 4); d1[i] = ld4(dgw + 256 + lane * 4);
+                zz[i] = A.z[tile[i] * 16 + p];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    o3[i][a] = *reinterpret_cast<cfloat*>(reinterpret_cast<uintptr_t>(A.ro + ray[i] * 3 + a));
+                    d3[i][a] = *reinterpret_cast<cfloat*>(reinterpret_cast<uintptr_t>(A.rd + ray[i] * 3 + a));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GS_MAXU; ++i) {
+            float m = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaxf(fabsf(d0[i][r]), fabsf(d1[i][r])));
+            const bool bad = !(m <= 3.0e38f);                                 // inf / NaN somewhere: keep float semantics (direct adds)
+            if (__any(bad)) m = __builtin_inff();
+            act[i] = act[i] && __any(m != 0.f);
+            amax = fmaxf(amax, m);
+            cidx[i][0] = cidx[i][1] = 0; cw[i][0] = cw[i][1] = 0.f; ccell[i] = 0;
+            if (act[i]) {
+                double pw[3];                                                 // tile_geo's point (raygrad.hpp), from the operands loaded above
+#pragma unroll
+                for (int a = 0; a < 3; ++a) pw[a] = (double)o3[i][a] + (double)d3[i][a] * zz[i];
+                const Vox v = make_vox(pw, A.lo, A.hi, gg);
+                ccell[i] = (v.iz * gg.H + v.iy) * gg.W + v.ix;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    int64_t idx; float w;
+                    const int c = q + 4 * j;
+                    corner(v, gg, c, idx, w);
+                    // a corner beyond the last voxel has no row (the same for every sample of the cell: runs of samples in one
+                    // cell share their rows); a corner whose weight merely happens to be 0 keeps its row
+                    const bool ok = (v.ix + (c & 1) < gg.W) && (v.iy + ((c >> 1) & 1) < gg.H) && (v.iz + (c >> 2) < gg.D);
+                    cidx[i][j] = ok ? (int)idx : -1; cw[i][j] = w;
+                }
+            }
+        }
+    }
+    // ---- C. fixed-point scale of the workgroup: 2^e with n_samples * max|dC| * 2^e < 2^50 (weights are <= 1)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    float gmax = 0.f;
+#pragma unroll
+    for (int w = 0; w < GS_WAVES; ++w) gmax = fmaxf(gmax, red[w]);
+    if (gmax == 0.f) return;                                                  // (uniform) nothing flows into this group's rows
+    const bool direct = !(gmax <= 3.0e38f);
+    int ex;
+    (void)frexpf(direct ? 1.f : gmax, &ex);                                   // gmax < 2^ex
+    const double scale = __builtin_ldexp(1.0, 50 - 10 - ex), inv_scale = __builtin_ldexp(1.0, ex + 10 - 50);   // (16 rays x 64 samples = 2^10)
+    const long long magic_bits = __builtin_bit_cast(long long, GS_MAGIC);
+
+    // ---- D. unit by unit: table rows of the corners, then the adds
+    // (a run-time loop: unrolled, the 4 x 64 add sites are 40 KB of code for 16 waves to share; the unit's registers are picked by selects)
+    unsigned act_bits = 0;
+#pragma unroll
+    for (int i = 0; i < GS_MAXU; ++i) act_bits |= act[i] ? 1u << i : 0u;
+#ifdef ENS_EXP_GS_NOUNITS
+    act_bits = 0;
+#endif
+#pragma unroll 1
+    for (int iu = 0; iu < GS_MAXU; ++iu) {
+        if (!((act_bits >> iu) & 1u)) continue;                               // (wave-uniform)
+        int64_t tile_u = tile[0];
+        int cidx_u[2] = {cidx[0][0], cidx[0][1]}, ccell_u = ccell[0];
+        float cw_u[2] = {cw[0][0], cw[0][1]};
+#pragma unroll
+        for (int i = 1; i < GS_MAXU; ++i)
+            if (iu == i) { tile_u = tile[i]; cidx_u[0] = cidx[i][0]; cidx_u[1] = cidx[i][1]; ccell_u = ccell[i]; cw_u[0] = cw[i][0]; cw_u[1] = cw[i][1]; }
+        const float* dgw = A.dgrid_ws + (tile_u * ACT_SLOTS + slot) * DG_STRIDE;
+        // dC in channel layout (lane = channel, both halves): element (q' * 16 + pt) * 4 + r of the register layout, L2-warm
+        float vv[16];
+        const float* dch = dgw + (ch >> 4) * 256 + ((ch & 15) >> 2) * 64 + (ch & 3);
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt) vv[pt] = dch[pt * 4];
+        int rowj[2];                                                          // table row of this lane's corners q, q + 4 of sample p
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int row = -1;
+            if (cidx_u[j] >= 0) {
+                const unsigned key = (unsigned)cidx_u[j];
+                row = -((int)key + 2);
+                if (!direct) {
+                    unsigned h = (((key * 2654435761u) >> 22) * GS_ROWS) >> 10;
+#pragma unroll 1
+                    for (int t = 0; t < GS_PROBES; ++t) {
+                        const unsigned old = atomicCAS(&keys[h], GS_EMPTY, key);
+                        if (old == GS_EMPTY || old == key) { row = (int)h; break; }
+                        h = h + 1 == GS_ROWS ? 0u : h + 1;
+                    }
+                }
+            }
+            rowj[j] = row;
+        }
+#ifndef ENS_EXP_GS_NOADD
+        {   // The adds, back to back.  Rows, weights and cells reach the (channel, x-half) lanes by v_readlane: LDS operations
+            // complete in order, so an LDS read issued behind the adds would wait for them.  Integer adds: ds_add_f32 runs at ~160
+            // cycles per wave instruction on gfx950, ds_add_u64 at ~10 -- so the sums are kept in 64-bit fixed point (exact,
+            // order-independent) and become float once, at the flush.
+            bool ovf = false;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            int prow[4] = {GS_ROWS, GS_ROWS, GS_ROWS, GS_ROWS}, pcell = 0;
+            auto emit = [&]() {                                               // the run of samples in cell pcell ends
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double d = __builtin_fma((double)acc[k], scale, GS_MAGIC);
+                    const long long fx = __builtin_bit_cast(long long, d) - magic_bits;
+                    __hip_atomic_fetch_add(vals + prow[k] * 32 + ch, (unsigned long long)fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    acc[k] = 0.f;
+                }
+            };
+            const int wb0 = __builtin_bit_cast(int, cw_u[0]), wb1 = __builtin_bit_cast(int, cw_u[1]);
+#pragma unroll
+            for (int pt = 0; pt < 16; ++pt) {
+                // consecutive samples of a ray in one cell (the surface samples) are summed in registers first
+                const int cnow = __builtin_amdgcn_readlane(ccell_u, pt);
+#ifdef ENS_EXP_GS_NORUN
+                if (pt > 0) emit();
+#else
+                if (pt > 0 && cnow != pcell) emit();
+#endif
+                pcell = cnow;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // corner c = dxb + 2 k of sample pt: register j = k >> 1 of lane pt + 16 * (2 * (k & 1) + dxb)
+                    const int src = pt + 32 * (k & 1);
+                    const int r_lo = __builtin_amdgcn_readlane(k < 2 ? rowj[0] : rowj[1], src);
+                    const int r_hi = __builtin_amdgcn_readlane(k < 2 ? rowj[0] : rowj[1], src + 16);
+                    const int w_lo = __builtin_amdgcn_readlane(k < 2 ? wb0 : wb1, src);
+                    const int w_hi = __builtin_amdgcn_readlane(k < 2 ? wb0 : wb1, src + 16);
+                    const int row = dxb ? r_hi : r_lo;
+                    const float w = __builtin_bit_cast(float, dxb ? w_hi : w_lo);
+                    ovf = ovf || row <= -2;
+                    prow[k] = row >= 0 ? row : GS_ROWS;
+                    acc[k] = fmaf(w, vv[pt], acc[k]);
+                }
+            }
+            emit();
+            if (__any(ovf)) {                                                 // rows without a place in the table: straight to the gradient
+#pragma unroll 1
+                for (int pt = 0; pt < 16; ++pt) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int src = pt + 32 * (k & 1);
+                        const int r_lo = __builtin_amdgcn_readlane(k < 2 ? rowj[0] : rowj[1], src);
+                        const int r_hi = __builtin_amdgcn_readlane(k < 2 ? rowj[0] : rowj[1], src + 16);
+                        const int w_lo = __builtin_amdgcn_readlane(k < 2 ? wb0 : wb1, src);
+                        const int w_hi = __builtin_amdgcn_readlane(k < 2 ? wb0 : wb1, src + 16);
+                        const int row = dxb ? r_hi : r_lo;
+                        const float x = __builtin_bit_cast(float, dxb ? w_hi : w_lo) * dch[pt * 4];
+                        if (row <= -2 && x != 0.f) atomicAdd(gg.data + (int64_t)(-(row + 2)) * 32 + ch, x);
+                    }
+                }
+            }
+        }
+#endif
+    }
+    __syncthreads();
+    // ---- E. the table leaves: two rows per wave instruction (two 128-byte segments: the full-rate float-atomic shape)
+    {
+        const int i0 = wave * (GS_ROWS / GS_WAVES);                            // 36 rows per wave
+        unsigned kk[GS_ROWS / GS_WAVES / 2];
+        long long xx[GS_ROWS / GS_WAVES / 2];
+#pragma unroll
+        for (int i = 0; i < GS_ROWS / GS_WAVES / 2; ++i) {
+            kk[i] = keys[i0 + 2 * i + dxb];
+            xx[i] = (long long)vals[(i0 + 2 * i + dxb) * 32 + ch];
+        }
+#pragma unroll
+        for (int i = 0; i < GS_ROWS / GS_WAVES / 2; ++i) {
+            const float x = (float)((double)xx[i] * inv_scale);
+            if (kk[i] != GS_EMPTY && x != 0.f) atomicAdd(gg.data + (int64_t)kk[i] * 32 + ch, x);
+        }
+    }
+}
+
+}  // namespace
+
+int ens_launch_grid_scatter(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z, const DevScene& sc,
+                            const float* dgrid_ws, const float* d_raw, const DevGrid* grad_grids, hipStream_t st) {
+    if (n_rays <= 0 || stage < 1 || stage > 3 || !dgrid_ws) return 0;
+    ScatterArgs A;
+    A.n_rays = n_rays; A.ntl = ntl; A.n_slots = stage;
+    A.ro = ro; A.rd = rd; A.z = z; A.dgrid_ws = dgrid_ws; A.d_raw = d_raw;
+    double ext = 0.0;
+    for (int a = 0; a < 3; ++a) { A.lo[a] = sc.lo[a]; A.hi[a] = sc.hi[a]; ext = sc.hi[a] - sc.lo[a] > ext ? sc.hi[a] - sc.lo[a] : ext; }
+    A.key_t = (float)(0.1 * ext);
+    A.n_active_slots = 0;
+    for (int s = 0; s < 3; ++s) {
+        A.ggrid[s] = DevGrid{nullptr, 0, 0, 0};
+        A.slot_of[s] = 0;
+    }
+    for (int s = 0; s < stage; ++s) {
+        if (grad_grids[s + 1].data == nullptr) continue;
+        A.ggrid[s] = grad_grids[s + 1];
+        A.slot_of[A.n_active_slots++] = s;
+    }
+    if (A.n_active_slots == 0) return 0;
+    static bool attr_done[ENS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[ens_device_ordinal()];
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(grid_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GS_BYTES) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
+    const int64_t n_groups = ((int64_t)n_rays + GS_G - 1) / GS_G;
+    if (n_groups * A.n_active_slots > 0x7fffffff) return -1;
+    grid_scatter_kernel<<<dim3((unsigned)(n_groups * A.n_active_slots)), dim3(GS_THREADS), GS_BYTES, st>>>(A);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -198,4 +198,8 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
                            const DevGrid* grad_grids, float* const* grad_packed, float* g_ro, float* g_rd,
                            hipStream_t st, const double* draw_scale = nullptr, const WorkList* wl = nullptr,
                            float* const* grad_partial = nullptr);
+// feature-gradient scatter from the decoder kernels' hand-off (grid_scatter.hip); grad_grids indexed by decoder kind, data null: not scattered;
+// d_raw null: every tile was handed off, else only the tiles whose d_raw is not all zero (the work list's criterion)
+int ens_launch_grid_scatter(int stage, int ntl, int n_rays, const float* ro, const float* rd, const double* z, const DevScene& sc,
+                            const float* dgrid_ws, const float* d_raw, const DevGrid* grad_grids, hipStream_t st);
 int ens_bwd_max_workgroups();      // upper bound of the workgroups of one decoder role (rows of a partial buffer)

@@ -756,7 +756,8 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     float* gpk = A.gpacked[kind];
     const bool want_w = WW && gpk != nullptr;       // (kept a run-time flag in the WW variant: folding it costs 30 spills)
     const bool want_g = A.ggrid[kind].data != nullptr, want_r = A.g_ro != nullptr;
-    const bool want_c = want_g || want_r;
+    const bool defer_g = (A.defer_mask >> kind) & 1;               // the scatter is grid_scatter_kernel's: dC leaves through the hand-off
+    const bool want_c = want_g || want_r || defer_g;
     float* ring = smem;
     float* slots = smem + WAREA_SAVED;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)smem;
@@ -858,7 +859,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         // ray gradients: handed off per tile to the ray-gradient launch (dgrid_ws given), or -- dgrid_ws NULL -- computed here at
         // the end of the round from the registers that would have been handed off (no 3 KB store + load per tile and decoder,
         // no ray-gradient role in the finish launch)
-        const bool handoff = want_r && A.dgrid_ws != nullptr;
+        const bool handoff = (want_r || defer_g) && A.dgrid_ws != nullptr;
         float* dgw = handoff ? A.dgrid_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * DG_STRIDE : nullptr;
         {   // skip the round when nothing flows into any of its 4 tiles (one barrier; waves stay in lockstep)
             const int par = (int)(round_no & 1);
@@ -1056,7 +1057,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         if (handoff && tvalid) {        // hand-off to grid_bwd_kernel: dC (register layout) + embedding's position gradient
             *reinterpret_cast<f32x4*>(dgw + lane * 4) = dc[0];
             *reinterpret_cast<f32x4*>(dgw + 256 + lane * 4) = dc[1];
-            *reinterpret_cast<f32x4*>(dgw + DG_DPE + lane * 4) = dpe[0];
+            if (want_r) *reinterpret_cast<f32x4*>(dgw + DG_DPE + lane * 4) = dpe[0];
         }
         if constexpr (SPLIT) {
             if (want_g) {               // dC of this tile (zeros for a padding tile) -> [sample][32] in this wave's H1 tiles, for dW wave `wave`
@@ -1628,6 +1629,15 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         lds_saved = need_s > lds_saved ? need_s : lds_saved;
     }
     if (n2 == 0) return 0;
+    // Deferred feature-gradient scatter (grid_scatter.hip; experiment of round 4, ENSLAM_DEFER_SCATTER=1): with a hand-off
+    // workspace the saved-activation kernels leave dC there and a launch of its own forms the sums that share a voxel row on
+    // chip before they reach the gradient (6.6 MB of float atomics per 1000-ray step instead of 50 MB).  The decoder kernel
+    // drops from 135 to 100 us, the extra launch takes 57: off by default.
+    static const bool defer_on = [] { const char* e = getenv("ENSLAM_DEFER_SCATTER"); return e != nullptr && e[0] == '1'; }();
+    A.defer_mask = 0;
+    if (defer_on && A.act_ws != nullptr && stage != 0 && dgrid_ws != nullptr)
+        for (int i = 0; i < n2; ++i)
+            if (A.ggrid[kk[i]].data != nullptr) A.defer_mask |= 1 << kk[i];
     const int64_t n_tiles = (int64_t)n_rays * ntl;
     static bool attr_done[ENS_MAX_DEVICES] = {};
     bool& attr_set = attr_done[ens_device_ordinal()];
@@ -1699,6 +1709,7 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
             B.role_kind[i] = ks[i];
             B.role_begin[i] = begin;
             B.ggrid[ks[i]] = A.ggrid[ks[i]];
+            if ((A.defer_mask >> ks[i]) & 1) B.ggrid[ks[i]].data = nullptr;       // (dims kept; the kernels test .data)
             B.gpacked[ks[i]] = A.gpacked[ks[i]];
             B.gpart[ks[i]] = A.gpart[ks[i]];
             begin += split[i];
@@ -1722,9 +1733,24 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
     if (rl != 0) return rl;
     bool partials = false;                                          // (partial images: the persistent kernel's flush only)
     for (int i = 0; i < nh; ++i) partials = partials || A.gpart[hk[i]] != nullptr;
-    if (nh > 0 && use_bwd2 && A.act_ws != nullptr && A.dh_ws != nullptr && hk[0] != 0 && !partials)
-        return ens_launch_decoder_bwd2(A, hk, hc, nh, stage, n_tiles, st);
-    return launch_subset(hk, hc, nh, false);
+    if (nh > 0 && use_bwd2 && A.act_ws != nullptr && A.dh_ws != nullptr && hk[0] != 0 && !partials) {
+        BwdArgs A2 = A;                                             // (the two-kernel form keeps its own scatter)
+        A2.defer_mask = 0;
+        const int r2 = ens_launch_decoder_bwd2(A2, hk, hc, nh, stage, n_tiles, st);
+        if (r2 != 0) return r2;
+        int lmask = 0;
+        for (int i = 0; i < nl; ++i) lmask |= 1 << lk[i];
+        A.defer_mask &= lmask;
+    } else {
+        const int rh = launch_subset(hk, hc, nh, false);
+        if (rh != 0) return rh;
+    }
+    if (A.defer_mask != 0) {
+        DevGrid dg[4];
+        for (int k = 0; k < 4; ++k) { dg[k] = A.ggrid[k]; if (!((A.defer_mask >> k) & 1)) dg[k].data = nullptr; }
+        return ens_launch_grid_scatter(stage, ntl, n_rays, ro, rd, z, sc, dgrid_ws, listed ? d_raw : nullptr, dg, st);
+    }
+    return 0;
 }
 
 // Second kernel of the saved-activation backward: ray gradients from the decoder kernel's hand-off buffer.

@@ -1233,7 +1233,11 @@ class _RenderFn(torch.autograd.Function):
         finish_needed = any((need_grid[k] and k not in plan.vm and not nat[k]) or need_par[k] for k in plan.kinds) or bool(accum.nat_persist)
         inline_rays = (not finish_needed) if INLINE_RAY_GRAD is None else INLINE_RAY_GRAD
         dgw = None
-        if act is not None and need_rays and not inline_rays:
+        # ENSLAM_DEFER_SCATTER=1 (experiment, csrc/grid_scatter.hip): the feature gradient of every grid leaves the decoder kernels
+        # through the same hand-off and is scattered by a launch of its own that first sums, in LDS, what neighbouring rays add
+        # to the same voxel rows.  The workspace is what switches it on in the library.
+        defer = DEFER_SCATTER and act is not None and plan.stage != 'coarse' and any(need_grid[k] for k in plan.kinds)
+        if act is not None and ((need_rays and not inline_rays) or defer):
             dgw = torch.empty(_lib_size('enslam_grid_handoff_floats', L.STAGE[plan.stage], N, S), dtype=torch.float32, device=dev)
         ev = plan.state.profile.get('decoder_bwd')
         if ev is not None:                      # bench.py: HIP events around the dominant kernel, on this stream
@@ -1246,7 +1250,7 @@ class _RenderFn(torch.autograd.Function):
             e1.record()
             ev.append((e0, e1))
         # saved-activation path: the ray gradients (corner re-gather from the hand-off in dgw) ride in the finish launch
-        ray_pending = dgw is not None and plan.stage != 'coarse'
+        ray_pending = dgw is not None and need_rays and plan.stage != 'coarse'
         out = [None, g_ro if needs[1] else None, g_rd if needs[2] else None, None, None]
         # ONE launch: grid gradients back to the callers' [1,32,D,H,W] layout + decoder gradients unpacked into views of
         # one flat buffer shaped like the parameters
@@ -1342,6 +1346,7 @@ class _RenderFn(torch.autograd.Function):
 ACT_WORKSPACE_LIMIT_BYTES = 8 << 30
 
 INLINE_RAY_GRAD = {'1': True, '0': False}.get(os.environ.get('ENSLAM_INLINE_RAY_GRAD', ''), None)     # None: decided per call
+DEFER_SCATTER = os.environ.get('ENSLAM_DEFER_SCATTER', '0') == '1'       # experiment: feature-gradient scatter as its own launch (csrc/grid_scatter.hip)
 # weight gradients as per-workgroup partial images summed by the finish launch instead of float atomics at the backward's tail:
 # backward 138 -> 132 us, finish launch 22 -> 28 us (17.6 MB more to read), step unchanged -- off by default (round 3)
 USE_DW_PARTIALS = os.environ.get('ENSLAM_DW_PARTIALS', '0') == '1'

@@ -205,11 +205,10 @@ def test_large_batch_forward_kernel_feeds_the_same_backward():
     assert 'WORST' in r.stdout
 
 
-def test_two_kernel_backward_matches_the_reference_fixtures():
-    """ENS_BWD2=1: the two-kernel form of the saved-activation backward (csrc/render_bwd2.hip: dX-chain kernel with dedicated
-    scatter waves + split-K weight-gradient kernel) against the reference-generated fixtures -- the tiny colour scene (all
-    gradients) and room0 at 1000 x 48 (outputs, ray gradients, every decoder parameter, sampled grid-gradient entries), the
-    latter also through the graphed bench step.  The switch is read once per process: a child process."""
+def _fixture_child(env_extra):
+    """A child process (switches that are read once per process) that checks the tiny colour scene (all gradients) and room0 at
+    1000 x 48 in both grid layouts (ray gradients, every decoder parameter, sampled grid-gradient entries, gradient sums) against
+    the reference-generated fixtures."""
     import os
     import subprocess
     import sys
@@ -257,10 +256,24 @@ def test_two_kernel_backward_matches_the_reference_fixtures():
         "        assert abs(gg.astype(np.float64).sum() - st[0]) <= 1e-3 * st[1] and int(np.count_nonzero(gg)) <= st[2] * 1.001 + 8\n"
         "    print('WORST room0', layout, w)\n"
         "    assert w <= 1e-3\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ENS_BWD2='1')
+    env = dict(os.environ, **env_extra)
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert 'WORST room0 channels_last_3d' in r.stdout
+
+
+def test_two_kernel_backward_matches_the_reference_fixtures():
+    """ENS_BWD2=1: the two-kernel form of the saved-activation backward (csrc/render_bwd2.hip: dX-chain kernel with dedicated
+    scatter waves + split-K weight-gradient kernel) against the reference-generated fixtures."""
+    _fixture_child({'ENS_BWD2': '1'})
+
+
+def test_deferred_scatter_matches_the_reference_fixtures():
+    """ENSLAM_DEFER_SCATTER=1: the feature-gradient scatter as a launch of its own (csrc/grid_scatter.hip: Morton-ordered ray
+    groups, LDS table of 64-bit fixed-point sums) against the same fixtures.  Its one documented difference from float32
+    accumulation -- elements below 2^-40 of a ray group's largest feature gradient come out as exact zeros -- is why the child
+    bounds the non-zero count from above only."""
+    _fixture_child({'ENSLAM_DEFER_SCATTER': '1'})
 
 
 def test_weight_gradients_as_partial_images_match_the_atomic_path():

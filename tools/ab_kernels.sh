@@ -10,7 +10,7 @@ import csv, sys
 t = sys.argv[1]
 d = {}
 for r in csv.DictReader(open(f'gpurun_out/ks_{t}.csv')):
-    for k in ('sample_prepare', 'step_kernel', 'render_fwd_ring', 'composite_fwd', 'decoder_bwd_split', 'decoder_chain', 'decoder_scatter', 'decoder_dw'):
+    for k in ('sample_prepare', 'step_kernel', 'render_fwd_ring', 'composite_fwd', 'decoder_bwd_split', 'decoder_chain', 'decoder_scatter', 'decoder_dw', 'grid_scatter'):
         if k in r['Name']: d[k] = float(r['AverageNs']) / 1e3
 print(f"{t:10s}", "  ".join(f"{k} {v:6.1f}" for k, v in d.items()), f"  sum {sum(d.values()):6.1f}")
 PY
