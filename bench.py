@@ -1008,7 +1008,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-api', action='store_true', help='skip the reference-API-only (Python-driven) timing `api_rays_per_s`')
-    ap.add_argument('--variant', default=None, choices=('surfaces',), help='primary workload on a map fitted to an analytic room')
+    ap.add_argument('--variant', default=None, choices=('surfaces', 'mapper_grads'), help="primary workload on a map fitted to an analytic room | with the reference mapper's gradient set")
     ap.add_argument('--grid-layout', default='channels_last_3d', choices=('channels_last_3d', 'contiguous'),
                     help='memory format of the feature-grid tensors (same shape and values either way)')
     ap.add_argument('--torch-loss', action='store_true', help='compute the mapper loss with torch ops instead of the fused HIP loss')

