@@ -1073,6 +1073,19 @@ def main():
                                  "decoder's parameters only -- no gradients for the middle / fine decoders' parameters (their backward runs the "
                                  "light chain kernel), none for the rays (no ray-gradient role in the finish launch).  frac / step_frac stay "
                                  "on the agreed yardstick (3 x 103 306 FLOP per point), of which this step needs 2.30 x")
+                # the same step with the feature-gradient scatter as a launch of its own (csrc/grid_scatter.hip; opt-in, read once per
+                # process: a child process).  Wins on this random-init map, loses on a map with surfaces
+                try:
+                    import subprocess
+                    cmd = [sys.executable, os.path.abspath(__file__), '--variant', 'mapper_grads', '--steps', str(max(50, args.steps // 2)),
+                           '--warmup', str(max(5, args.warmup // 2)), '--no-secondary', '--no-cpu-baseline', '--no-api', '--no-kernel-events']
+                    cp = subprocess.run(cmd, env=dict(os.environ, ENSLAM_DEFER_SCATTER='2'), capture_output=True, text=True, timeout=300)
+                    line = [ln for ln in cp.stdout.splitlines() if ln.startswith('{')][-1]
+                    c = json.loads(line)
+                    o["deferred_scatter"] = {"switch": "ENSLAM_DEFER_SCATTER=2", "value": c["value"], "unit": c["unit"],
+                                             "ms_per_step": c["ms_per_step"], "loss": c.get("loss")}
+                except Exception as e:                                       # (never fails the bench line)
+                    o["deferred_scatter"] = {"error": repr(e)[:200]}
                 return o
 
             guarded("config2_mapper_grads", mapper_grads)

@@ -1019,7 +1019,7 @@ int enslam_plan_layout(const enslam_step_plan* plan, enslam_step_layout* L) {
     L->s_dgw = -1;
     bool any_ggrid = false;                   // the grid gradients' scatter reads the hand-off (grid_scatter.hip; policy: ens_launch_decoder_bwd)
     {
-        static const int defer_mode = [] { const char* e = getenv("ENSLAM_DEFER_SCATTER"); return e == nullptr ? 2 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)); }();
+        static const int defer_mode = [] { const char* e = getenv("ENSLAM_DEFER_SCATTER"); return e == nullptr ? 0 : (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0)); }();
         bool any_grid = false, light_grid = false;
         for (int k = 1; k < 4; ++k) {
             any_grid = any_grid || plan->grid_mode[k] >= 2;

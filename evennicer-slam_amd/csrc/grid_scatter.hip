@@ -1,5 +1,6 @@
-// Feature-gradient scatter of the saved-activation backward as a launch of its own -- an EXPERIMENT of round 4, off by default
-// (ENSLAM_DEFER_SCATTER=1 selects it; DESIGN.md section 6.3 has the numbers and why it does not pay on gfx950).
+// Feature-gradient scatter of the saved-activation backward as a launch of its own -- round 4, opt-in (ENSLAM_DEFER_SCATTER=1: always,
+// =2: when a decoder without parameter gradients has a grid gradient; DESIGN.md section 6.3 has the numbers: it wins on a random-init
+// map with the reference mapper's gradient set, loses on a map with surfaces and wherever the persistent kernel can hide the atomics).
 //
 // The decoder backward leaves d(loss)/d(interpolated feature) of every (tile, decoder) in the hand-off workspace the ray-gradient
 // role already reads (dgrid_ws: dC in register layout).  What is left is the transpose of the forward's trilinear gather
@@ -11,7 +12,7 @@
 //   * the rays of a batch are ordered along a Morton curve (key: the cell, at 1/128 of the bound, of the point one tenth of
 //     the bound's extent along the ray), in chunks of 1024 -- every workgroup sorts the chunk of its group itself (bitonic:
 //     shuffles inside a wave, LDS across waves; no extra launch, no buffer, nothing for the host to provide);
-//   * one workgroup takes 16 consecutive rays of that order and ONE grid: neighbouring rays cross the same cells, so the
+//   * one workgroup takes 12 consecutive rays of that order and ONE grid (252 workgroups at 1000 rays: every CU; 16 rays: 189): neighbouring rays cross the same cells, so the
 //     ~6 000 corner contributions of the group fall on ~500 distinct voxel rows (tools/sim_scatter_merge.py) -- they are
 //     added into an LDS table of 576 rows x 32 channels (open addressing on the voxel index) and leave once per row:
 //     52 k row-adds (6.6 MB) per step instead of ~400 k (50 MB);
@@ -21,10 +22,9 @@
 //     float32 accumulation: gradient elements some 12 decades below the group's largest come out as exact zeros);
 //   * a row that finds no place in the table (8 probes) is added to the gradient directly, and a group that holds an inf / NaN
 //     adds everything directly -- correctness does not depend on the table's size or on the order of the rays.
-// Measured (1000 rays, room0): 57 us, of which 14.5 us launch + table clear + sort + flush scan, 10 us the units' loads,
-// geometry and probes, 32 us the adds -- the VALU work of 48 (tile, grid) units per CU (operand distribution, fixed-point
-// conversion, addresses: ~900 instructions each) on the 189 CUs the launch occupies.  The decoder kernel does the same
-// arithmetic in the issue slots its MFMA chains leave free.
+// Measured (1000 rays, room0, random-init map): 50 us with 12 rays per workgroup (60 with 16).  s_memtime stamps (tools/stamps_scatter.py,
+// 16-ray form, cycles per wave): table clear 2.5 k, ordering 12.7 k, loads + geometry 9.7 k, scale 3.3 k, table probes 19 k (they return
+// through the LDS queue the other waves' adds sit in), adds 13.7 k, waiting for the slowest wave 28 k, flush 3.5 k.
 #include "common.hpp"
 #include "kernels.hpp"
 #include "raygrad.hpp"
@@ -34,8 +34,11 @@ namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int GS_G = 16;                 // rays per workgroup
-constexpr int GS_CHUNK = 1024;           // rays ordered together
+#ifndef ENS_GS_G
+#define ENS_GS_G 12
+#endif
+constexpr int GS_G = ENS_GS_G;           // rays per workgroup
+constexpr int GS_CHUNK = (1024 / GS_G) * GS_G;   // rays ordered together (whole groups, at most one key per thread)
 constexpr int GS_ROWS = 576;             // table rows (the largest group of the bench scene needs 570)
 constexpr int GS_WAVES = 16;
 constexpr int GS_THREADS = GS_WAVES * 64;
@@ -45,14 +48,14 @@ constexpr int GS_THREADS = GS_WAVES * 64;
 constexpr int GS_PROBES = ENS_GS_PROBES;
 constexpr int GS_MAXU = 4;               // units per wave: GS_G * ntl / GS_WAVES, ntl <= 4
 constexpr unsigned GS_EMPTY = 0xFFFFFFFFu;
-static_assert(GS_CHUNK == GS_THREADS, "one key per thread");
+static_assert(GS_CHUNK <= GS_THREADS && GS_G * 4 <= GS_MAXU * GS_WAVES, "one key per thread; units per wave");
 
 // LDS map (bytes)
 constexpr int GS_VALS = 0;                                   // [GS_ROWS + 1][32] int64 fixed point (row GS_ROWS: dummy, never read)
 constexpr int GS_KEYS = GS_VALS + (GS_ROWS + 1) * 256;       // [GS_ROWS] voxel row index or GS_EMPTY
 constexpr int GS_SORT = GS_KEYS + GS_ROWS * 4;               // [GS_CHUNK] u32: bin counts of the counting sort
-constexpr int GS_ORD = GS_SORT + GS_CHUNK * 4;               // [GS_CHUNK] int: chunk position -> ray
-constexpr int GS_RAYS = GS_ORD + GS_CHUNK * 4;              // [GS_G] ray of the group (-1: none)
+constexpr int GS_ORD = GS_SORT + GS_THREADS * 4;               // [GS_CHUNK] int: chunk position -> ray
+constexpr int GS_RAYS = GS_ORD + GS_THREADS * 4;             // [GS_G] ray of the group (-1: none)
 constexpr int GS_RED = GS_RAYS + 64;                         // [GS_WAVES] max |dC| per wave; before: key bounding box [8] + wave totals [16]
 constexpr int GS_BYTES = GS_RED + 96;
 static_assert(GS_BYTES <= 160 * 1024, "LDS");
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(GS_THREADS) void grid_scatter_kernel(ScatterArgs A)
         // the rays if all workgroups agree: rank the bin's rays by index
         int mypos = 0;
         if (kvalid) {
-            const int s0 = (int)hist[bin], n = (int)(bin + 1 < GS_CHUNK ? hist[bin + 1] : (unsigned)n_chunk) - s0;
+            const int s0 = (int)hist[bin], n = (int)(bin + 1 < GS_THREADS ? hist[bin + 1] : (unsigned)n_chunk) - s0;
             int c = 0;
             for (int i = 0; i < n; ++i) c += ordr[s0 + i] < tid ? 1 : 0;
             mypos = s0 + c;

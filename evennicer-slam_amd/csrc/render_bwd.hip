@@ -1637,14 +1637,15 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         lds_saved = need_s > lds_saved ? need_s : lds_saved;
     }
     if (n2 == 0) return 0;
-    // Deferred feature-gradient scatter (grid_scatter.hip): with a hand-off workspace the saved-activation kernels leave dC there and a
-    // launch of its own forms the sums that share a voxel row on chip before they reach the gradient (6.6 MB of float atomics per
-    // 1000-ray step instead of 50 MB; 58 us).  Policy (ENSLAM_DEFER_SCATTER unset): deferred exactly when a LIGHT role -- a decoder
-    // without parameter gradients, e.g. the fixed occupancy decoders of the reference's mapper -- has a grid gradient: the light kernel
-    // has no second wave kind to hide the atomics behind (75.7 us with the scatter, 18.3 without), and once the launch exists the heavy
-    // roles hand off too (colour role alone: 75.2 -> 48.9 us).  With heavy roles only the persistent kernel hides most of it (134 us
-    // against 100 + 58).  ENSLAM_DEFER_SCATTER=0 / 1: never / whenever a hand-off workspace is given.
-    static const int defer_mode = [] { const char* e = getenv("ENSLAM_DEFER_SCATTER"); return e == nullptr ? 2 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)); }();
+    // Deferred feature-gradient scatter (grid_scatter.hip; opt-in): with a hand-off workspace the saved-activation kernels leave dC there
+    // and a launch of its own forms the sums that share a voxel row on chip before they reach the gradient (6.6 MB of float atomics per
+    // 1000-ray step instead of 50 MB; 50 us).  ENSLAM_DEFER_SCATTER=1: whenever a hand-off workspace is given; =2: when a LIGHT role -- a
+    // decoder without parameter gradients, e.g. the fixed occupancy decoders of the reference's mapper -- has a grid gradient (the light
+    // kernel has no second wave kind to hide the atomics behind: 75.7 us with the scatter, 19 without; once the launch exists the heavy
+    // roles hand off too).  Default off: on a RANDOM-INIT map that policy takes the mapper's backward from 151 to 117 us, on a map with
+    // surfaces most feature gradients are exact zeros, the in-kernel scatter skips them, and the extra launch loses (mapper iteration
+    // 307 -> 327 us); with heavy roles only the persistent kernel hides most of it (134 us against 100 + 50).
+    static const int defer_mode = [] { const char* e = getenv("ENSLAM_DEFER_SCATTER"); return e == nullptr ? 0 : (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0)); }();
     static const bool split_on = [] { const char* e = getenv("ENS_SPLIT"); return e == nullptr || e[0] != '0'; }();   // (the 4-wave A/B kernel has no deferred form)
     A.defer_mask = 0;
     if (defer_mode != 0 && split_on && A.act_ws != nullptr && stage != 0 && dgrid_ws != nullptr) {

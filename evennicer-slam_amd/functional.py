@@ -1233,10 +1233,9 @@ class _RenderFn(torch.autograd.Function):
         finish_needed = any((need_grid[k] and k not in plan.vm and not nat[k]) or need_par[k] for k in plan.kinds) or bool(accum.nat_persist)
         inline_rays = (not finish_needed) if INLINE_RAY_GRAD is None else INLINE_RAY_GRAD
         dgw = None
-        # Feature-gradient scatter as a launch of its own (csrc/grid_scatter.hip): the decoder kernels leave dC in the same hand-off and
-        # the scatter first sums, in LDS, what neighbouring rays add to the same voxel rows.  The library does that whenever it is
-        # given the workspace and a decoder WITHOUT parameter gradients has a grid gradient (the reference mapper's fixed occupancy
-        # decoders: their light kernel cannot hide the atomics); ENSLAM_DEFER_SCATTER=0 / 1: never / always.  Same rule here.
+        # ENSLAM_DEFER_SCATTER=1 / 2 (opt-in, csrc/grid_scatter.hip): the decoder kernels leave dC in the same hand-off and a launch of its
+        # own scatters it, first summing in LDS what neighbouring rays add to the same voxel rows -- always / when a decoder WITHOUT
+        # parameter gradients has a grid gradient (the reference mapper's fixed occupancy decoders).  Same rule here as in the library.
         defer = False
         if DEFER_SCATTER and act is not None and plan.stage != 'coarse':
             any_grid = any(need_grid[k] for k in plan.kinds)
@@ -1351,7 +1350,7 @@ class _RenderFn(torch.autograd.Function):
 ACT_WORKSPACE_LIMIT_BYTES = 8 << 30
 
 INLINE_RAY_GRAD = {'1': True, '0': False}.get(os.environ.get('ENSLAM_INLINE_RAY_GRAD', ''), None)     # None: decided per call
-DEFER_SCATTER = {'0': 0, '1': 1}.get(os.environ.get('ENSLAM_DEFER_SCATTER', ''), 2)    # feature-gradient scatter as its own launch (csrc/grid_scatter.hip): never / always / by policy
+DEFER_SCATTER = {'1': 1, '2': 2}.get(os.environ.get('ENSLAM_DEFER_SCATTER', ''), 0)    # feature-gradient scatter as its own launch (csrc/grid_scatter.hip): off (default) / always / by policy
 # weight gradients as per-workgroup partial images summed by the finish launch instead of float atomics at the backward's tail:
 # backward 138 -> 132 us, finish launch 22 -> 28 us (17.6 MB more to read), step unchanged -- off by default (round 3)
 USE_DW_PARTIALS = os.environ.get('ENSLAM_DW_PARTIALS', '0') == '1'

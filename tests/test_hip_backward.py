@@ -269,7 +269,7 @@ def test_two_kernel_backward_matches_the_reference_fixtures():
 
 
 def test_deferred_scatter_matches_the_reference_fixtures():
-    """ENSLAM_DEFER_SCATTER=1: the feature-gradient scatter as a launch of its own (csrc/grid_scatter.hip: Morton-ordered ray
+    """ENSLAM_DEFER_SCATTER=1: the feature-gradient scatter as a launch of its own (csrc/grid_scatter.hip: spatially ordered ray
     groups, LDS table of 64-bit fixed-point sums) against the same fixtures.  Its one documented difference from float32
     accumulation -- elements below 2^-40 of a ray group's largest feature gradient come out as exact zeros -- is why the child
     bounds the non-zero count from above only."""
