@@ -48,7 +48,11 @@ ENS_DEV void ws_store_dep(float* __restrict__ ws_tile, const f32x4& x, float* st
     const f32x4 v = *reinterpret_cast<const f32x4*>(stage + lane * 4);     // the tile goes to the workspace swizzled, as the backward reads it
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#ifdef ENS_EXP_NT_WS          // A/B aid: the workspace written with non-temporal stores
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ws_tile + lane * 4));
+#else
     *reinterpret_cast<f32x4*>(ws_tile + lane * 4) = v;
+#endif
 #endif
 }
 

@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/eager -o e -- python3
 PMC_MODE=${PMC_MODE:-}
 rocprofv3 --list-avail > $O/avail.txt 2>&1 || true
 MALL=$(grep -o -E "\b[A-Z0-9_]*(MALL|INFINITY_CACHE|L3_HIT|L3_MISS)[A-Z0-9_]*\b" $O/avail.txt | sort -u | head -4 | tr '\n' ' ')
-echo "Infinity-Cache (MALL) counters in rocprofv3 --list-avail: ${MALL:-none (the TCC_EA0_RDREQ_DRAM / _GMI / _IO counters classify a request's DESTINATION, not its residency: a hit rate of the Infinity Cache cannot be read on this stack)}" > $O/mall.txt
+echo "Infinity-Cache (MALL) counters in rocprofv3 --list-avail: ${MALL:-none (the TCC_EA0_RDREQ_DRAM / _GMI / _IO counters classify the DESTINATION of a request, not its residency: a hit rate of the Infinity Cache cannot be read on this stack)}" > $O/mall.txt
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "$MALL"; do
   [ -z "$(echo $c | tr -d ' ')" ] && continue
   tag=$(echo $c | cut -d' ' -f1)
