@@ -205,7 +205,7 @@ def test_large_batch_forward_kernel_feeds_the_same_backward():
     assert 'WORST' in r.stdout
 
 
-def _fixture_child(env_extra):
+def _fixture_child(env_extra, scenes=(('room0', 'room0_color1000'),)):
     """A child process (switches that are read once per process) that checks the tiny colour scene (all gradients) and room0 at
     1000 x 48 in both grid layouts (ray gradients, every decoder parameter, sampled grid-gradient entries, gradient sums) against
     the reference-generated fixtures."""
@@ -232,12 +232,14 @@ def _fixture_child(env_extra):
         "print('WORST tiny', w)\n"
         "assert w <= 1e-3\n"
         "dev = torch.device('cuda', 0)\n"
-        "sc = bench.build_scene_cpu('room0', 0)\n"
-        "g = load('room0_color1000')\n"
-        "model = sc['model'].to(dev); bench.attach_bounds(model, sc['bound'])\n"
-        "renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **bench.CAM))\n"
-        "t = lambda k: torch.from_numpy(g[k]).to(dev)\n"
-        "for layout in ('contiguous', 'channels_last_3d'):\n"
+        "del model, grids, renderer, cg\n"
+        "for tag, fixture in %r:\n"
+        "  sc = bench.build_scene_cpu(tag, 0)\n"
+        "  g = load(fixture)\n"
+        "  model = sc['model'].to(dev); bench.attach_bounds(model, sc['bound'])\n"
+        "  renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **sc['cam']))\n"
+        "  t = lambda k: torch.from_numpy(g[k]).to(dev)\n"
+        "  for layout in ('contiguous', 'channels_last_3d'):\n"
         "    cg = {k: (v.to(dev).contiguous(memory_format=torch.channels_last_3d) if layout != 'contiguous' else v.to(dev)).requires_grad_(True)\n"
         "          for k, v in sc['grids'].items()}\n"
         "    for p in model.parameters(): p.grad = None\n"
@@ -254,12 +256,15 @@ def _fixture_child(env_extra):
         "        w = max(w, float(np.abs(gg[g['gidx_' + key]] - ref).max() / np.abs(ref).max()))\n"
         "        st = g['gstat_' + key]\n"
         "        assert abs(gg.astype(np.float64).sum() - st[0]) <= 1e-3 * st[1] and int(np.count_nonzero(gg)) <= st[2] * 1.001 + 8\n"
-        "    print('WORST room0', layout, w)\n"
-        "    assert w <= 1e-3\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        "    print('WORST', tag, layout, w)\n"
+        "    assert w <= 1e-3\n"
+        "    del cg\n"
+        "  del model, renderer, sc\n"
+        "  torch.cuda.empty_cache()\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), tuple(scenes))
     env = dict(os.environ, **env_extra)
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert 'WORST room0 channels_last_3d' in r.stdout
+    assert all(f'WORST {tag} channels_last_3d' in r.stdout for tag, _f in scenes)
 
 
 def test_two_kernel_backward_matches_the_reference_fixtures():
@@ -273,7 +278,7 @@ def test_deferred_scatter_matches_the_reference_fixtures():
     groups, LDS table of 64-bit fixed-point sums) against the same fixtures.  Its one documented difference from float32
     accumulation -- elements below 2^-40 of a ray group's largest feature gradient come out as exact zeros -- is why the child
     bounds the non-zero count from above only."""
-    _fixture_child({'ENSLAM_DEFER_SCATTER': '1'})
+    _fixture_child({'ENSLAM_DEFER_SCATTER': '1'}, scenes=(('room0', 'room0_color1000'), ('office0', 'office0_color5000')))      # (5000 rays: five chunks of ray groups)
 
 
 def test_weight_gradients_as_partial_images_match_the_atomic_path():
