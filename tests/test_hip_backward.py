@@ -306,3 +306,18 @@ def test_weight_gradients_as_partial_images_match_the_atomic_path():
     for n, a in out[False].items():
         b = out[True][n]
         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), n
+
+
+def test_deferred_scatter_passes_the_edge_case_suites():
+    """ENSLAM_DEFER_SCATTER=1 (read once per process: a child pytest) under the suites that vary the SHAPES the scatter launch
+    sees -- ragged and empty batches, 32 / 48 / 64 samples per ray, N_surface = 0, importance sampling, rays leaving the bound,
+    both grid layouts, the device-layout mapper step -- all against the oracle / the reference fixtures with their own bars."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    suites = ['tests/test_hip_edge_cases.py', 'tests/test_hip_importance.py', 'tests/test_hip_native_grids.py', 'tests/test_hip_mapper.py']
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-p', 'no:cacheprovider'] + suites, cwd=root,
+                       env=dict(os.environ, ENSLAM_DEFER_SCATTER='1'), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
