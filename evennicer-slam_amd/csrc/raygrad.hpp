@@ -89,12 +89,13 @@ ENS_DEV void ray_grad_unit(const RayGradArgs& A, int64_t unit, int lane) {
     const float* dgw = A.dgrid_ws + (tile * ACT_SLOTS + slot_idx) * DG_STRIDE;
     const f32x4 dc0 = ld4(dgw + lane * 4), dc1 = ld4(dgw + 256 + lane * 4);
     const f32x4 dpe = ld4(dgw + DG_DPE + lane * 4);
+    // (the geometry's loads leave with the hand-off's, not behind the zero test: one memory round trip less in this latency chain)
+    const int S = 16 * A.ntl;
+    const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
     bool nz = false;
 #pragma unroll
     for (int r = 0; r < 4; ++r) nz = nz || dc0[r] != 0.f || dc1[r] != 0.f || dpe[r] != 0.f;
     if (!__any(nz)) return;
-    const int S = 16 * A.ntl;
-    const TileGeo G = tile_geo(tile, A.ntl, S, A.ro, A.rd, A.z, p);
     const Vox v = make_vox(G.pw, A.lo, A.hi, grid);
     float gx, gy, gz;
     coord_grad_partial(v, grid, q, dc0, dc1, gx, gy, gz);
