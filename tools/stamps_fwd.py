@@ -9,12 +9,13 @@ names = ["geometry + first gather", "embedding (B^T, MFMA, sin)", "ws stores emb
          "barrier + chunk wait", "output layer", "later gathers", "raw store", "-", "-", "-"]
 dev = torch.device('cuda', 0)
 sc = bench.build_scene_cpu('room0', 0)
-rays = bench.make_rays(sc, 1000, 1000)
+N = int(os.environ.get('RAYS', 1000))
+rays = bench.make_rays(sc, N, 1000)
 model = sc['model'].to(dev); bench.attach_bounds(model, sc['bound'])
 grids = {k: v.to(dev).requires_grad_(True) for k, v in sc['grids'].items()}
 ro, rd, gd, gc = [t.to(dev) for t in rays]
 renderer = E.Renderer(sc['cfg'], None, types.SimpleNamespace(nice=True, bound=sc['bound'], **bench.CAM))
-nwg = (3000 + 3) // 4
+nwg = (3 * N + 3) // 4
 buf = torch.zeros(nwg * 4 * NSEG, dtype=torch.int64, device=dev)
 handle = ctypes.CDLL(E.LIB_PATH)
 assert handle.enslam_debug_set_stamp_buffer_fwd(ctypes.c_void_p(buf.data_ptr())) == 0
@@ -24,6 +25,6 @@ for i in range(5):
 torch.cuda.synchronize()
 st = buf.cpu().numpy().reshape(nwg * 4, NSEG).astype(np.float64)
 tot = st.sum(1)
-print(f"waves {st.shape[0]}, cycles per wave mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f})")
+print(f"rays {N}: waves {st.shape[0]}, cycles per wave mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f})")
 for k in range(9):
     print(f"    {names[k]:30s} {st[:, k].mean():10.0f} cycles  {100 * st[:, k].mean() / tot.mean():5.1f} %")
