@@ -112,7 +112,7 @@ def test_tracker_process_renders_what_a_mapper_process_wrote(layout):
 def test_undeclared_direct_render_of_contiguous_shared_grids_is_the_documented_hazard():
     """Without the declaration the clone flow is still right (new tensors every frame: nothing to go stale), channels_last_3d
     grids would be too (read in place), but a DIRECT render of contiguous shared grids and shared decoders serves this process's
-    cached copies, made before the other process wrote: the result equals the OLD picture.  INTEGRATION.md section 5 names
+    cached copies, made before the other process wrote: the result equals the OLD picture.  INTEGRATION.md section 3c names
     `functional.external_writers(True)` / ENSLAM_EXTERNAL_WRITERS=1 for that case."""
     out, before, after = _run('contiguous', declare=False)
     assert _same(out['clone_before'], before) and _same(out['clone_after'], after)
