@@ -1676,6 +1676,12 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
     // whose slowest role finishes first (the proportional split wastes up to one round of the slowest role: 4-11 % at
     // 1000 rays).  Searched once per (shape, roles).
     const int groups = (int)((n_tiles + 3) / 4);
+    // With a work list the kernels walk the ACTIVE tiles only, and their number is on the device.  ENS_ACTIVE_FRACTION=f (A/B aid) lets the
+    // split search run on f x the tiles: at 0.67 the random-init bench scene gains 4.5 us (134.9 -> 130.4, five alternating pairs) and
+    // the fitted scene loses 14 (114 -> 128): the roles' relative costs move with the scene (zero feature gradients skip their atomics),
+    // so the quantisation that suits one does not suit the other.  Default: all tiles, as before.
+    static const float act_frac = [] { const char* e = getenv("ENS_ACTIVE_FRACTION"); const float f = e ? (float)atof(e) : 1.f; return f > 0.05f && f <= 1.f ? f : 1.f; }();
+    const int groups_eff = listed ? (int)(groups * act_frac + 0.5f) > 0 ? (int)(groups * act_frac + 0.5f) : 1 : groups;
     // chain waves + dW waves (decoder_bwd_split_kernel) unless ENS_SPLIT=0 selects the 4-wave kernel (A/B aid)
     static const bool use_split = [] { const char* e = getenv("ENS_SPLIT"); return e == nullptr || e[0] != '0'; }();
     // ENS_BWD2=1: the two-kernel form (render_bwd2.hip: dX-chain kernel + split-K weight-gradient kernel).  Built and parity-
@@ -1697,7 +1703,7 @@ int ens_launch_decoder_bwd(int stage, int ntl, int n_rays, const float* ro, cons
         if (key[0] == groups && key[1] == total && key[2] == mask && key[3] == stage) {
             for (int i = 0; i < 3; ++i) split[i] = cached[i];
         } else {
-            auto rounds = [&](int m) { return (groups + m - 1) / m; };
+            auto rounds = [&](int m) { return (groups_eff + m - 1) / m; };
             if (n == 1) {
                 split[0] = total;
             } else if (n == 2) {
